@@ -1,0 +1,81 @@
+"""Loader of libbp_msm_ntt.so (the C ABI of include/bp_msm_ntt.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is usable, every compute entry point
+raises.  Loading the library and resolving its symbols works without a GPU (the CPU test-suite checks
+that every symbol of the header is exported)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libbp_msm_ntt.so")
+
+BP_OK = 0
+ERRORS = {
+    -1: "BP_ERR_INVALID_ARG", -2: "BP_ERR_NOT_POW2", -3: "BP_ERR_BAD_POINT", -4: "BP_ERR_BAD_SCALAR",
+    -5: "BP_ERR_BASIS", -6: "BP_ERR_LENGTH", -7: "BP_ERR_DIV_ZERO", -8: "BP_ERR_NO_DEVICE", -9: "BP_ERR_HIP",
+    -10: "BP_ERR_TOO_LARGE",
+}
+FR_BYTES_LE, FR_MONT = 0, 1
+BASIS_LAGRANGE, BASIS_MONOMIAL = 0, 1
+
+_vp, _sz, _u64, _u32, _int, _cp = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int, C.c_char_p
+_pp = C.POINTER
+
+# name -> (restype, argtypes); mirrors include/bp_msm_ntt.h one to one
+SIGNATURES = {
+    "bp_init": (_int, [_pp(_vp), _int]),
+    "bp_destroy": (None, [_vp]),
+    "bp_last_error": (_cp, [_vp]),
+    "bp_version": (_cp, []),
+    "bp_set_stream": (_int, [_vp, _vp]),
+    "bp_synchronize": (_int, [_vp]),
+    "bp_srs_load": (_int, [_vp, _vp, _sz, _pp(_u64)]),
+    "bp_srs_generate": (_int, [_vp, _sz, _vp, _pp(_u64)]),
+    "bp_srs_generate_progression": (_int, [_vp, _sz, _vp, _vp, _pp(_u64)]),
+    "bp_srs_len": (_int, [_vp, _u64, _pp(_sz)]),
+    "bp_srs_export": (_int, [_vp, _u64, _sz, _sz, _vp]),
+    "bp_srs_free": (_int, [_vp, _u64]),
+    "bp_msm_g1": (_int, [_vp, _u64, _vp, _sz, _int, _vp]),
+    "bp_msm_g1_partial": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),
+    "bp_g1_sum_partials": (_int, [_vp, _sz, _vp]),
+    "bp_g1_partial_to_bytes96": (_int, [_vp, _vp]),
+    "bp_g1_bytes96_to_partial": (_int, [_vp, _vp]),
+    "bp_msm_last_stats": (_int, [_vp, _pp(C.c_float), _pp(C.c_float), _pp(_u64), _pp(_u32)]),
+    "bp_ntt_fr": (_int, [_vp, _vp, _u32, _int, _int, _sz, _sz]),
+    "bp_ntt_fr_device": (_int, [_vp, _vp, _u32, _int, _sz, _sz]),
+    "bp_ntt_last_stats": (_int, [_vp, _pp(C.c_float), _pp(_u32)]),
+    "bp_root_of_unity": (_int, [_u64, _int, _vp]),
+    "bp_roots_of_unity": (_int, [_vp, _u64, _int, _vp]),
+    "bp_poly_evaluate": (_int, [_vp, _vp, _sz, _int, _vp, _int, _vp]),
+    "bp_poly_add": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _int, _vp, _pp(_sz)]),
+    "bp_poly_sub": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _int, _vp, _pp(_sz)]),
+    "bp_poly_scalar_op": (_int, [_vp, _vp, _sz, _int, _vp, _int, _int, _vp]),
+    "bp_poly_mul": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _int, _vp, _pp(_sz)]),
+    "bp_poly_div": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _int, _vp, _pp(_sz)]),
+    "bp_commit": (_int, [_vp, _u64, _vp, _sz, _int, _int, _vp]),
+}
+
+_lib = None
+
+
+class BpError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__("%s failed: %s (%d)%s" % (where, ERRORS.get(code, "?"), code, (": " + detail) if detail else ""))
+
+
+def load():
+    """dlopen the HIP library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            "libbp_msm_ntt.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C baby_plonk_rust_amd/csrc`. There is no CPU fallback." % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library drift
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib

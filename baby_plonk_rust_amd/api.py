@@ -1,0 +1,352 @@
+"""Host-side mirror of the reference's interface for the hot path, on top of the C ABI.
+
+Names, argument meaning and error behaviour follow the reference (Rust) so the parity tests read like its
+own tests; where the reference panics (assert!/unwrap) these raise BpError/AssertionError.
+
+  reference (file:line)                               here
+  ---------------------------------------------------------------------------------------------
+  Setup::generate_srs(powers, tau)   setup.rs:12-31   Setup.generate_srs(powers, tau)
+  Setup::commit(&poly)               setup.rs:32-37   Setup.commit(poly)
+  BucketMSM::bucket_msm(p, s, b, c)  msm.rs:76-118    BucketMSM.bucket_msm(points, scalars, b, c)
+  ntt_381 / i_ntt_381                utils.rs:63,106  ntt_381(values) / i_ntt_381(values)
+  root_of_unity / roots_of_unity     utils.rs:39-52   root_of_unity(n) / roots_of_unity(n)
+  Polynomial{values,basis} + ops     polynomial.rs    Polynomial(values, basis) with + - * / and methods
+
+Scalars travel as numpy uint64 arrays of shape [n, 4]: the reference's Montgomery limbs (Scalar::to_array,
+scalar.rs:35-40).  Points travel in the 96-byte uncompressed encoding (g1.rs:246-260)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BASIS_LAGRANGE, BASIS_MONOMIAL, FR_BYTES_LE, FR_MONT, BpError
+
+Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+_R = pow(2, 256, Q)
+_RINV = pow(_R, Q - 2, Q)
+
+
+def scalar_from_int(v):
+    """Scalar::from / from_raw: canonical integer -> Montgomery limbs (host-side big-int, O(1))"""
+    m = (v % Q) * _R % Q
+    return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def scalar_to_int(limbs):
+    m = sum(int(x) << (64 * i) for i, x in enumerate(np.asarray(limbs, dtype=np.uint64).reshape(4)))
+    return m * _RINV % Q
+
+
+def scalars_from_ints(vals):
+    return np.stack([scalar_from_int(v) for v in vals]) if len(vals) else np.zeros((0, 4), dtype=np.uint64)
+
+
+def scalars_to_ints(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 4)
+    return [scalar_to_int(a[i]) for i in range(len(a))]
+
+
+def _fr_array(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim == 1:
+        a = a.reshape(-1, 4)
+    assert a.ndim == 2 and a.shape[1] == 4, a.shape
+    return a
+
+
+class Context:
+    """One GPU, one HIP stream (bp_ctx).  The module keeps a default context per device."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.bp_init(C.byref(h), device)
+        if rc != 0:
+            raise BpError(rc, "bp_init", "no usable GPU: this package has no CPU fallback")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc, where):
+        if rc != 0:
+            raise BpError(rc, where, (self._lib.bp_last_error(self._h) or b"").decode())
+
+    # ---- thin wrappers -----------------------------------------------------------------------
+    def srs_load(self, points96):
+        buf = np.ascontiguousarray(np.frombuffer(bytes(points96), dtype=np.uint8))
+        n, h = len(buf) // 96, C.c_uint64()
+        self.check(self._lib.bp_srs_load(self._h, buf.ctypes.data, n, C.byref(h)), "bp_srs_load")
+        return h.value
+
+    def srs_generate(self, powers, tau_int):
+        t, h = np.frombuffer((tau_int % Q).to_bytes(32, "little"), dtype=np.uint8).copy(), C.c_uint64()
+        self.check(self._lib.bp_srs_generate(self._h, powers, t.ctypes.data, C.byref(h)), "bp_srs_generate")
+        return h.value
+
+    def srs_generate_progression(self, n, a_int, d_int):
+        a = np.frombuffer((a_int % Q).to_bytes(32, "little"), dtype=np.uint8).copy()
+        d = np.frombuffer((d_int % Q).to_bytes(32, "little"), dtype=np.uint8).copy()
+        h = C.c_uint64()
+        self.check(self._lib.bp_srs_generate_progression(self._h, n, a.ctypes.data, d.ctypes.data, C.byref(h)),
+                   "bp_srs_generate_progression")
+        return h.value
+
+    def srs_len(self, handle):
+        n = C.c_size_t()
+        self.check(self._lib.bp_srs_len(self._h, handle, C.byref(n)), "bp_srs_len")
+        return n.value
+
+    def srs_export(self, handle, first=0, n=None):
+        n = self.srs_len(handle) - first if n is None else n
+        out = np.zeros(96 * n, dtype=np.uint8)
+        self.check(self._lib.bp_srs_export(self._h, handle, first, n, out.ctypes.data), "bp_srs_export")
+        return bytes(out)
+
+    def srs_free(self, handle):
+        self.check(self._lib.bp_srs_free(self._h, handle), "bp_srs_free")
+
+    def msm(self, handle, scalars, fmt=FR_MONT):
+        s = _fr_array(scalars) if fmt == FR_MONT else np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        out = np.zeros(96, dtype=np.uint8)
+        self.check(self._lib.bp_msm_g1(self._h, handle, s.ctypes.data, len(s), fmt, out.ctypes.data), "bp_msm_g1")
+        return bytes(out)
+
+    def msm_partial(self, handle, scalars, first=0, fmt=FR_MONT, device_ptr=None, n=None):
+        """144-byte projective partial over SRS[first:first+n]; scalars = host array or (device_ptr, n)"""
+        out = np.zeros(144, dtype=np.uint8)
+        if device_ptr is not None:
+            rc = self._lib.bp_msm_g1_partial(self._h, handle, first, device_ptr, n, fmt, 1, out.ctypes.data)
+        else:
+            s = _fr_array(scalars)
+            rc = self._lib.bp_msm_g1_partial(self._h, handle, first, s.ctypes.data, len(s), fmt, 0, out.ctypes.data)
+        self.check(rc, "bp_msm_g1_partial")
+        return bytes(out)
+
+    def msm_stats(self):
+        a, t, adds, c = C.c_float(), C.c_float(), C.c_uint64(), C.c_uint32()
+        self.check(self._lib.bp_msm_last_stats(self._h, C.byref(a), C.byref(t), C.byref(adds), C.byref(c)), "bp_msm_last_stats")
+        return {"accumulate_ms": a.value, "device_ms": t.value, "mixed_adds": adds.value, "window_bits": c.value}
+
+    def ntt(self, values, inverse=False, fmt=FR_MONT):
+        """one vector; raises like the reference's assert!(is_power_of_two(n)) (utils.rs:65,108)"""
+        a = _fr_array(values).copy()
+        n = len(a)
+        if n == 0 or n & (n - 1):
+            raise BpError(-2, "ntt_381", "length %d is not a power of two" % n)
+        self.check(self._lib.bp_ntt_fr(self._h, a.ctypes.data, n.bit_length() - 1, int(inverse), fmt, 1, n), "bp_ntt_fr")
+        return a
+
+    def ntt_batch(self, values, inverse=False, stride=None, fmt=FR_MONT):
+        """values [batch, stride, 4]: transforms the first 2^k entries of every row (independent columns)"""
+        a = np.ascontiguousarray(values, dtype=np.uint64).copy()
+        assert a.ndim == 3 and a.shape[2] == 4
+        batch, row = a.shape[0], a.shape[1]
+        n = stride if stride is not None else row
+        if n == 0 or n & (n - 1) or n > row:
+            raise BpError(-2, "ntt_381", "length %d is not a power of two" % n)
+        self.check(self._lib.bp_ntt_fr(self._h, a.ctypes.data, n.bit_length() - 1, int(inverse), fmt, batch, row), "bp_ntt_fr")
+        return a
+
+    def ntt_device(self, ptr, log_n, inverse=False, batch=1, stride=None):
+        self.check(self._lib.bp_ntt_fr_device(self._h, ptr, log_n, int(inverse), batch, stride if stride else (1 << log_n)),
+                   "bp_ntt_fr_device")
+
+    def ntt_stats(self):
+        ms, p = C.c_float(), C.c_uint32()
+        self.check(self._lib.bp_ntt_last_stats(self._h, C.byref(ms), C.byref(p)), "bp_ntt_last_stats")
+        return {"device_ms": ms.value, "passes": p.value}
+
+    def set_stream(self, stream_ptr):
+        self.check(self._lib.bp_set_stream(self._h, stream_ptr), "bp_set_stream")
+
+    def synchronize(self):
+        self.check(self._lib.bp_synchronize(self._h), "bp_synchronize")
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def sum_partials(partials144):
+    """host-side: add 144-byte projective partials and return the 96-byte affine encoding"""
+    lib = _lib.load()
+    buf = np.ascontiguousarray(np.frombuffer(bytes(partials144), dtype=np.uint8))
+    out = np.zeros(96, dtype=np.uint8)
+    rc = lib.bp_g1_sum_partials(buf.ctypes.data, len(buf) // 144, out.ctypes.data)
+    if rc != 0:
+        raise BpError(rc, "bp_g1_sum_partials")
+    return bytes(out)
+
+
+def bytes96_to_partial(b96):
+    lib = _lib.load()
+    src, out = np.frombuffer(bytes(b96), dtype=np.uint8).copy(), np.zeros(144, dtype=np.uint8)
+    rc = lib.bp_g1_bytes96_to_partial(src.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise BpError(rc, "bp_g1_bytes96_to_partial")
+    return bytes(out)
+
+
+# ------------------------------------------------------------------------------------------------
+# reference-shaped API
+# ------------------------------------------------------------------------------------------------
+def root_of_unity(group_order, ctx=None):
+    """utils.rs:39-43"""
+    lib = _lib.load()
+    out = np.zeros(4, dtype=np.uint64)
+    rc = lib.bp_root_of_unity(group_order, FR_MONT, out.ctypes.data)
+    if rc != 0:
+        raise BpError(rc, "root_of_unity")
+    return out
+
+
+def roots_of_unity(group_order, ctx=None):
+    """utils.rs:45-52"""
+    ctx = ctx or default_context()
+    out = np.zeros((group_order, 4), dtype=np.uint64)
+    ctx.check(ctx._lib.bp_roots_of_unity(ctx._h, group_order, FR_MONT, out.ctypes.data), "roots_of_unity")
+    return out
+
+
+def ntt_381(elements, ctx=None):
+    """utils.rs:63-81: natural-order DFT; asserts a power-of-two length"""
+    return (ctx or default_context()).ntt(elements, inverse=False)
+
+
+def i_ntt_381(elements, ctx=None):
+    """utils.rs:106-129: inverse DFT including the 1/n factor"""
+    return (ctx or default_context()).ntt(elements, inverse=True)
+
+
+class BucketMSM:
+    """src/msm.rs:8"""
+
+    @staticmethod
+    def bucket_msm(points96, scalars, b=256, c=4, ctx=None):
+        """msm.rs:76-118.  points96: concatenated 96-byte encodings; scalars [n,4] Montgomery limbs.
+        (b, c) are accepted for signature parity; they do not change the group element."""
+        ctx = ctx or default_context()
+        h = ctx.srs_load(points96)
+        try:
+            return ctx.msm(h, scalars)
+        finally:
+            ctx.srs_free(h)
+
+
+class Polynomial:
+    """polynomial.rs:14-17; value semantics (every operator returns a new object)"""
+
+    def __init__(self, values, basis, ctx=None):
+        self.values = _fr_array(values).copy() if len(values) else np.zeros((0, 4), dtype=np.uint64)
+        assert basis in (BASIS_LAGRANGE, BASIS_MONOMIAL)
+        self.basis = basis
+        self.ctx = ctx or default_context()
+
+    def __len__(self):
+        return len(self.values)
+
+    def __eq__(self, other):
+        return self.basis == other.basis and self.values.shape == other.values.shape and bool((self.values == other.values).all())
+
+    def _binop(self, other, fn, name):
+        if self.basis != other.basis:
+            raise BpError(-5, name, "Basis must be the same")
+        out = np.zeros((max(len(self) + len(other), 1), 4), dtype=np.uint64)
+        n = C.c_size_t()
+        c = self.ctx
+        c.check(fn(c._h, self.values.ctypes.data, len(self), other.values.ctypes.data, len(other), self.basis, FR_MONT,
+                   out.ctypes.data, C.byref(n)), name)
+        return Polynomial(out[: n.value], self.basis, c)
+
+    def _scalar(self, s, op, name):
+        s = np.ascontiguousarray(s, dtype=np.uint64).reshape(4)
+        out = np.zeros_like(self.values)
+        c = self.ctx
+        c.check(c._lib.bp_poly_scalar_op(c._h, self.values.ctypes.data, len(self), self.basis, s.ctypes.data, op, FR_MONT,
+                                         out.ctypes.data), name)
+        return Polynomial(out, self.basis, c)
+
+    def __add__(self, other):            # polynomial.rs:57-117
+        if isinstance(other, Polynomial):
+            return self._binop(other, self.ctx._lib.bp_poly_add, "Polynomial + Polynomial")
+        return self._scalar(other, 0, "Polynomial + Scalar")
+
+    def __sub__(self, other):            # polynomial.rs:119-174
+        if isinstance(other, Polynomial):
+            return self._binop(other, self.ctx._lib.bp_poly_sub, "Polynomial - Polynomial")
+        return self._scalar(other, 1, "Polynomial - Scalar")
+
+    def __mul__(self, other):            # polynomial.rs:176-312
+        if isinstance(other, Polynomial):
+            return self._binop(other, self.ctx._lib.bp_poly_mul, "Polynomial * Polynomial")
+        return self._scalar(other, 2, "Polynomial * Scalar")
+
+    def __truediv__(self, other):        # polynomial.rs:314-380
+        return self._binop(other, self.ctx._lib.bp_poly_div, "Polynomial / Polynomial")
+
+    def coeffs_evaluate(self, x):        # polynomial.rs:34-45
+        x = np.ascontiguousarray(x, dtype=np.uint64).reshape(4)
+        out = np.zeros(4, dtype=np.uint64)
+        c = self.ctx
+        c.check(c._lib.bp_poly_evaluate(c._h, self.values.ctypes.data, len(self), self.basis, x.ctypes.data, FR_MONT,
+                                        out.ctypes.data), "coeffs_evaluate")
+        return out
+
+    def ntt(self):                       # polynomial.rs:47-51
+        if self.basis != BASIS_MONOMIAL:
+            raise BpError(-5, "Polynomial.ntt", "needs the Monomial basis")
+        return Polynomial(self.ctx.ntt(self.values, inverse=False), BASIS_LAGRANGE, self.ctx)
+
+    def i_ntt(self):                     # polynomial.rs:52-55
+        if self.basis != BASIS_LAGRANGE:
+            raise BpError(-5, "Polynomial.i_ntt", "needs the Lagrange basis")
+        return Polynomial(self.ctx.ntt(self.values, inverse=True), BASIS_MONOMIAL, self.ctx)
+
+    def shift_left(self, n):             # polynomial.rs:22-33 (index permutation, host side)
+        if self.basis != BASIS_LAGRANGE:
+            raise BpError(-5, "Polynomial.shift_left", "needs the Lagrange basis")
+        return np.roll(self.values, -(n % len(self)), axis=0)
+
+
+class Setup:
+    """src/setup.rs:7-10 (G1 part; x_2 in G2 belongs to the verifier's pairing, out of scope)"""
+
+    def __init__(self, handle, ctx):
+        self.handle, self.ctx = handle, ctx
+
+    @staticmethod
+    def generate_srs(powers, tau_int, ctx=None):
+        """setup.rs:12-31: [G, tau G, ..., tau^(powers-1) G], generated and kept on the GPU"""
+        ctx = ctx or default_context()
+        return Setup(ctx.srs_generate(powers, tau_int), ctx)
+
+    @staticmethod
+    def from_points(points96, ctx=None):
+        ctx = ctx or default_context()
+        return Setup(ctx.srs_load(points96), ctx)
+
+    def powers_of_x(self):
+        return self.ctx.srs_export(self.handle)
+
+    def commit(self, polynomial):
+        """setup.rs:32-37: asserts the Monomial basis, then bucket_msm over the whole SRS"""
+        c = self.ctx
+        out = np.zeros(96, dtype=np.uint8)
+        c.check(c._lib.bp_commit(c._h, self.handle, polynomial.values.ctypes.data, len(polynomial), polynomial.basis, FR_MONT,
+                                 out.ctypes.data), "Setup.commit")
+        return bytes(out)

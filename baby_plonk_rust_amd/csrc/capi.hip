@@ -1,0 +1,571 @@
+// capi.hip -- the C ABI of include/bp_msm_ntt.h: context management, host<->HBM staging, the O(1)/O(W)
+// host epilogues (Horner over window sums, affine normalisation, wire encodings).  All O(N) work runs in
+// the HIP kernels of msm.hip / ntt.hip / poly.hip / srs.hip; there is no CPU fallback for it.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "ctx.hpp"
+
+using namespace bp;
+
+namespace bp {
+
+int fail(bp_ctx* ctx, int code, const char* what, hipError_t e, const char* file, int line) {
+  if (ctx) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s%s%s (%s:%d)", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "", file,
+             line);
+    ctx->last_error = buf;
+  }
+  return code;
+}
+
+int ws_get(bp_ctx* ctx, const char* name, size_t bytes, void** out) {
+  DevBuf& b = ctx->ws[name];
+  if (bytes == 0) bytes = 16;
+  if (b.cap < bytes) {
+    if (b.p) {
+      BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      BP_HIP(ctx, hipFree(b.p));
+      b.p = nullptr;
+      b.cap = 0;
+    }
+    size_t cap = (bytes + 255) & ~(size_t)255;
+    BP_HIP(ctx, hipMalloc(&b.p, cap));
+    b.cap = cap;
+  }
+  *out = b.p;
+  return BP_OK;
+}
+
+int pinned_get(bp_ctx* ctx, size_t bytes, void** out) {
+  if (ctx->pinned_cap < bytes) {
+    if (ctx->pinned) BP_HIP(ctx, hipHostFree(ctx->pinned));
+    ctx->pinned = nullptr;
+    ctx->pinned_cap = 0;
+    size_t cap = std::max<size_t>(bytes, 64 * 1024);
+    BP_HIP(ctx, hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
+    ctx->pinned_cap = cap;
+  }
+  *out = ctx->pinned;
+  return BP_OK;
+}
+
+// result = sum_w 2^(c*w) * T_w, most significant window first (the reference's combine, msm.rs:107-115)
+void host_horner(g1_proj& out, const g1_proj* window_sums, uint32_t W, uint32_t c) {
+  g1_proj acc = window_sums[W - 1];
+  for (uint32_t w = W - 1; w-- > 0;) {
+    for (uint32_t d = 0; d < c; d++) g1_double(acc, acc);
+    g1_add(acc, acc, window_sums[w]);
+  }
+  out = acc;
+}
+
+static void fp_to_be48_host(uint8_t* b, const fp_t& a) {
+  for (int i = 0; i < 12; i++) {
+    uint8_t* p = b + 4 * (11 - i);
+    p[0] = (uint8_t)(a.l[i] >> 24); p[1] = (uint8_t)(a.l[i] >> 16); p[2] = (uint8_t)(a.l[i] >> 8); p[3] = (uint8_t)a.l[i];
+  }
+}
+static fp_t fp_from_be48_host(const uint8_t* b) {
+  fp_t r;
+  for (int i = 0; i < 12; i++) {
+    const uint8_t* p = b + 4 * (11 - i);
+    r.l[i] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+  }
+  return r;
+}
+// G1Affine::from(p).to_uncompressed()  (g1.rs:49-63, 246-260)
+void host_encode96(uint8_t out96[96], const g1_proj& p) {
+  memset(out96, 0, 96);
+  if (g1_is_identity(p)) {
+    out96[0] = 0x40;
+    return;
+  }
+  g1_affine a = g1_to_affine(p);
+  fp_t x, y;
+  Fp::from_mont(x, a.x);
+  Fp::from_mont(y, a.y);
+  fp_to_be48_host(out96, x);
+  fp_to_be48_host(out96 + 48, y);
+}
+// G1Affine::from_uncompressed_unchecked (g1.rs:273-322) without the curve check
+bool host_decode96(g1_proj& out, const uint8_t in96[96]) {
+  uint8_t buf[96];
+  memcpy(buf, in96, 96);
+  const uint32_t flags = buf[0] >> 5;
+  buf[0] &= 0x1f;
+  fp_t x = fp_from_be48_host(buf), y = fp_from_be48_host(buf + 48), t;
+  if (!big_sub(t, x, Fp::modulus()) || !big_sub(t, y, Fp::modulus())) return false;
+  if (flags & 0b101) return false;
+  if (flags & 0b010) {
+    if (!big_is_zero(x) || !big_is_zero(y)) return false;
+    out = g1_identity();
+    return true;
+  }
+  Fp::to_mont(out.x, x);
+  Fp::to_mont(out.y, y);
+  out.z = Fp::one();
+  return true;
+}
+
+}  // namespace bp
+
+// ------------------------------------------------------------------------------------------------------
+static bool fr_bytes_to_mont(fr_t& out, const uint8_t* b32, int fmt) {
+  fr_t v;
+  memcpy(&v, b32, 32);
+  if (fmt == BP_FR_MONT) {
+    out = v;
+    return true;
+  }
+  fr_t t;
+  if (!big_sub(t, v, Fr::modulus())) return false;       // >= q: Scalar::from_bytes rejects (scalar.rs:264-288)
+  Fr::to_mont(out, v);
+  return true;
+}
+static void fr_mont_to_bytes(uint8_t* b32, const fr_t& v, int fmt) {
+  fr_t t = v;
+  if (fmt == BP_FR_BYTES_LE) Fr::from_mont(t, v);
+  memcpy(b32, &t, 32);
+}
+static bool fmt_ok(int fmt) { return fmt == BP_FR_BYTES_LE || fmt == BP_FR_MONT; }
+static bool basis_ok(int b) { return b == BP_BASIS_LAGRANGE || b == BP_BASIS_MONOMIAL; }
+
+// upload n scalars to workspace `name`, converting to Montgomery form on the device if needed
+static int upload_fr(bp_ctx* ctx, const char* name, const void* host, size_t n, size_t cap_elems, int fmt, fr_t** out) {
+  fr_t* d;
+  BP_TRY(ws_get(ctx, name, std::max(cap_elems, n) * sizeof(fr_t), (void**)&d));
+  if (n) BP_HIP(ctx, hipMemcpyAsync(d, host, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+  if (fmt == BP_FR_BYTES_LE) BP_TRY(fr_convert_run(ctx, d, n, 0));
+  *out = d;
+  return BP_OK;
+}
+static int download_fr(bp_ctx* ctx, fr_t* d, void* host, size_t n, int fmt) {
+  if (n == 0) return BP_OK;
+  if (fmt == BP_FR_BYTES_LE) BP_TRY(fr_convert_run(ctx, d, n, 1));
+  BP_HIP(ctx, hipMemcpyAsync(host, d, n * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+extern "C" {
+
+const char* bp_version(void) { return "bp_msm_ntt 0.1 (gfx950)"; }
+
+int bp_init(bp_ctx** out, int device_id) {
+  if (!out) return BP_ERR_INVALID_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return BP_ERR_NO_DEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return BP_ERR_NO_DEVICE;
+  bp_ctx* ctx = new bp_ctx();
+  ctx->device = device_id;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return BP_ERR_NO_DEVICE;
+  }
+  for (auto& e : ctx->ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      delete ctx;
+      return BP_ERR_NO_DEVICE;
+    }
+  int rc = ntt_init_tables(ctx);
+  if (rc != BP_OK) {
+    fprintf(stderr, "bp_init: %s\n", ctx->last_error.c_str());
+    delete ctx;
+    return rc;
+  }
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    delete ctx;
+    return BP_ERR_HIP;
+  }
+  *out = ctx;
+  return BP_OK;
+}
+
+void bp_destroy(bp_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->ws)
+    if (kv.second.p) (void)hipFree(kv.second.p);
+  for (auto& kv : ctx->srs)
+    if (kv.second.d_points) (void)hipFree(kv.second.d_points);
+  for (auto& kv : ctx->ntt_tables) {
+    (void)hipFree(kv.second.lo);
+    (void)hipFree(kv.second.hi);
+    if (kv.second.hi_scaled) (void)hipFree(kv.second.hi_scaled);
+    if (kv.second.n_inv) (void)hipFree(kv.second.n_inv);
+  }
+  for (auto& t : ctx->small_tw)
+    if (t) (void)hipFree(t);
+  for (auto& e : ctx->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* bp_last_error(bp_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int bp_set_stream(bp_ctx* ctx, void* hip_stream) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hip_stream == nullptr) {
+    if (!ctx->own_stream) {
+      BP_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = true;
+    }
+    return BP_OK;
+  }
+  if (ctx->own_stream) BP_HIP(ctx, hipStreamDestroy(ctx->stream));
+  ctx->stream = (hipStream_t)hip_stream;
+  ctx->own_stream = false;
+  return BP_OK;
+}
+
+int bp_synchronize(bp_ctx* ctx) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- SRS
+static int srs_register(bp_ctx* ctx, g1_affine* d, size_t n, uint64_t* handle) {
+  SrsEntry e;
+  e.d_points = d;
+  e.n = n;
+  *handle = ctx->next_handle++;
+  ctx->srs[*handle] = e;
+  return BP_OK;
+}
+static int srs_find(bp_ctx* ctx, uint64_t handle, SrsEntry** out) {
+  auto it = ctx->srs.find(handle);
+  if (it == ctx->srs.end()) return fail(ctx, BP_ERR_INVALID_ARG, "unknown SRS handle", hipSuccess, __FILE__, __LINE__);
+  *out = &it->second;
+  return BP_OK;
+}
+
+int bp_srs_load(bp_ctx* ctx, const uint8_t* points96, size_t n, uint64_t* srs_handle) {
+  if (!ctx || !srs_handle || (n && !points96)) return BP_ERR_INVALID_ARG;
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  uint8_t* d_bytes;
+  BP_TRY(ws_get(ctx, "io.bytes", n * 96, (void**)&d_bytes));
+  g1_affine* d_pts = nullptr;
+  BP_HIP(ctx, hipMalloc((void**)&d_pts, std::max<size_t>(n, 1) * sizeof(g1_affine)));
+  if (n) BP_HIP(ctx, hipMemcpyAsync(d_bytes, points96, n * 96, hipMemcpyHostToDevice, ctx->stream));
+  int rc = srs_decode_run(ctx, d_bytes, n, d_pts);
+  if (rc != BP_OK) {
+    (void)hipFree(d_pts);
+    return rc;
+  }
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return srs_register(ctx, d_pts, n, srs_handle);
+}
+
+static int srs_generate_common(bp_ctx* ctx, size_t n, const uint8_t a32[32], const uint8_t d32[32], int mode, uint64_t* handle) {
+  if (!ctx || !handle || !a32 || (mode == 1 && !d32)) return BP_ERR_INVALID_ARG;
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  fr_t a, d = Fr::zero();
+  if (!fr_bytes_to_mont(a, a32, BP_FR_BYTES_LE)) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q", hipSuccess, __FILE__, __LINE__);
+  if (mode == 1 && !fr_bytes_to_mont(d, d32, BP_FR_BYTES_LE)) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q", hipSuccess, __FILE__, __LINE__);
+  g1_affine* d_pts = nullptr;
+  BP_HIP(ctx, hipMalloc((void**)&d_pts, std::max<size_t>(n, 1) * sizeof(g1_affine)));
+  int rc = srs_generate_run(ctx, a, d, mode, n, d_pts);
+  if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BP_ERR_HIP;
+  if (rc != BP_OK) {
+    (void)hipFree(d_pts);
+    return rc;
+  }
+  return srs_register(ctx, d_pts, n, handle);
+}
+int bp_srs_generate(bp_ctx* ctx, size_t powers, const uint8_t tau32[32], uint64_t* srs_handle) {
+  return srs_generate_common(ctx, powers, tau32, nullptr, 0, srs_handle);
+}
+int bp_srs_generate_progression(bp_ctx* ctx, size_t n, const uint8_t a32[32], const uint8_t d32[32], uint64_t* srs_handle) {
+  return srs_generate_common(ctx, n, a32, d32, 1, srs_handle);
+}
+
+int bp_srs_len(bp_ctx* ctx, uint64_t srs_handle, size_t* n) {
+  if (!ctx || !n) return BP_ERR_INVALID_ARG;
+  SrsEntry* e;
+  BP_TRY(srs_find(ctx, srs_handle, &e));
+  *n = e->n;
+  return BP_OK;
+}
+
+int bp_srs_export(bp_ctx* ctx, uint64_t srs_handle, size_t first, size_t n, uint8_t* points96) {
+  if (!ctx || (n && !points96)) return BP_ERR_INVALID_ARG;
+  SrsEntry* e;
+  BP_TRY(srs_find(ctx, srs_handle, &e));
+  if (first > e->n || n > e->n - first) return fail(ctx, BP_ERR_INVALID_ARG, "SRS range out of bounds", hipSuccess, __FILE__, __LINE__);
+  if (n == 0) return BP_OK;
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  uint8_t* d_bytes;
+  BP_TRY(ws_get(ctx, "io.bytes", n * 96, (void**)&d_bytes));
+  BP_TRY(srs_encode_run(ctx, e->d_points + first, n, d_bytes));
+  BP_HIP(ctx, hipMemcpyAsync(points96, d_bytes, n * 96, hipMemcpyDeviceToHost, ctx->stream));
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+int bp_srs_free(bp_ctx* ctx, uint64_t srs_handle) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  SrsEntry* e;
+  BP_TRY(srs_find(ctx, srs_handle, &e));
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, hipFree(e->d_points));
+  ctx->srs.erase(srs_handle);
+  return BP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- MSM
+int bp_msm_g1_partial(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
+                      int scalars_on_device, uint8_t out144[144]) {
+  if (!ctx || !out144 || !fmt_ok(scalar_fmt) || (n_scalars && !scalars)) return BP_ERR_INVALID_ARG;
+  SrsEntry* e;
+  BP_TRY(srs_find(ctx, srs_handle, &e));
+  if (first > e->n) return fail(ctx, BP_ERR_INVALID_ARG, "SRS offset out of bounds", hipSuccess, __FILE__, __LINE__);
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = std::min(n_scalars, e->n - first);          // zip() truncation, msm.rs:29
+  const fr_t* d_scalars = (const fr_t*)scalars;
+  if (!scalars_on_device) {
+    fr_t* d;
+    BP_TRY(ws_get(ctx, "io.scalars", n * sizeof(fr_t), (void**)&d));
+    if (n) BP_HIP(ctx, hipMemcpyAsync(d, scalars, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    d_scalars = d;
+  }
+  g1_proj r;
+  BP_TRY(msm_run(ctx, e->d_points + first, n, d_scalars, scalar_fmt, &r));
+  memcpy(out144, &r, 144);
+  return BP_OK;
+}
+
+int bp_msm_g1(bp_ctx* ctx, uint64_t srs_handle, const void* scalars, size_t n_scalars, int scalar_fmt, uint8_t out96[96]) {
+  if (!out96) return BP_ERR_INVALID_ARG;
+  uint8_t part[144];
+  BP_TRY(bp_msm_g1_partial(ctx, srs_handle, 0, scalars, n_scalars, scalar_fmt, 0, part));
+  g1_proj r;
+  memcpy(&r, part, 144);
+  host_encode96(out96, r);
+  return BP_OK;
+}
+
+int bp_g1_sum_partials(const uint8_t* partials144, size_t n, uint8_t out96[96]) {
+  if (!out96 || (n && !partials144)) return BP_ERR_INVALID_ARG;
+  g1_proj acc = g1_identity();
+  for (size_t i = 0; i < n; i++) {
+    g1_proj p;
+    memcpy(&p, partials144 + 144 * i, 144);
+    g1_add(acc, acc, p);
+  }
+  host_encode96(out96, acc);
+  return BP_OK;
+}
+int bp_g1_partial_to_bytes96(const uint8_t in144[144], uint8_t out96[96]) { return bp_g1_sum_partials(in144, 1, out96); }
+int bp_g1_bytes96_to_partial(const uint8_t in96[96], uint8_t out144[144]) {
+  if (!in96 || !out144) return BP_ERR_INVALID_ARG;
+  g1_proj p;
+  if (!host_decode96(p, in96)) return BP_ERR_BAD_POINT;
+  memcpy(out144, &p, 144);
+  return BP_OK;
+}
+
+int bp_msm_last_stats(bp_ctx* ctx, float* accumulate_ms, float* total_device_ms, uint64_t* mixed_adds, uint32_t* window_bits) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  if (accumulate_ms) *accumulate_ms = ctx->msm_accumulate_ms;
+  if (total_device_ms) *total_device_ms = ctx->msm_total_ms;
+  if (mixed_adds) *mixed_adds = ctx->msm_adds;
+  if (window_bits) *window_bits = ctx->msm_c;
+  return BP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- DFT
+int bp_ntt_fr_device(bp_ctx* ctx, void* d_data, uint32_t log_n, int inverse, size_t batch, size_t stride) {
+  if (!ctx || (!d_data && batch)) return BP_ERR_INVALID_ARG;
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  BP_TRY(ntt_run(ctx, (fr_t*)d_data, log_n, inverse, batch, stride));
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, hipEventElapsedTime(&ctx->ntt_ms, ctx->ev[0], ctx->ev[1]));
+  return BP_OK;
+}
+
+int bp_ntt_fr(bp_ctx* ctx, void* data, uint32_t log_n, int inverse, int scalar_fmt, size_t batch, size_t stride) {
+  if (!ctx || !fmt_ok(scalar_fmt) || (!data && batch)) return BP_ERR_INVALID_ARG;
+  if (log_n > 28) return fail(ctx, BP_ERR_TOO_LARGE, "NTT length > 2^28", hipSuccess, __FILE__, __LINE__);
+  if (batch == 0) return BP_OK;
+  const size_t N = (size_t)1 << log_n;
+  if (batch > 1 && stride < N) return fail(ctx, BP_ERR_INVALID_ARG, "NTT stride < N", hipSuccess, __FILE__, __LINE__);
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t span = (batch - 1) * stride + N;
+  fr_t* d;
+  BP_TRY(upload_fr(ctx, "io.ntt", data, span, span, scalar_fmt, &d));
+  BP_TRY(ntt_run(ctx, d, log_n, inverse, batch, stride));
+  BP_TRY(download_fr(ctx, d, data, span, scalar_fmt));
+  BP_HIP(ctx, hipEventElapsedTime(&ctx->ntt_ms, ctx->ev[0], ctx->ev[1]));
+  return BP_OK;
+}
+
+int bp_ntt_last_stats(bp_ctx* ctx, float* device_ms, uint32_t* passes) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  if (device_ms) *device_ms = ctx->ntt_ms;
+  if (passes) *passes = ctx->ntt_passes;
+  return BP_OK;
+}
+
+// utils.rs:39-43: ROOT_OF_UNITY.pow([2^32 / group_order, 0, 0, 0]) -- integer division, as written
+static bool host_root_of_unity(fr_t& out, uint64_t group_order) {
+  if (group_order == 0) return false;                       // division by zero panics in the reference
+  const uint64_t e = ((uint64_t)1 << 32) / group_order;
+  uint32_t e32[2] = {(uint32_t)e, (uint32_t)(e >> 32)};
+  Fr::pow(out, fr_root_of_unity(false), e32, 2);
+  return true;
+}
+int bp_root_of_unity(uint64_t group_order, int scalar_fmt, uint8_t out32[32]) {
+  if (!out32 || !fmt_ok(scalar_fmt)) return BP_ERR_INVALID_ARG;
+  fr_t w;
+  if (!host_root_of_unity(w, group_order)) return BP_ERR_INVALID_ARG;
+  fr_mont_to_bytes(out32, w, scalar_fmt);
+  return BP_OK;
+}
+int bp_roots_of_unity(bp_ctx* ctx, uint64_t group_order, int scalar_fmt, void* out) {
+  if (!ctx || !out || !fmt_ok(scalar_fmt)) return BP_ERR_INVALID_ARG;
+  fr_t w;
+  if (!host_root_of_unity(w, group_order)) return fail(ctx, BP_ERR_INVALID_ARG, "group_order == 0", hipSuccess, __FILE__, __LINE__);
+  if (group_order > ((uint64_t)1 << 28)) return fail(ctx, BP_ERR_TOO_LARGE, "group_order > 2^28", hipSuccess, __FILE__, __LINE__);
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  fr_t* d;
+  BP_TRY(ws_get(ctx, "io.roots", group_order * sizeof(fr_t), (void**)&d));
+  BP_TRY(roots_run(ctx, w, group_order, d));
+  return download_fr(ctx, d, out, group_order, scalar_fmt);
+}
+
+// ---------------------------------------------------------------------------------------------- Polynomial
+int bp_poly_evaluate(bp_ctx* ctx, const void* coeffs, size_t n, int basis, const void* x32, int scalar_fmt, void* out32) {
+  if (!ctx || !x32 || !out32 || !fmt_ok(scalar_fmt) || !basis_ok(basis) || (n && !coeffs)) return BP_ERR_INVALID_ARG;
+  if (basis != BP_BASIS_MONOMIAL) return fail(ctx, BP_ERR_BASIS, "coeffs_evaluate needs the Monomial basis", hipSuccess, __FILE__, __LINE__);
+  fr_t x, r;
+  if (!fr_bytes_to_mont(x, (const uint8_t*)x32, scalar_fmt)) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q", hipSuccess, __FILE__, __LINE__);
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  fr_t* d;
+  BP_TRY(upload_fr(ctx, "io.poly_a", coeffs, n, n, scalar_fmt, &d));
+  BP_TRY(poly_eval_run(ctx, d, n, x, &r));
+  fr_mont_to_bytes((uint8_t*)out32, r, scalar_fmt);
+  return BP_OK;
+}
+
+static int poly_addsub(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb, int basis, int fmt, void* out, size_t* n_out,
+                       int op) {
+  if (!ctx || !n_out || !fmt_ok(fmt) || !basis_ok(basis) || (na && !a) || (nb && !b)) return BP_ERR_INVALID_ARG;
+  if (basis == BP_BASIS_LAGRANGE && na != nb)
+    return fail(ctx, BP_ERR_LENGTH, "Polynomials must have the same length", hipSuccess, __FILE__, __LINE__);
+  const size_t n = std::max(na, nb);
+  *n_out = n;
+  if (n == 0) return BP_OK;
+  if (!out) return BP_ERR_INVALID_ARG;
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  fr_t *da, *db, *dout;
+  // add/sub commute with the Montgomery map, so canonical inputs need no conversion at all
+  BP_TRY(upload_fr(ctx, "io.poly_a", a, na, na, BP_FR_MONT, &da));
+  BP_TRY(upload_fr(ctx, "io.poly_b", b, nb, nb, BP_FR_MONT, &db));
+  BP_TRY(ws_get(ctx, "io.poly_out", n * sizeof(fr_t), (void**)&dout));
+  BP_TRY(fr_binary_run(ctx, da, na, db, nb, dout, n, op));
+  return download_fr(ctx, dout, out, n, BP_FR_MONT);
+}
+int bp_poly_add(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb, int basis, int scalar_fmt, void* out, size_t* n_out) {
+  return poly_addsub(ctx, a, na, b, nb, basis, scalar_fmt, out, n_out, 0);
+}
+int bp_poly_sub(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb, int basis, int scalar_fmt, void* out, size_t* n_out) {
+  return poly_addsub(ctx, a, na, b, nb, basis, scalar_fmt, out, n_out, 1);
+}
+
+int bp_poly_scalar_op(bp_ctx* ctx, const void* a, size_t n, int basis, const void* s32, int op, int scalar_fmt, void* out) {
+  if (!ctx || !s32 || !fmt_ok(scalar_fmt) || !basis_ok(basis) || op < 0 || op > 2 || (n && (!a || !out))) return BP_ERR_INVALID_ARG;
+  // Monomial Add/Sub<Scalar> index values[0] (polynomial.rs:62,123): an empty polynomial panics there
+  if (n == 0) return op == 2 || basis == BP_BASIS_LAGRANGE ? BP_OK
+                                                           : fail(ctx, BP_ERR_INVALID_ARG, "empty polynomial", hipSuccess, __FILE__, __LINE__);
+  fr_t s;
+  if (!fr_bytes_to_mont(s, (const uint8_t*)s32, scalar_fmt)) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q", hipSuccess, __FILE__, __LINE__);
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  fr_t *da, *dout;
+  BP_TRY(upload_fr(ctx, "io.poly_a", a, n, n, scalar_fmt, &da));
+  BP_TRY(ws_get(ctx, "io.poly_out", n * sizeof(fr_t), (void**)&dout));
+  if (op == 2) {
+    BP_TRY(fr_scalar_run(ctx, da, s, dout, n, 2));
+  } else if (basis == BP_BASIS_MONOMIAL) {
+    BP_HIP(ctx, hipMemcpyAsync(dout, da, n * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
+    BP_TRY(fr_scalar_run(ctx, da, s, dout, 1, op));          // values[0] += / -= rhs
+  } else {
+    BP_TRY(fr_scalar_run(ctx, da, s, dout, n, 0));           // Lagrange: += rhs for Add AND Sub (polynomial.rs:126-128)
+  }
+  return download_fr(ctx, dout, out, n, scalar_fmt);
+}
+
+int bp_poly_mul(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb, int basis, int scalar_fmt, void* out, size_t* n_out) {
+  if (!ctx || !n_out || !fmt_ok(scalar_fmt) || !basis_ok(basis) || !a || !b || !out) return BP_ERR_INVALID_ARG;
+  if (basis != BP_BASIS_MONOMIAL) return fail(ctx, BP_ERR_BASIS, "Polynomial * Polynomial: Lagrange basis is todo!() in the reference", hipSuccess, __FILE__, __LINE__);
+  if (na == 0 || nb == 0) return fail(ctx, BP_ERR_INVALID_ARG, "empty polynomial (len - 1 underflows, polynomial.rs:248-249)", hipSuccess, __FILE__, __LINE__);
+  // find_next_power_of_two(n, m) with n = na-1, m = nb-1: smallest power of two >= n + m + 1 (utils.rs:54-61)
+  const size_t target = na + nb - 1;
+  uint32_t k = 0;
+  while (((size_t)1 << k) < target) k++;
+  if (k > 28) return fail(ctx, BP_ERR_TOO_LARGE, "product too long", hipSuccess, __FILE__, __LINE__);
+  const size_t N = (size_t)1 << k;
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  fr_t* d;
+  BP_TRY(ws_get(ctx, "io.poly_mul", 2 * N * sizeof(fr_t), (void**)&d));
+  BP_HIP(ctx, hipMemsetAsync(d, 0, 2 * N * sizeof(fr_t), ctx->stream));
+  BP_HIP(ctx, hipMemcpyAsync(d, a, na * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+  BP_HIP(ctx, hipMemcpyAsync(d + N, b, nb * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+  if (scalar_fmt == BP_FR_BYTES_LE) BP_TRY(fr_convert_run(ctx, d, 2 * N, 0));
+  BP_TRY(ntt_run(ctx, d, k, 0, 2, N));                        // evaluate both at the N roots (polynomial.rs:255-260)
+  BP_TRY(fr_binary_run(ctx, d, N, d + N, N, d, N, 2));        // pointwise product (:262-266)
+  BP_TRY(ntt_run(ctx, d, k, 1, 1, N));                        // i_ntt_381 (:270)
+  *n_out = target;                                            // [0 ..= n+m] (:272)
+  return download_fr(ctx, d, out, target, scalar_fmt);
+}
+
+int bp_poly_div(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb, int basis, int scalar_fmt, void* out, size_t* n_out) {
+  if (!ctx || !n_out || !fmt_ok(scalar_fmt) || !basis_ok(basis) || (na && !a) || (nb && !b)) return BP_ERR_INVALID_ARG;
+  if (basis != BP_BASIS_MONOMIAL) return fail(ctx, BP_ERR_BASIS, "Div needs the Monomial basis (polynomial.rs:319)", hipSuccess, __FILE__, __LINE__);
+  const fr_t* ha = (const fr_t*)a;
+  const fr_t* hb = (const fr_t*)b;
+  while (na > 0 && big_is_zero(ha[na - 1])) na--;             // polynomial.rs:325-339 (zero is all-zero in both formats)
+  while (nb > 0 && big_is_zero(hb[nb - 1])) nb--;
+  if (nb == 0) return fail(ctx, BP_ERR_DIV_ZERO, "division by the zero polynomial", hipSuccess, __FILE__, __LINE__);
+  *n_out = 0;
+  if (na < nb) return BP_OK;
+  if (!out) return BP_ERR_INVALID_ARG;
+  const size_t nq = na - nb + 1;
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  fr_t *da, *db, *dq;
+  BP_TRY(upload_fr(ctx, "io.poly_a", a, na, na, scalar_fmt, &da));
+  BP_TRY(upload_fr(ctx, "io.poly_b", b, nb, nb, scalar_fmt, &db));
+  BP_TRY(ws_get(ctx, "io.poly_out", nq * sizeof(fr_t), (void**)&dq));
+  std::vector<fr_t> hbm(nb);
+  for (size_t i = 0; i < nb; i++)
+    if (!fr_bytes_to_mont(hbm[i], (const uint8_t*)&hb[i], scalar_fmt)) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q", hipSuccess, __FILE__, __LINE__);
+  BP_TRY(poly_div_run(ctx, da, na, db, nb, hbm.data(), dq, nq));
+  std::vector<fr_t> q(nq);
+  BP_TRY(download_fr(ctx, dq, q.data(), nq, scalar_fmt));
+  // The reference inserts one quotient coefficient per loop turn and pops every newly zero leading remainder
+  // term (polynomial.rs:371-376): its result is the true quotient with the zero coefficients squeezed out.
+  fr_t* o = (fr_t*)out;
+  size_t m = 0;
+  for (size_t i = 0; i < nq; i++)
+    if (!big_is_zero(q[i])) o[m++] = q[i];
+  *n_out = m;
+  return BP_OK;
+}
+
+int bp_commit(bp_ctx* ctx, uint64_t srs_handle, const void* coeffs, size_t n, int basis, int scalar_fmt, uint8_t out96[96]) {
+  if (!ctx || !basis_ok(basis)) return BP_ERR_INVALID_ARG;
+  if (basis != BP_BASIS_MONOMIAL) return fail(ctx, BP_ERR_BASIS, "commit needs the Monomial basis (setup.rs:34)", hipSuccess, __FILE__, __LINE__);
+  return bp_msm_g1(ctx, srs_handle, coeffs, n, scalar_fmt, out96);
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// ctx.hpp -- per-GPU context shared by the translation units of libbp_msm_ntt.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bp_msm_ntt.h"
+#include "g1.cuh"
+
+namespace bp {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct SrsEntry {
+  g1_affine* d_points = nullptr;
+  size_t n = 0;
+};
+
+struct NttTables {       // per (log_n, inverse)
+  fr_t* lo = nullptr;    // w_N^j, j < 2^h
+  fr_t* hi = nullptr;    // w_N^(j << h), j < 2^(k-h)
+  fr_t* hi_scaled = nullptr;   // hi * N^-1 (inverse transforms, first pass)
+  fr_t* n_inv = nullptr;       // device copy of N^-1
+  uint32_t h = 0;
+};
+
+}  // namespace bp
+
+struct bp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  std::string last_error;
+  std::map<std::string, bp::DevBuf> ws;            // grow-only named device workspaces
+  std::map<uint64_t, bp::SrsEntry> srs;
+  uint64_t next_handle = 1;
+  bp::fr_t* small_tw[2] = {nullptr, nullptr};      // w_1024^j, j < 512: forward / inverse
+  std::map<uint32_t, bp::NttTables> ntt_tables;    // key = log_n * 2 + inverse
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // stats of the last calls
+  float msm_accumulate_ms = 0, msm_total_ms = 0;
+  uint64_t msm_adds = 0;
+  uint32_t msm_c = 0;
+  float ntt_ms = 0;
+  uint32_t ntt_passes = 0;
+  void* pinned = nullptr;                          // small pinned staging buffer (window sums etc.)
+  size_t pinned_cap = 0;
+};
+
+namespace bp {
+
+int fail(bp_ctx* ctx, int code, const char* what, hipError_t e, const char* file, int line);
+
+#define BP_HIP(ctx, call)                                                              \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess) return ::bp::fail(ctx, BP_ERR_HIP, #call, e__, __FILE__, __LINE__); \
+  } while (0)
+#define BP_TRY(expr)              \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != BP_OK) return rc__; \
+  } while (0)
+
+// device workspace `name` of at least `bytes` (contents undefined after growth)
+int ws_get(bp_ctx* ctx, const char* name, size_t bytes, void** out);
+int pinned_get(bp_ctx* ctx, size_t bytes, void** out);
+
+// ---- launchers implemented in msm.hip / ntt.hip / poly.hip / srs.hip --------------------------------
+int msm_run(bp_ctx* ctx, const g1_affine* d_points, size_t n, const fr_t* d_scalars, int fmt, g1_proj* host_out);
+int ntt_init_tables(bp_ctx* ctx);
+int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t log_n, int inverse, size_t batch, size_t stride);
+int fr_convert_run(bp_ctx* ctx, fr_t* d, size_t n, int dir);
+int fr_binary_run(bp_ctx* ctx, const fr_t* a, size_t na, const fr_t* b, size_t nb, fr_t* out, size_t n, int op);
+int fr_scalar_run(bp_ctx* ctx, const fr_t* a, const fr_t& s, fr_t* out, size_t n, int op);
+int poly_eval_run(bp_ctx* ctx, const fr_t* d_coeffs, size_t n, const fr_t& x, fr_t* host_out);
+int poly_div_run(bp_ctx* ctx, fr_t* d_a, size_t na, const fr_t* d_b, size_t nb, const fr_t* host_b, fr_t* d_q, size_t nq);
+int roots_run(bp_ctx* ctx, const fr_t& w, size_t n, fr_t* d_out);
+int srs_decode_run(bp_ctx* ctx, const uint8_t* d_bytes, size_t n, g1_affine* d_out);
+int srs_encode_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, uint8_t* d_bytes);
+int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t n, g1_affine* d_out);
+
+// ---- host-side helpers (host.cpp part of capi.hip) ---------------------------------------------------
+void host_horner(g1_proj& out, const g1_proj* window_sums, uint32_t W, uint32_t c);
+void host_encode96(uint8_t out96[96], const g1_proj& p);
+bool host_decode96(g1_proj& out, const uint8_t in96[96]);
+
+}  // namespace bp

@@ -1,0 +1,313 @@
+// msm_kernels.cuh -- G1 multi-scalar multiplication on gfx950: sum_i s_i * P_i.
+// Replaces BucketMSM::bucket_msm (src/msm.rs:76-118) behind Setup::commit (src/setup.rs:32-37).
+//
+// The reference walks 64 four-bit windows with 15 buckets each and ~60 projective adds per point.
+// Any bucket method yields the same group element, and parity is defined on its affine encoding
+// (SURVEY.md section 8a), so the device algorithm is chosen for the hardware:
+//
+//   1. msm_digits       scalars (Montgomery Fr, coalesced 32-B loads) -> canonical integer ->
+//                       W signed c-bit digits (bias trick, no carry chain), written window-major.
+//   2. msm_count        per (window, slice) workgroup: LDS histogram of the 2^(c-1) buckets of one
+//                       window (c = 16 -> 128 KiB, which is why LDS size picks c), flushed to HBM.
+//   3. scan_u32         exclusive scan of all W * 2^(c-1) bucket sizes -> bucket offsets.
+//   4. msm_scatter      same LDS histogram; one global atomic per (workgroup, bucket) reserves a range,
+//                       LDS atomics rank inside it; point indices land bucket-sorted (counting sort).
+//   5. msm_accumulate   the hot loop.  The bucket-sorted index list is cut into equal chunks, one per
+//                       lane, regardless of bucket boundaries: every lane performs the same number of
+//                       complete mixed additions (gathered 96-B affine points, accumulator in VGPRs),
+//                       so wave utilisation does not depend on the scalar distribution.  Runs that
+//                       cover a whole bucket are stored as the bucket sum; runs cut by a chunk edge go
+//                       to a per-lane partial slot.
+//   6. msm_fixup        buckets that straddle chunks: add their partials.
+//   7. msm_reduce       sum_b b * S_b per window by segmented running sums + LDS tree.
+//   host epilogue       Horner over the W window sums (c doublings each) + one affine normalisation.
+//
+// Group law: complete RCB formulas (g1.cuh) -- branch-free, so P+P / P+(-P) / identity need no
+// divergent special cases.
+#pragma once
+#include "g1.cuh"
+
+namespace bp {
+
+constexpr int MSM_MAX_C = 16;
+constexpr int MSM_MAX_WINDOWS = 128;
+
+struct MsmPlan {
+  uint32_t n;          // number of (point, scalar) pairs
+  uint32_t c;          // window bits
+  uint32_t W;          // windows
+  uint32_t B;          // buckets per window = 2^(c-1)
+  uint32_t chunk;      // entries per lane in msm_accumulate
+  uint32_t slices;     // workgroups per window in count/scatter
+  uint32_t seg;        // buckets per lane in msm_reduce
+  uint32_t bias[9];    // sum_w 2^(c-1) * 2^(c*w)
+};
+
+// ---------------------------------------------------------------- 1. digits
+// fmt 0: 32-byte little-endian canonical (Scalar::to_bytes), 1: Montgomery limbs (Scalar::to_array)
+__global__ void __launch_bounds__(256) msm_digits(const fr_t* __restrict__ scalars, int fmt, MsmPlan plan,
+                                                   int16_t* __restrict__ digits) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= plan.n) return;
+  fr_t k = scalars[i];
+  if (fmt == 1) Fr::from_mont(k, k);               // msm.rs:126: scalar.to_bytes() = canonical integer
+  uint32_t kp[10];
+  uint64_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    carry += (uint64_t)(j < 8 ? k.l[j] : 0u) + plan.bias[j];
+    kp[j] = (uint32_t)carry;
+    carry >>= 32;
+  }
+  kp[9] = 0;
+  const uint32_t c = plan.c, mask = (1u << c) - 1u, half = 1u << (c - 1);
+  for (uint32_t w = 0; w < plan.W; w++) {
+    uint32_t o = c * w, word = o >> 5, sh = o & 31;
+    uint64_t two = (uint64_t)kp[word] | ((uint64_t)kp[word + 1] << 32);
+    int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (int32_t)half;
+    digits[(size_t)w * plan.n + i] = (int16_t)d;
+  }
+}
+
+// bucket index inside a window for a non-zero digit: |d| - 1 in [0, 2^(c-1))
+__device__ __forceinline__ uint32_t digit_bucket(int32_t d) { return (uint32_t)(d < 0 ? -d : d) - 1u; }
+
+// ---------------------------------------------------------------- 2. count
+extern __shared__ uint32_t msm_lds_hist[];
+
+__device__ __forceinline__ void slice_range(const MsmPlan& plan, uint32_t slice, uint32_t& lo, uint32_t& hi) {
+  uint32_t per = (plan.n + plan.slices - 1) / plan.slices;
+  lo = slice * per;
+  hi = lo + per < plan.n ? lo + per : plan.n;
+  if (lo > plan.n) lo = plan.n;
+}
+
+__global__ void __launch_bounds__(256) msm_count(const int16_t* __restrict__ digits, MsmPlan plan,
+                                                  uint32_t* __restrict__ counts) {
+  const uint32_t w = blockIdx.y, B = plan.B;
+  for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) msm_lds_hist[b] = 0;
+  __syncthreads();
+  uint32_t lo, hi;
+  slice_range(plan, blockIdx.x, lo, hi);
+  const int16_t* dw = digits + (size_t)w * plan.n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    int32_t d = dw[i];
+    if (d != 0) atomicAdd(&msm_lds_hist[digit_bucket(d)], 1u);
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
+    uint32_t v = msm_lds_hist[b];
+    if (v) atomicAdd(&counts[(size_t)w * B + b], v);
+  }
+}
+
+// ---------------------------------------------------------------- 3. scan (single workgroup, 1024 lanes)
+// offsets[0..total] = exclusive prefix sums of counts[0..total); cursors = copy of offsets[0..total)
+__global__ void __launch_bounds__(1024) scan_u32(const uint32_t* __restrict__ counts, uint32_t total,
+                                                  uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors) {
+  __shared__ uint32_t sums[1024];
+  const uint32_t t = threadIdx.x, per = (total + 1023) / 1024;
+  const uint32_t lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
+  uint32_t s = 0;
+  for (uint32_t i = lo; i < hi; i++) s += counts[i];
+  sums[t] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan
+    uint32_t v = t >= d ? sums[t - d] : 0;
+    __syncthreads();
+    sums[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = sums[t] - s;
+  for (uint32_t i = lo; i < hi; i++) {
+    offsets[i] = run;
+    cursors[i] = run;
+    run += counts[i];
+  }
+  if (t == 1023) offsets[total] = sums[1023];
+}
+
+// ---------------------------------------------------------------- 4. scatter (counting sort)
+__global__ void __launch_bounds__(256) msm_scatter(const int16_t* __restrict__ digits, MsmPlan plan,
+                                                    uint32_t* __restrict__ cursors, uint32_t* __restrict__ sorted) {
+  const uint32_t w = blockIdx.y, B = plan.B;
+  for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) msm_lds_hist[b] = 0;
+  __syncthreads();
+  uint32_t lo, hi;
+  slice_range(plan, blockIdx.x, lo, hi);
+  const int16_t* dw = digits + (size_t)w * plan.n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    int32_t d = dw[i];
+    if (d != 0) atomicAdd(&msm_lds_hist[digit_bucket(d)], 1u);
+  }
+  __syncthreads();
+  // reserve this workgroup's range in every bucket it touches; LDS now holds the range start
+  for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
+    uint32_t v = msm_lds_hist[b];
+    if (v) msm_lds_hist[b] = atomicAdd(&cursors[(size_t)w * B + b], v);
+  }
+  __syncthreads();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    int32_t d = dw[i];
+    if (d != 0) {
+      uint32_t pos = atomicAdd(&msm_lds_hist[digit_bucket(d)], 1u);
+      sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- 5. accumulate
+__device__ __forceinline__ g1_affine load_affine(const g1_affine* __restrict__ p) {
+  g1_affine r;
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 v[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) v[j] = q[j];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    r.x.l[4 * j] = v[j].x; r.x.l[4 * j + 1] = v[j].y; r.x.l[4 * j + 2] = v[j].z; r.x.l[4 * j + 3] = v[j].w;
+    r.y.l[4 * j] = v[j + 3].x; r.y.l[4 * j + 1] = v[j + 3].y; r.y.l[4 * j + 2] = v[j + 3].z; r.y.l[4 * j + 3] = v[j + 3].w;
+  }
+  return r;
+}
+__device__ __forceinline__ void store_proj(g1_proj* __restrict__ dst, const g1_proj& p) {
+  uint4* q = reinterpret_cast<uint4*>(dst);
+  const uint32_t* s = p.x.l;   // x | y | z are contiguous members
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    const uint32_t* f = j < 3 ? p.x.l + 4 * j : (j < 6 ? p.y.l + 4 * (j - 3) : p.z.l + 4 * (j - 6));
+    q[j] = make_uint4(f[0], f[1], f[2], f[3]);
+  }
+  (void)s;
+}
+__device__ __forceinline__ g1_proj load_proj(const g1_proj* __restrict__ src) {
+  g1_proj p;
+  const uint4* q = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    uint4 v = q[j];
+    uint32_t* f = j < 3 ? p.x.l + 4 * j : (j < 6 ? p.y.l + 4 * (j - 3) : p.z.l + 4 * (j - 6));
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+  return p;
+}
+
+// largest g in [0, total) with offsets[g] <= p   (offsets is non-decreasing, offsets[0] = 0)
+__device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offsets, uint32_t total, uint32_t p) {
+  uint32_t lo = 0, hi = total;                 // invariant: offsets[lo] <= p < offsets[hi]
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (offsets[mid] <= p) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256, 2)
+msm_accumulate(const g1_affine* __restrict__ points, const uint32_t* __restrict__ sorted,
+               const uint32_t* __restrict__ offsets, MsmPlan plan, g1_proj* __restrict__ bucket_sum,
+               g1_proj* __restrict__ partial) {
+  const uint32_t total = plan.W * plan.B;
+  const uint32_t M = offsets[total];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t p0_64 = (uint64_t)t * plan.chunk;
+  if (p0_64 >= M) return;
+  const uint32_t p0 = (uint32_t)p0_64;
+  const uint32_t p1 = (uint64_t)p0 + plan.chunk < M ? p0 + plan.chunk : M;
+
+  uint32_t g = bucket_of(offsets, total, p0);
+  uint32_t g_end = offsets[g + 1];
+  uint32_t run_start = p0;
+  g1_proj acc = g1_identity();
+  for (uint32_t p = p0; p < p1; p++) {
+    if (p >= g_end) {                            // leave bucket g: flush its run [run_start, p)
+      const bool complete = run_start == offsets[g];    // it ended at g_end by construction
+      store_proj(complete ? &bucket_sum[g] : &partial[2 * (size_t)t + (run_start == p0 ? 0 : 1)], acc);
+      acc = g1_identity();
+      run_start = p;
+      do { g++; g_end = offsets[g + 1]; } while (p >= g_end);    // skip empty buckets
+    }
+    const uint32_t e = sorted[p];
+    g1_affine q = load_affine(&points[e & 0x7fffffffu]);
+    if (e >> 31) Fp::neg(q.y, q.y);
+    g1_add_mixed(acc, acc, q);
+  }
+  const bool complete = run_start == offsets[g] && p1 == g_end;
+  store_proj(complete ? &bucket_sum[g] : &partial[2 * (size_t)t + (run_start == p0 ? 0 : 1)], acc);
+}
+
+// ---------------------------------------------------------------- 6. fixup
+__global__ void __launch_bounds__(256, 2)
+msm_fixup(const uint32_t* __restrict__ offsets, MsmPlan plan, g1_proj* __restrict__ bucket_sum,
+          const g1_proj* __restrict__ partial) {
+  const uint32_t total = plan.W * plan.B;
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const uint32_t a = offsets[g], b = offsets[g + 1];
+  if (a == b) return;
+  const uint32_t t_lo = a / plan.chunk, t_hi = (b - 1) / plan.chunk;
+  if (t_lo == t_hi) return;                       // the whole bucket sat inside one chunk: already stored
+  g1_proj acc = g1_identity();
+  for (uint32_t t = t_lo; t <= t_hi; t++) {
+    const uint32_t slot = a <= t * plan.chunk ? 0 : 1;
+    g1_proj q = load_proj(&partial[2 * (size_t)t + slot]);
+    g1_add(acc, acc, q);
+  }
+  store_proj(&bucket_sum[g], acc);
+}
+
+// ---------------------------------------------------------------- 7. reduce: T_w = sum_b (b+1) * S_{w,b}
+// grid (blocks_per_window, W), 256 lanes; lane handles `seg` consecutive buckets.
+// out[w * gridDim.x + blockIdx.x] = this block's share.
+extern __shared__ uint32_t msm_lds_tree[];
+
+__global__ void __launch_bounds__(256, 2)
+msm_reduce(const uint32_t* __restrict__ offsets, MsmPlan plan, const g1_proj* __restrict__ bucket_sum,
+           g1_proj* __restrict__ block_out) {
+  const uint32_t w = blockIdx.y, B = plan.B, seg = plan.seg;
+  const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * seg;      // first bucket (0-based) of this lane
+  g1_proj acc = g1_identity(), wsum = g1_identity();
+  if (first < B) {
+    const uint32_t last = first + seg < B ? first + seg : B;
+    for (uint32_t b = last; b-- > first;) {
+      const size_t g = (size_t)w * B + b;
+      if (offsets[g + 1] != offsets[g]) {
+        g1_proj s = load_proj(&bucket_sum[g]);
+        g1_add(acc, acc, s);
+      }
+      g1_add(wsum, wsum, acc);                    // after the loop: sum_b (b - first + 1) * S_b
+    }
+    if (first != 0) {                             // + first * acc
+      g1_proj scaled;
+      g1_mul_small(scaled, acc, first, 32 - __clz(first));
+      g1_add(wsum, wsum, scaled);
+    }
+  }
+  // LDS tree over the 256 lanes
+  g1_proj* tree = reinterpret_cast<g1_proj*>(msm_lds_tree);
+  tree[threadIdx.x] = wsum;
+  __syncthreads();
+  for (uint32_t stride = blockDim.x >> 1; stride > 0; stride >>= 1) {
+    if (threadIdx.x < stride) {
+      g1_proj a = tree[threadIdx.x], b = tree[threadIdx.x + stride];
+      g1_add(a, a, b);
+      tree[threadIdx.x] = a;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_out[(size_t)w * gridDim.x + blockIdx.x] = tree[0];
+}
+
+// window_sum[w] = sum of the block shares of window w (one lane per window)
+__global__ void __launch_bounds__(64) msm_window_finish(const g1_proj* __restrict__ block_out, uint32_t blocks_per_window,
+                                                         uint32_t W, g1_proj* __restrict__ window_sum) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  g1_proj acc = g1_identity();
+  for (uint32_t j = 0; j < blocks_per_window; j++) {
+    g1_proj q = load_proj(&block_out[(size_t)w * blocks_per_window + j]);
+    g1_add(acc, acc, q);
+  }
+  store_proj(&window_sum[w], acc);
+}
+
+}  // namespace bp

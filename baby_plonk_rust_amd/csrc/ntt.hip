@@ -1,0 +1,148 @@
+// ntt.hip -- host driver of the Fr NTT (kernels in ntt_kernels.cuh) and of the element-wise Fr kernels.
+#include <string.h>
+
+#include "ctx.hpp"
+#include "ntt_kernels.cuh"
+
+namespace bp {
+
+static fr_t host_root_pow2(bool inverse, uint32_t log_order) {
+  // w_{2^log_order} = ROOT_OF_UNITY^(2^(32 - log_order))   (utils.rs:39-43)
+  fr_t w = fr_root_of_unity(inverse);
+  for (uint32_t i = log_order; i < 32; i++) Fr::sqr(w, w);
+  return w;
+}
+
+static int make_table(bp_ctx* ctx, const fr_t& base, uint32_t count, uint32_t shift, const fr_t* d_scale, fr_t* d_out) {
+  hipLaunchKernelGGL(ntt_make_table, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, base, count, shift, d_scale, d_out);
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
+
+int ntt_init_tables(bp_ctx* ctx) {
+  for (int inv = 0; inv < 2; inv++) {
+    BP_HIP(ctx, hipMalloc((void**)&ctx->small_tw[inv], 512 * sizeof(fr_t)));
+    BP_TRY(make_table(ctx, host_root_pow2(inv != 0, NTT_SMALL_MAX_LOG), 512, 0, nullptr, ctx->small_tw[inv]));
+  }
+  static bool attr = false;
+  if (!attr) {
+    BP_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    BP_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_last, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  return BP_OK;
+}
+
+static void make_ntt_plan(NttPlan& plan, uint32_t k) {
+  memset(&plan, 0, sizeof plan);
+  plan.k = k;
+  plan.P = k <= NTT_SMALL_MAX_LOG ? 1 : (k + NTT_MAX_PASS_LOG - 1) / NTT_MAX_PASS_LOG;
+  uint32_t rem = k;
+  for (uint32_t i = 0; i < plan.P; i++) {          // balanced widths, larger ones first
+    uint32_t left = plan.P - i;
+    plan.l[i] = (rem + left - 1) / left;
+    rem -= plan.l[i];
+  }
+  plan.h = (k + 1) / 2;
+}
+
+static int get_tables(bp_ctx* ctx, uint32_t k, int inverse, NttTables** out) {
+  const uint32_t key = k * 2 + (inverse ? 1 : 0);
+  auto it = ctx->ntt_tables.find(key);
+  if (it != ctx->ntt_tables.end()) {
+    *out = &it->second;
+    return BP_OK;
+  }
+  NttTables t;
+  t.h = (k + 1) / 2;
+  const uint32_t nlo = 1u << t.h, nhi = 1u << (k - t.h);
+  const fr_t w = host_root_pow2(inverse != 0, k);
+  BP_HIP(ctx, hipMalloc((void**)&t.lo, (size_t)nlo * sizeof(fr_t)));
+  BP_HIP(ctx, hipMalloc((void**)&t.hi, (size_t)nhi * sizeof(fr_t)));
+  BP_TRY(make_table(ctx, w, nlo, 0, nullptr, t.lo));
+  BP_TRY(make_table(ctx, w, nhi, t.h, nullptr, t.hi));
+  if (inverse) {
+    // N^-1 = (2^k)^-1 in Montgomery form (utils.rs:126: Scalar::from(n).invert())
+    fr_t two = Fr::one(), n_m = Fr::one(), n_inv;
+    Fr::dbl(two, two);
+    for (uint32_t i = 0; i < k; i++) Fr::mul(n_m, n_m, two);
+    fr_invert(n_inv, n_m);
+    BP_HIP(ctx, hipMalloc((void**)&t.n_inv, sizeof(fr_t)));
+    BP_HIP(ctx, hipMemcpyAsync(t.n_inv, &n_inv, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+    BP_HIP(ctx, hipStreamSynchronize(ctx->stream));    // n_inv lives on this stack frame
+    BP_HIP(ctx, hipMalloc((void**)&t.hi_scaled, (size_t)nhi * sizeof(fr_t)));
+    BP_TRY(make_table(ctx, w, nhi, t.h, t.n_inv, t.hi_scaled));
+  }
+  ctx->ntt_tables[key] = t;
+  *out = &ctx->ntt_tables[key];
+  return BP_OK;
+}
+
+int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, size_t stride) {
+  if (k > 28) return fail(ctx, BP_ERR_TOO_LARGE, "NTT length > 2^28", hipSuccess, __FILE__, __LINE__);
+  if (batch == 0) return BP_OK;
+  if (batch > 65535) return fail(ctx, BP_ERR_TOO_LARGE, "NTT batch > 65535", hipSuccess, __FILE__, __LINE__);
+  const size_t N = (size_t)1 << k;
+  if (batch > 1 && stride < N) return fail(ctx, BP_ERR_INVALID_ARG, "NTT stride < N", hipSuccess, __FILE__, __LINE__);
+  NttPlan plan;
+  make_ntt_plan(plan, k);
+  NttTables* tab;
+  BP_TRY(get_tables(ctx, k, inverse, &tab));
+  hipStream_t st = ctx->stream;
+  const fr_t* small = ctx->small_tw[inverse ? 1 : 0];
+  BP_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+  if (plan.P == 1) {
+    const size_t lds = (N + (N >> 1)) * sizeof(fr_t) + 16;
+    hipLaunchKernelGGL(ntt_small, dim3((unsigned)batch), dim3(256), lds, st, d_data, stride, k, small,
+                       inverse ? tab->n_inv : (const fr_t*)nullptr);
+  } else {
+    // ping-pong: pass 1 data -> tmp, middle passes in tmp, last pass tmp -> data
+    fr_t* tmp;
+    BP_TRY(ws_get(ctx, "ntt.tmp", batch * N * sizeof(fr_t), (void**)&tmp));
+    constexpr uint32_t C = 1u << NTT_TILE_COLS_LOG;
+    uint32_t s = k;
+    for (uint32_t i = 0; i + 1 < plan.P; i++) {
+      const uint32_t l = plan.l[i];
+      s -= l;
+      const size_t lds = ((size_t)(1u << l) * (C + 1) + (1u << l) / 2) * sizeof(fr_t) + 16;
+      const fr_t* hi = (inverse && i == 0) ? tab->hi_scaled : tab->hi;     // N^-1 rides on the first twiddle
+      hipLaunchKernelGGL(ntt_pass_strided, dim3((unsigned)(N >> (l + NTT_TILE_COLS_LOG)), (unsigned)batch), dim3(256), lds, st,
+                         i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp, tmp, i == 0 ? stride : N, N, k, l, s, small, tab->lo, hi,
+                         tab->h);
+    }
+    const uint32_t l = plan.l[plan.P - 1];
+    const size_t lds = ((size_t)(1u << l) * (C + 1) + (1u << l) / 2) * sizeof(fr_t) + 16;
+    hipLaunchKernelGGL(ntt_pass_last, dim3((unsigned)(N >> (l + NTT_TILE_COLS_LOG)), (unsigned)batch), dim3(256), lds, st,
+                       (const fr_t*)tmp, d_data, N, stride, plan, small);
+  }
+  BP_HIP(ctx, hipGetLastError());
+  BP_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+  ctx->ntt_passes = plan.P;
+  return BP_OK;
+}
+
+int fr_convert_run(bp_ctx* ctx, fr_t* d, size_t n, int dir) {
+  if (n == 0) return BP_OK;
+  hipLaunchKernelGGL(fr_convert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, n, dir);
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
+int fr_binary_run(bp_ctx* ctx, const fr_t* a, size_t na, const fr_t* b, size_t nb, fr_t* out, size_t n, int op) {
+  if (n == 0) return BP_OK;
+  hipLaunchKernelGGL(fr_binary, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, na, b, nb, out, n, op);
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
+int fr_scalar_run(bp_ctx* ctx, const fr_t* a, const fr_t& s, fr_t* out, size_t n, int op) {
+  if (n == 0) return BP_OK;
+  hipLaunchKernelGGL(fr_scalar_op, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, s, out, n, op);
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
+// out[j] = w^j, j < n   (roots_of_unity, utils.rs:45-52)
+int roots_run(bp_ctx* ctx, const fr_t& w, size_t n, fr_t* d_out) {
+  if (n == 0) return BP_OK;
+  return make_table(ctx, w, (uint32_t)n, 0, nullptr, d_out);
+}
+
+}  // namespace bp

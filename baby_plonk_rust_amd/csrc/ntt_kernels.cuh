@@ -1,0 +1,206 @@
+// ntt_kernels.cuh -- Fr number-theoretic transform on gfx950.
+// Replaces ntt_381 / i_ntt_381 (src/utils.rs:63-81, 106-129): out[x] = sum_y in[y] * w^(x*y),
+// w = ROOT_OF_UNITY^(2^32/N) (inverse: ROOT_OF_UNITY_INV, then * N^-1); natural order in and out.
+// The reference evaluates that sum literally (O(N^2), one 256-bit pow per term); every value is a
+// unique reduced residue, so an O(N log N) factorisation produces bit-identical output.
+//
+// Factorisation (decimation by index digits, "four-step" applied recursively):
+//   N = 2^k, k = l_1 + ... + l_P, each l_i <= 8.  Input index n = (d_1, ..., d_P), d_1 most significant.
+//   pass i < P : length-2^(l_i) transforms over digit d_i (stride 2^(s_i), s_i = bits below d_i), all
+//                butterflies in LDS, then one multiply by w_{M}^(e_i * r) (M = 2^(l_i+s_i), r = low part)
+//                from a two-level precomputed table; written back in place of d_i.
+//   pass P     : length-2^(l_P) transforms over contiguous rows; the result goes to the digit-reversed
+//                position e_1 + 2^(l_1) e_2 + ..., i.e. natural order, written in coalesced runs.
+//   A tile is 2^l x C elements (C = 8 adjacent columns = 256-B global runs) staged in LDS with a
+//   one-element row pad (conflict-free 16-B LDS accesses for both the column-major and row-major fills).
+//   HBM traffic: P reads + P writes of the vector (P = 1 up to 2^10, 2 up to 2^16, 3 up to 2^24).
+#pragma once
+#include "fr_io.cuh"
+
+namespace bp {
+
+constexpr int NTT_MAX_PASS_LOG = 8;     // per-pass transform length 2^8
+constexpr int NTT_SMALL_MAX_LOG = 10;   // single-workgroup transform up to 2^10
+constexpr int NTT_TILE_COLS_LOG = 3;    // C = 8
+
+struct NttPlan {
+  uint32_t k;            // log2 N
+  uint32_t P;            // passes
+  uint32_t l[4];         // digit widths
+  uint32_t h;            // low table has 2^h entries, high table 2^(k-h)
+};
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? __brev(x) >> (32 - bits) : 0; }
+
+// out[j] = base^(j << shift_), j < count  (table builder; base is a Montgomery Fr).  If scale != null
+// every entry is additionally multiplied by *scale (used to fold N^-1 into the high table).
+__global__ void __launch_bounds__(256) ntt_make_table(fr_t base, uint32_t count, uint32_t shift_, const fr_t* scale,
+                                                       fr_t* __restrict__ out) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  uint64_t e = (uint64_t)j << shift_;
+  fr_t acc = Fr::one(), b = base;
+  while (e) {
+    if (e & 1) Fr::mul(acc, acc, b);
+    Fr::sqr(b, b);
+    e >>= 1;
+  }
+  if (scale) Fr::mul(acc, acc, *scale);
+  store_fr(&out[j], acc);
+}
+
+extern __shared__ uint4 ntt_lds_raw[];
+
+// In-LDS radix-2 decimation-in-frequency transform of length L = 2^l on every column of a tile
+// [L][CP] (CP = padded column count, C live columns).  Result of output index e sits at row bitrev(e).
+// tw[j] = w_L^j for j < L/2 (LDS).
+__device__ __forceinline__ void lds_ntt_dif(fr_t* tile, const fr_t* tw, uint32_t l, uint32_t cl, uint32_t CP) {
+  const uint32_t L = 1u << l, C = 1u << cl, nbf = (L >> 1) << cl;
+  for (uint32_t s = 0; s < l; s++) {
+    const uint32_t hl = l - s - 1, half = 1u << hl;
+    for (uint32_t b = threadIdx.x; b < nbf; b += blockDim.x) {
+      const uint32_t c = b & (C - 1), jp = b >> cl;
+      const uint32_t blk = jp >> hl, j = jp & (half - 1);
+      const uint32_t i0 = (blk * 2 * half + j) * CP + c, i1 = i0 + half * CP;
+      fr_t u = tile[i0], v = tile[i1], t;
+      Fr::add(t, u, v);
+      tile[i0] = t;
+      Fr::sub(t, u, v);
+      if (j != 0) Fr::mul(t, t, tw[j << s]);
+      tile[i1] = t;
+    }
+    __syncthreads();
+  }
+}
+
+// Single-pass transform: N = 2^k <= 2^10, one workgroup per transform (blockIdx.x = batch index).
+// small_tw[j] = w_1024^j (forward or inverse table), scale = N^-1 (Montgomery) or null.
+__global__ void __launch_bounds__(256) ntt_small(fr_t* __restrict__ data, size_t stride, uint32_t k,
+                                                  const fr_t* __restrict__ small_tw, const fr_t* scale) {
+  fr_t* tile = reinterpret_cast<fr_t*>(ntt_lds_raw);
+  const uint32_t N = 1u << k;
+  fr_t* tw = tile + N;
+  fr_t* base = data + (size_t)blockIdx.x * stride;
+  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) tile[i] = load_fr(&base[i]);
+  for (uint32_t j = threadIdx.x; j < (N >> 1); j += blockDim.x) tw[j] = load_fr(&small_tw[j << (NTT_SMALL_MAX_LOG - k)]);
+  __syncthreads();
+  lds_ntt_dif(tile, tw, k, 0, 1);
+  fr_t sc;
+  if (scale) sc = *scale;
+  for (uint32_t e = threadIdx.x; e < N; e += blockDim.x) {
+    fr_t v = tile[bitrev(e, k)];
+    if (scale) Fr::mul(v, v, sc);
+    store_fr(&base[e], v);
+  }
+}
+
+// w_N^E from the two-level table (lo[E & (2^h-1)], hi[E >> h])
+__device__ __forceinline__ fr_t twiddle_lookup(const fr_t* __restrict__ lo, const fr_t* __restrict__ hi, uint32_t h, uint64_t E) {
+  fr_t a = load_fr(&lo[E & ((1u << h) - 1u)]), b = load_fr(&hi[E >> h]), r;
+  Fr::mul(r, a, b);
+  return r;
+}
+
+// Strided pass (every pass but the last).  grid.x = tiles, grid.y = batch.
+//   l      digit width, s = bits below the digit, mlog = l + s, k = log2 N
+//   element (hi, d, r): address hi * 2^mlog + d * 2^s + r; tile = all d x C consecutive r.
+__global__ void __launch_bounds__(256) ntt_pass_strided(const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride,
+                                                         uint32_t k, uint32_t l, uint32_t s,
+                                                         const fr_t* __restrict__ small_tw, const fr_t* __restrict__ tw_lo,
+                                                         const fr_t* __restrict__ tw_hi, uint32_t h) {
+  constexpr uint32_t C = 1u << NTT_TILE_COLS_LOG, CP = C + 1;
+  const uint32_t L = 1u << l, mlog = l + s;
+  fr_t* tile = reinterpret_cast<fr_t*>(ntt_lds_raw);
+  fr_t* tw = tile + L * CP;
+  const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
+  const uint32_t tiles_per_hi = 1u << (s - NTT_TILE_COLS_LOG);
+  const uint32_t hi = blockIdx.x / tiles_per_hi, r0 = (blockIdx.x % tiles_per_hi) << NTT_TILE_COLS_LOG;
+  const size_t base = ((size_t)hi << mlog) + r0;
+  for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
+    const uint32_t c = x % C, d = x / C;
+    tile[d * CP + c] = load_fr(&src[soff + base + ((size_t)d << s) + c]);
+  }
+  for (uint32_t j = threadIdx.x; j < (L >> 1); j += blockDim.x) tw[j] = load_fr(&small_tw[j << (NTT_SMALL_MAX_LOG - l)]);
+  __syncthreads();
+  lds_ntt_dif(tile, tw, l, NTT_TILE_COLS_LOG, CP);
+  const uint32_t tshift = k - mlog;                 // w_M^x = w_N^(x << tshift)
+  for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
+    const uint32_t c = x % C, e = x / C;
+    fr_t v = tile[bitrev(e, l) * CP + c];
+    const uint64_t E = ((uint64_t)e * (r0 + c)) << tshift;
+    fr_t w = twiddle_lookup(tw_lo, tw_hi, h, E);     // tw_hi may carry the folded N^-1 (first pass of an inverse)
+    Fr::mul(v, v, w);
+    store_fr(&dst[doff + base + ((size_t)e << s) + c], v);
+  }
+}
+
+// Last pass: contiguous rows of length L = 2^l (l = l_P); tile = C rows with consecutive e_1.
+// Row (e_1, mid): src address (e_1 * 2^(s1 - l) + mid) * L + d, s1 = k - l_1.
+// Output index = e_1 + 2^(l_1) * rev_digits(mid) + 2^(k - l) * e_P, where mid = (e_2..e_{P-1}) is re-ordered
+// digit by digit (least significant output digit first).
+__global__ void __launch_bounds__(256) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
+                                                      size_t dst_stride, NttPlan plan, const fr_t* __restrict__ small_tw) {
+  constexpr uint32_t C = 1u << NTT_TILE_COLS_LOG, CP = C + 1;
+  const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l;
+  fr_t* tile = reinterpret_cast<fr_t*>(ntt_lds_raw);
+  fr_t* tw = tile + L * CP;
+  const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
+  const uint32_t midbits = k - l1 - l;              // bits of (e_2 .. e_{P-1})
+  // blockIdx.x enumerates (e1_tile, mid): e_1 = e1_tile * C + c
+  const uint32_t mid = blockIdx.x & ((1u << midbits) - 1u), e1_0 = (blockIdx.x >> midbits) << NTT_TILE_COLS_LOG;
+  for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
+    const uint32_t d = x % L, c = x / L;
+    const size_t row = ((size_t)(e1_0 + c) << midbits) + mid;
+    tile[d * CP + c] = load_fr(&src[soff + (row << l) + d]);
+  }
+  for (uint32_t j = threadIdx.x; j < (L >> 1); j += blockDim.x) tw[j] = load_fr(&small_tw[j << (NTT_SMALL_MAX_LOG - l)]);
+  __syncthreads();
+  lds_ntt_dif(tile, tw, l, NTT_TILE_COLS_LOG, CP);
+  // digit-reverse mid: mid = e_2 * 2^(l_3+..+l_{P-1}) + ... + e_{P-1}; output wants e_2 lowest.
+  uint32_t mid_out = 0, shift_out = 0, rem = midbits;
+  for (uint32_t i = 1; i + 1 < P; i++) {
+    rem -= plan.l[i];
+    const uint32_t digit = (mid >> rem) & ((1u << plan.l[i]) - 1u);
+    mid_out |= digit << shift_out;
+    shift_out += plan.l[i];
+  }
+  const size_t obase = ((size_t)mid_out << l1) + e1_0;
+  for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
+    const uint32_t c = x % C, e = x / C;
+    fr_t v = tile[bitrev(e, l) * CP + c];
+    store_fr(&dst[doff + obase + ((size_t)e << (k - l)) + c], v);
+  }
+}
+
+// ---- element-wise helpers used by the Polynomial layer (src/polynomial.rs) -------------------------
+// op: 0 a+b, 1 a-b, 2 a*b (pointwise), with broadcast of a single scalar when nb == 1 is not done here.
+__global__ void __launch_bounds__(256) fr_binary(const fr_t* a, size_t na, const fr_t* b, size_t nb,
+                                                  fr_t* out, size_t n, int op) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fr_t x = i < na ? load_fr(&a[i]) : Fr::zero(), y = i < nb ? load_fr(&b[i]) : Fr::zero(), r;
+  if (op == 0) Fr::add(r, x, y);
+  else if (op == 1) Fr::sub(r, x, y);
+  else Fr::mul(r, x, y);
+  store_fr(&out[i], r);
+}
+// out[i] = a[i] (op) s for i < n;  op: 0 add, 1 sub, 2 mul
+__global__ void __launch_bounds__(256) fr_scalar_op(const fr_t* a, fr_t s, fr_t* out, size_t n, int op) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fr_t x = load_fr(&a[i]), r;
+  if (op == 0) Fr::add(r, x, s);
+  else if (op == 1) Fr::sub(r, x, s);
+  else Fr::mul(r, x, s);
+  store_fr(&out[i], r);
+}
+// in-place conversion between 32-byte LE canonical and Montgomery limbs (dir 0: to Montgomery, 1: from)
+__global__ void __launch_bounds__(256) fr_convert(fr_t* __restrict__ a, size_t n, int dir) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fr_t x = load_fr(&a[i]), r;
+  if (dir == 0) Fr::to_mont(r, x); else Fr::from_mont(r, x);
+  store_fr(&a[i], r);
+}
+
+}  // namespace bp

@@ -1,0 +1,65 @@
+// poly.hip -- host drivers of the polynomial kernels (poly_kernels.cuh).
+#include <string.h>
+
+#include "ctx.hpp"
+#include "poly_kernels.cuh"
+
+namespace bp {
+
+// coeffs_evaluate (polynomial.rs:34-45): sum_i c_i x^i.  The reference spends one 256-bit pow per term;
+// the sum is the same field element however it is associated.
+int poly_eval_run(bp_ctx* ctx, const fr_t* d_coeffs, size_t n, const fr_t& x, fr_t* host_out) {
+  if (n == 0) {
+    *host_out = Fr::zero();
+    return BP_OK;
+  }
+  uint32_t K = 16;
+  while ((n + K - 1) / K > 256 * 1024 && K < (1u << 20)) K <<= 1;     // at most 1024 workgroups
+  const size_t lanes = (n + K - 1) / K;
+  const unsigned blocks = (unsigned)((lanes + 255) / 256);
+  fr_t *partial, *result;
+  BP_TRY(ws_get(ctx, "poly.partial", (size_t)blocks * sizeof(fr_t), (void**)&partial));
+  BP_TRY(ws_get(ctx, "poly.result", sizeof(fr_t), (void**)&result));
+  hipLaunchKernelGGL(poly_eval_partial, dim3(blocks), dim3(256), 256 * sizeof(fr_t), ctx->stream, d_coeffs, n, x, K, partial);
+  hipLaunchKernelGGL(fr_sum_small, dim3(1), dim3(256), 256 * sizeof(fr_t), ctx->stream, partial, blocks, result);
+  BP_HIP(ctx, hipGetLastError());
+  BP_HIP(ctx, hipMemcpyAsync(host_out, result, sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
+// True polynomial quotient of a (na coeffs, a[na-1] != 0) by b (nb coeffs, b[nb-1] != 0), na >= nb.
+// d_a is clobbered by the general path.  host_b = host copy of b (to pick the fast path).
+int poly_div_run(bp_ctx* ctx, fr_t* d_a, size_t na, const fr_t* d_b, size_t nb, const fr_t* host_b, fr_t* d_q, size_t nq) {
+  bool binomial = nb >= 2;
+  for (size_t i = 1; i + 1 < nb && binomial; i++) binomial = big_is_zero(host_b[i]);
+  fr_t lead_inv;
+  fr_invert(lead_inv, host_b[nb - 1]);
+  if (binomial) {
+    const size_t m = nb - 1;
+    fr_t f;
+    Fr::mul(f, host_b[0], lead_inv);
+    Fr::neg(f, f);                                   // f = -b0 / bm
+    const size_t max_len = (nq + m - 1) / m;
+    const uint32_t K = 32;
+    const size_t chunks = (max_len + K - 1) / K;
+    fr_t *head, *carry;
+    BP_TRY(ws_get(ctx, "poly.div_head", chunks * m * sizeof(fr_t), (void**)&head));
+    BP_TRY(ws_get(ctx, "poly.div_carry", chunks * m * sizeof(fr_t), (void**)&carry));
+    const size_t lanes = m * chunks;
+    hipLaunchKernelGGL(poly_div_binomial_local, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, d_a, nq, m, f,
+                       lead_inv, K, chunks, d_q, head);
+    if (chunks > 1) {
+      hipLaunchKernelGGL(poly_div_binomial_carry, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, nq, m, f, K, chunks,
+                         head, carry);
+      hipLaunchKernelGGL(poly_div_binomial_apply, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, nq, m, f, K, chunks,
+                         carry, d_q);
+    }
+  } else {
+    hipLaunchKernelGGL(poly_div_general, dim3(1), dim3(1024), 0, ctx->stream, d_a, na, d_b, nb, lead_inv, d_q);
+  }
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
+
+}  // namespace bp

@@ -1,0 +1,33 @@
+// srs.hip -- host drivers of the SRS kernels (srs_kernels.cuh).
+#include "ctx.hpp"
+#include "srs_kernels.cuh"
+
+namespace bp {
+
+int srs_decode_run(bp_ctx* ctx, const uint8_t* d_bytes, size_t n, g1_affine* d_out) {
+  if (n == 0) return BP_OK;
+  uint32_t* status;
+  BP_TRY(ws_get(ctx, "srs.status", 4, (void**)&status));
+  BP_HIP(ctx, hipMemsetAsync(status, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(srs_decode96, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_bytes, n, d_out, status);
+  BP_HIP(ctx, hipGetLastError());
+  uint32_t h = 0;
+  BP_HIP(ctx, hipMemcpyAsync(&h, status, 4, hipMemcpyDeviceToHost, ctx->stream));
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h) return fail(ctx, BP_ERR_BAD_POINT, h & 1 ? "non-canonical point encoding" : "point not on the curve", hipSuccess, __FILE__, __LINE__);
+  return BP_OK;
+}
+int srs_encode_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, uint8_t* d_bytes) {
+  if (n == 0) return BP_OK;
+  hipLaunchKernelGGL(srs_encode96, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, n, d_bytes);
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
+int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t n, g1_affine* d_out) {
+  if (n == 0) return BP_OK;
+  hipLaunchKernelGGL(srs_generate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, d, mode, n, d_out);
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
+
+}  // namespace bp

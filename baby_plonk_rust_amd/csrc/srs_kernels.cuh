@@ -1,0 +1,117 @@
+// srs_kernels.cuh -- SRS ingest / export / generation on the GPU.
+//   srs_decode96   : 96-byte zkcrypto uncompressed encoding (g1.rs:246-322) -> device Montgomery affine
+//   srs_encode96   : the inverse (G1Affine::to_uncompressed)
+//   srs_generate   : P_i = s_i * G with s_i = tau^i (Setup::generate_srs, setup.rs:12-31) or
+//                    s_i = a + i*d (synthetic benchmark points)
+#pragma once
+#include "g1.cuh"
+
+namespace bp {
+
+__device__ __forceinline__ bool fp_lt_modulus(const fp_t& a) {
+  fp_t t;
+  return big_sub(t, a, Fp::modulus()) != 0;
+}
+// 48 big-endian bytes -> canonical limbs (fp.rs:179-190)
+__device__ __forceinline__ fp_t fp_from_be48(const uint8_t* b) {
+  fp_t r;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    const uint8_t* p = b + 4 * (11 - i);
+    r.l[i] = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+  }
+  return r;
+}
+__device__ __forceinline__ void fp_to_be48(uint8_t* b, const fp_t& a) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    uint8_t* p = b + 4 * (11 - i);
+    p[0] = (uint8_t)(a.l[i] >> 24); p[1] = (uint8_t)(a.l[i] >> 16); p[2] = (uint8_t)(a.l[i] >> 8); p[3] = (uint8_t)a.l[i];
+  }
+}
+
+// status: bit 0 = non-canonical coordinate or bad flag bits, bit 1 = point not on the curve
+__global__ void __launch_bounds__(256) srs_decode96(const uint8_t* __restrict__ in, size_t n, g1_affine* __restrict__ out,
+                                                     uint32_t* __restrict__ status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t buf[96];
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(in + 96 * i);   // 96*i is 4-byte aligned
+#pragma unroll
+  for (int j = 0; j < 24; j++) {
+    uint32_t w = src[j];
+    buf[4 * j] = (uint8_t)w; buf[4 * j + 1] = (uint8_t)(w >> 8); buf[4 * j + 2] = (uint8_t)(w >> 16); buf[4 * j + 3] = (uint8_t)(w >> 24);
+  }
+  const uint32_t flags = buf[0] >> 5;              // compression | infinity | sort   (g1.rs:275-277)
+  buf[0] &= 0x1f;
+  fp_t x = fp_from_be48(buf), y = fp_from_be48(buf + 48);
+  uint32_t bad = 0;
+  if (!fp_lt_modulus(x) || !fp_lt_modulus(y)) bad |= 1;
+  if (flags & 0b101) bad |= 1;                     // compressed / sort flag on an uncompressed point
+  g1_affine p;
+  if (flags & 0b010) {                             // infinity: coordinates must be zero (g1.rs:313-314)
+    if (!big_is_zero(x) || !big_is_zero(y)) bad |= 1;
+    p.x = Fp::zero();
+    p.y = Fp::zero();
+  } else {
+    Fp::to_mont(p.x, x);
+    Fp::to_mont(p.y, y);
+    fp_t lhs, rhs, b4;                             // y^2 == x^3 + 4  (g1.rs:101-106)
+    Fp::sqr(lhs, p.y);
+    Fp::sqr(rhs, p.x);
+    Fp::mul(rhs, rhs, p.x);
+    b4 = Fp::one();
+    Fp::dbl(b4, b4);
+    Fp::dbl(b4, b4);
+    Fp::add(rhs, rhs, b4);
+    if (!big_eq(lhs, rhs)) bad |= 2;
+  }
+  if (bad) atomicOr(status, bad);
+  out[i] = p;
+}
+
+__global__ void __launch_bounds__(256) srs_encode96(const g1_affine* __restrict__ in, size_t n, uint8_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g1_affine p = in[i];
+  uint8_t buf[96];
+  if (g1_affine_is_identity(p)) {
+#pragma unroll
+    for (int j = 0; j < 96; j++) buf[j] = 0;
+    buf[0] = 0x40;
+  } else {
+    fp_t x, y;
+    Fp::from_mont(x, p.x);
+    Fp::from_mont(y, p.y);
+    fp_to_be48(buf, x);
+    fp_to_be48(buf + 48, y);
+  }
+  uint32_t* dst = reinterpret_cast<uint32_t*>(out + 96 * i);
+#pragma unroll
+  for (int j = 0; j < 24; j++)
+    dst[j] = (uint32_t)buf[4 * j] | ((uint32_t)buf[4 * j + 1] << 8) | ((uint32_t)buf[4 * j + 2] << 16) | ((uint32_t)buf[4 * j + 3] << 24);
+}
+
+// mode 0: s_i = a^i (a = tau, Montgomery);  mode 1: s_i = a + i*d (Montgomery).  P_i = s_i * G, affine.
+__global__ void __launch_bounds__(256, 2) srs_generate(fr_t a, fr_t d, int mode, size_t n, g1_affine* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fr_t s;
+  if (mode == 0) {
+    uint32_t e[2] = {(uint32_t)i, (uint32_t)(i >> 32)};
+    Fr::pow(s, a, e, 2);
+  } else {
+    fr_t idx = Fr::zero(), t;
+    idx.l[0] = (uint32_t)i;
+    idx.l[1] = (uint32_t)(i >> 32);
+    Fr::to_mont(idx, idx);
+    Fr::mul(t, idx, d);
+    Fr::add(s, a, t);
+  }
+  Fr::from_mont(s, s);
+  g1_proj g = g1_from_affine(g1_affine_generator()), r;
+  g1_mul_scalar(r, g, s);
+  out[i] = g1_to_affine(r);
+}
+
+}  // namespace bp

@@ -1,0 +1,133 @@
+/*
+ * bp_msm_ntt.h -- C ABI of the MI355X-native PLONK hot path (BLS12-381 G1 MSM + Fr NTT + polynomial ops).
+ *
+ * This is the drop-in boundary.  The reference (ChainUpZero/baby-plonk-rust) has no FFI of its own; the
+ * entry points below are what a Rust `extern "C"` block in src/msm.rs / src/utils.rs / src/polynomial.rs /
+ * src/setup.rs would bind (INTEGRATION.md shows those stubs).  Each entry names the reference interface it
+ * replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no ownership transfer; every call returns BP_OK (0) or a negative code
+ *     and never throws.  Where the reference panics (assert!, unwrap), the call returns an error instead and
+ *     the Rust shim turns it back into a panic.
+ *   - one bp_ctx drives one GPU from one host thread (the reference is single-threaded).  Multi-GPU = one
+ *     process and one ctx per GPU; partial MSM results are exchanged by the caller (RCCL all-gather of the
+ *     144-byte projective partials, see bp_msm_g1_partial / bp_g1_sum_partials).
+ *   - wire formats are the reference's own:
+ *       scalar  fmt BP_FR_BYTES_LE : 32-byte little-endian canonical  (Scalar::to_bytes,  scalar.rs:292-304)
+ *               fmt BP_FR_MONT     : 4 x u64 Montgomery limbs          (Scalar::to_array,  scalar.rs:35-40)
+ *       point   96-byte uncompressed affine, x||y big-endian, bit 6 of byte 0 = infinity
+ *                                                                      (G1Affine::to_uncompressed, g1.rs:246-260)
+ *       projective partial: 144 bytes = x|y|z, 6 x u64 Montgomery limbs each = the memory image of
+ *               G1Projective (g1.rs:442-446); only used between our own ranks.
+ *   - *_device variants take pointers to HBM (hipMalloc / torch CUDA tensors) and leave results there.
+ */
+#ifndef BP_MSM_NTT_H
+#define BP_MSM_NTT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bp_ctx bp_ctx;
+
+enum {
+  BP_OK = 0,
+  BP_ERR_INVALID_ARG = -1,   /* null pointer, bad format flag, bad handle */
+  BP_ERR_NOT_POW2 = -2,      /* utils.rs:65,108   assert!(is_power_of_two(n)) */
+  BP_ERR_BAD_POINT = -3,     /* non-canonical / off-curve / bad flags (g1.rs:273-322) */
+  BP_ERR_BAD_SCALAR = -4,    /* 32-byte value >= q (scalar.rs:264-288) */
+  BP_ERR_BASIS = -5,         /* polynomial.rs:35,48,53,319, setup.rs:34   assert_eq!(basis, ..) */
+  BP_ERR_LENGTH = -6,        /* polynomial.rs:85-89,142-146   Lagrange operands of different length */
+  BP_ERR_DIV_ZERO = -7,      /* polynomial.rs:347-348   division by the zero polynomial (unwrap on None) */
+  BP_ERR_NO_DEVICE = -8,     /* no usable GPU / HIP runtime error at init */
+  BP_ERR_HIP = -9,           /* HIP runtime error; bp_last_error() has the text */
+  BP_ERR_TOO_LARGE = -10     /* size beyond the supported range (NTT > 2^28, MSM >= 2^31 points) */
+};
+enum { BP_FR_BYTES_LE = 0, BP_FR_MONT = 1 };
+enum { BP_BASIS_LAGRANGE = 0, BP_BASIS_MONOMIAL = 1 };   /* polynomial.rs:8-11 */
+
+/* ---- context ------------------------------------------------------------------------------------- */
+int  bp_init(bp_ctx** out, int device_id);
+void bp_destroy(bp_ctx* ctx);
+const char* bp_last_error(bp_ctx* ctx);            /* text of the last error on this ctx ("" if none) */
+const char* bp_version(void);
+/* Run all subsequent work of this ctx on an existing hipStream_t (e.g. torch's current stream). NULL = own stream. */
+int  bp_set_stream(bp_ctx* ctx, void* hip_stream);
+int  bp_synchronize(bp_ctx* ctx);
+
+/* ---- SRS: Setup.powers_of_x (src/setup.rs:7-10), resident in HBM ----------------------------------- */
+/* Upload n points in the 96-byte encoding.  Replaces handing &self.powers_of_x to bucket_msm on every
+ * commit (setup.rs:36): the SRS is immutable after construction, so it is uploaded once and cached. */
+int  bp_srs_load(bp_ctx* ctx, const uint8_t* points96, size_t n, uint64_t* srs_handle);
+/* Setup::generate_srs(powers, tau) (setup.rs:12-31): P_i = tau^i * G, generated on the GPU. tau: 32-byte LE. */
+int  bp_srs_generate(bp_ctx* ctx, size_t powers, const uint8_t tau32[32], uint64_t* srs_handle);
+/* Synthetic benchmark points P_i = (a + i*d) * G, generated on the GPU. */
+int  bp_srs_generate_progression(bp_ctx* ctx, size_t n, const uint8_t a32[32], const uint8_t d32[32], uint64_t* srs_handle);
+int  bp_srs_len(bp_ctx* ctx, uint64_t srs_handle, size_t* n);
+/* Read points [first, first+n) back in the 96-byte encoding (G1Affine::to_uncompressed). */
+int  bp_srs_export(bp_ctx* ctx, uint64_t srs_handle, size_t first, size_t n, uint8_t* points96);
+int  bp_srs_free(bp_ctx* ctx, uint64_t srs_handle);
+
+/* ---- MSM: BucketMSM::bucket_msm(points, scalars, b, c) (src/msm.rs:76-118) ----------------------- */
+/* sum_{i < min(n_scalars, srs_len - first)} s_i * P_{first+i}   (zip truncation of msm.rs:29).
+ * The window parameters (b, c) of the reference do not change the group element and are not taken.
+ * out96: affine result in the 96-byte encoding (identity = 0x40 then zeros). */
+int  bp_msm_g1(bp_ctx* ctx, uint64_t srs_handle, const void* scalars, size_t n_scalars, int scalar_fmt,
+               uint8_t out96[96]);
+/* Same sum over the SRS slice starting at `first`, result as a 144-byte projective partial (multi-GPU:
+ * each rank owns a point range; partials are all-gathered and added).  scalars_on_device != 0: `scalars`
+ * points to HBM. */
+int  bp_msm_g1_partial(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars,
+                       int scalar_fmt, int scalars_on_device, uint8_t out144[144]);
+/* Host-side: add n projective partials (complete addition, g1.rs:670-712) and normalise (g1.rs:49-63). */
+int  bp_g1_sum_partials(const uint8_t* partials144, size_t n, uint8_t out96[96]);
+/* Host-side conversions of single points (for the Rust shim's G1Projective <-> bytes plumbing). */
+int  bp_g1_partial_to_bytes96(const uint8_t in144[144], uint8_t out96[96]);
+int  bp_g1_bytes96_to_partial(const uint8_t in96[96], uint8_t out144[144]);
+/* HIP-event duration of the bucket-accumulation kernel of the last MSM on this ctx, and its adds. */
+int  bp_msm_last_stats(bp_ctx* ctx, float* accumulate_ms, float* total_device_ms, uint64_t* mixed_adds,
+                       uint32_t* window_bits);
+
+/* ---- DFT: ntt_381 / i_ntt_381 (src/utils.rs:63-81, 106-129) --------------------------------------- */
+/* In-place natural-order transform of length 2^log_n on `batch` vectors, vector b at data + b*stride
+ * elements (32 bytes each).  inverse != 0 includes the 1/N scaling (utils.rs:126). */
+int  bp_ntt_fr(bp_ctx* ctx, void* data, uint32_t log_n, int inverse, int scalar_fmt, size_t batch, size_t stride);
+/* Same on HBM-resident Montgomery data. */
+int  bp_ntt_fr_device(bp_ctx* ctx, void* d_data, uint32_t log_n, int inverse, size_t batch, size_t stride);
+/* HIP-event duration of all kernels of the last bp_ntt_fr_device call. */
+int  bp_ntt_last_stats(bp_ctx* ctx, float* device_ms, uint32_t* passes);
+/* root_of_unity(n) (utils.rs:39-43) and roots_of_unity(n) (utils.rs:45-52), output in scalar_fmt. */
+int  bp_root_of_unity(uint64_t group_order, int scalar_fmt, uint8_t out32[32]);
+int  bp_roots_of_unity(bp_ctx* ctx, uint64_t group_order, int scalar_fmt, void* out);
+
+/* ---- Polynomial (src/polynomial.rs:14-380); values are n x 32-byte scalars in scalar_fmt ---------- */
+/* coeffs_evaluate (polynomial.rs:34-45); asserts Monomial basis. */
+int  bp_poly_evaluate(bp_ctx* ctx, const void* coeffs, size_t n, int basis, const void* x32, int scalar_fmt,
+                      void* out32);
+/* impl Add/Sub for Polynomial (polynomial.rs:76-117,134-174). out needs max(na,nb) slots; *n_out = length. */
+int  bp_poly_add(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb, int basis, int scalar_fmt,
+                 void* out, size_t* n_out);
+int  bp_poly_sub(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb, int basis, int scalar_fmt,
+                 void* out, size_t* n_out);
+/* impl Add<Scalar>/Sub<Scalar>/Mul<Scalar> (polynomial.rs:57-74,119-132,176-187), including the reference's
+ * Lagrange-basis Sub<Scalar> quirk (it adds, :126-128). op: 0 add, 1 sub, 2 mul. */
+int  bp_poly_scalar_op(bp_ctx* ctx, const void* a, size_t n, int basis, const void* s32, int op, int scalar_fmt,
+                       void* out);
+/* impl Mul for Polynomial, Monomial basis (polynomial.rs:240-273): out has na+nb-1 coefficients. */
+int  bp_poly_mul(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb, int basis, int scalar_fmt,
+                 void* out, size_t* n_out);
+/* impl Div for Polynomial (polynomial.rs:314-380): quotient only, exactly as the reference produces it
+ * (zero quotient coefficients are squeezed out).  out needs na slots. */
+int  bp_poly_div(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb, int basis, int scalar_fmt,
+                 void* out, size_t* n_out);
+/* Setup::commit (setup.rs:32-37): asserts Monomial basis, MSM of the coefficients against the SRS. */
+int  bp_commit(bp_ctx* ctx, uint64_t srs_handle, const void* coeffs, size_t n, int basis, int scalar_fmt,
+               uint8_t out96[96]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -135,6 +135,7 @@ void oracle_splitmix_scalars(fr_t *out, size_t n, uint64_t seed);     /* from_by
 void oracle_points_progression(g1_affine_t *out, size_t n, const fr_t *a, const fr_t *d);
 void oracle_points_to_bytes96(uint8_t *out, const g1_affine_t *p, size_t n);
 void oracle_proj_from_bytes96(g1_proj_t *out, const uint8_t *in, size_t n);
+void oracle_dot_progression(fr_t *r, const fr_t *s, size_t n, const fr_t *a, const fr_t *d);
 double oracle_now(void);
 
 #ifdef __cplusplus

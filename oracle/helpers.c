@@ -54,3 +54,14 @@ double oracle_now(void) {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
+/* r = sum_i s_i * (a + i*d)  -- the closed-form exponent of an MSM over the progression points */
+void oracle_dot_progression(fr_t *r, const fr_t *s, size_t n, const fr_t *a, const fr_t *d) {
+    fr_t acc, cur = *a, t;
+    fr_zero(&acc);
+    for (size_t i = 0; i < n; i++) {
+        fr_mul(&t, &s[i], &cur);
+        fr_add(&acc, &acc, &t);
+        fr_add(&cur, &cur, d);
+    }
+    *r = acc;
+}

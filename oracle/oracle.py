@@ -66,6 +66,7 @@ def _load():
         "oracle_splitmix_scalars": (None, [vp, sz, u64]),
         "oracle_points_progression": (None, [vp, sz, vp, vp]),
         "oracle_points_to_bytes96": (None, [vp, vp, sz]), "oracle_proj_from_bytes96": (None, [vp, vp, sz]),
+        "oracle_dot_progression": (None, [vp, vp, sz, vp, vp]),
         "oracle_now": (C.c_double, []),
     }
     for name, (res, args) in sig.items():
@@ -395,3 +396,11 @@ def poly_eval(coeffs, x, fast=False):
     out, x = u64(4), arr(x)
     (lib.poly_coeffs_evaluate_fast if fast else lib.poly_coeffs_evaluate)(_p(out), _p(coeffs), len(coeffs), _p(x))
     return out
+
+
+def dot_progression(scalars, a_int, d_int):
+    """integer k = sum_i s_i (a + i d) mod q"""
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    out, a, d = u64(4), fr_from_int(a_int), fr_from_int(d_int)
+    lib.oracle_dot_progression(_p(out), _p(scalars), len(scalars), _p(a), _p(d))
+    return fr_to_int(out)

@@ -1,0 +1,71 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/bp_msm_ntt.h declares; the
+host-only entry points (partials, encodings, roots of unity) work on the CPU and agree with the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import baby_plonk_rust_amd as bp
+from baby_plonk_rust_amd import _lib
+from oracle import oracle as O
+from tests import bigint_model as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "bp_msm_ntt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+    lib = bp.load()
+    names = header_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.SIGNATURES) == names          # python binding table and header agree
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(bp.BpError) as e:
+        bp.Context()
+    assert e.value.code == -8
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "baby_plonk_rust_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                for needle in ("import oracle", "from oracle", "oracle/", "liboracle", "bp_oracle", "oracle."):
+                    assert needle not in src, (needle, os.path.join(dirpath, f))
+
+
+def test_host_partials_and_encodings():
+    g = O.g1_generator()
+    pts = [O.g1_mul(g, O.fr_from_int(k)) for k in (5, 11, M.Q - 3)] + [O.g1_identity()]
+    raw = b"".join(p.tobytes() for p in pts)                     # G1Projective memory image = 144-byte partial
+    assert bp.sum_partials(raw) == M.enc96(M.ec_mul(5 + 11 - 3))
+    assert bp.sum_partials(b"") == M.enc96(None)
+    assert bp.sum_partials(pts[3].tobytes()) == M.enc96(None)
+    # bytes96 -> partial -> bytes96 round trip, and rejection of a non-canonical x
+    enc = M.enc96(M.ec_mul(77))
+    assert bp.sum_partials(bp.bytes96_to_partial(enc)) == enc
+    assert bp.sum_partials(bp.bytes96_to_partial(M.enc96(None))) == M.enc96(None)
+    with pytest.raises(bp.BpError):
+        bp.bytes96_to_partial(bytes([0x1F]) + bytes([0xFF] * 95))
+
+
+def test_root_of_unity_host():
+    for n in (1, 2, 4, 8, 1 << 16, 1 << 24, 3, 1000):      # non powers of two: integer division, as written
+        want = pow(M.ROOT_OF_UNITY, (1 << 32) // n, M.Q)
+        assert bp.scalar_to_int(bp.root_of_unity(n)) == want
+    with pytest.raises(bp.BpError):
+        bp.root_of_unity(0)
+    assert (bp.scalar_from_int(12345) == O.fr_from_int(12345)).all()

@@ -1,0 +1,117 @@
+"""-m gpu: Polynomial operators (src/polynomial.rs:14-380) through the C ABI vs the oracle restatement,
+including the reference's own unit-test literals (polynomial.rs:386-521) and its quirks."""
+import random
+
+import numpy as np
+import pytest
+
+import baby_plonk_rust_amd as bp
+from oracle import oracle as O
+from tests.gpu_common import Q
+
+pytestmark = pytest.mark.gpu
+MONO, LAG = bp.BASIS_MONOMIAL, bp.BASIS_LAGRANGE
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return bp.default_context()
+
+
+def P(vals, basis=MONO):
+    return bp.Polynomial(bp.scalars_from_ints([v % Q for v in vals]), basis)
+
+
+def ints(p):
+    return bp.scalars_to_ints(p.values)
+
+
+def S(v):
+    return bp.scalar_from_int(v % Q)
+
+
+def test_add_sub_scalar_literals(ctx):
+    assert ints(P([1, 2, 3]) + P([4, 5, 6])) == [5, 7, 9]
+    assert ints(P([1, 2, 3]) + P([4, 5])) == [5, 7, 3]
+    assert ints(P([4, 5, 6]) - P([1, 2])) == [3, 3, 6]
+    assert ints(P([1]) - P([1, 2])) == [0, Q - 2]
+    assert ints(P([1, 2, 3], LAG) + P([4, 5, 6], LAG)) == [5, 7, 9]
+    with pytest.raises(bp.BpError) as e:
+        P([1, 2, 3], LAG) + P([4, 5], LAG)
+    assert e.value.code == -6
+    with pytest.raises(bp.BpError) as e:
+        P([1, 2, 3], LAG) + P([4, 5, 6], MONO)
+    assert e.value.code == -5
+    assert ints(P([1, 2, 3]) * S(2)) == [2, 4, 6]
+    assert ints(P([1, 2, 3]) + S(2)) == [3, 2, 3]
+    assert ints(P([1, 2, 3], LAG) + S(2)) == [3, 4, 5]
+    assert ints(P([1, 2, 3]) - S(2)) == [Q - 1, 2, 3]
+    assert ints(P([1, 2, 3], LAG) - S(2)) == [3, 4, 5]           # reference quirk (polynomial.rs:126-128)
+    assert bp.scalars_to_ints(P([1, 2, 3], LAG).shift_left(1)) == [2, 3, 1]
+
+
+def test_mul_literals_and_random(ctx):
+    assert ints(P([1, 1]) * P([1, 1])) == [1, 2, 1]             # polynomial.rs:437-451
+    rnd = random.Random(31)
+    for na, nb in ((1, 1), (3, 2), (5, 8), (9, 9), (100, 29), (1000, 1025), (5000, 3000)):
+        a = O.splitmix_scalars(na, rnd.randrange(2**32))
+        b = O.splitmix_scalars(nb, rnd.randrange(2**32))
+        got = bp.Polynomial(a, MONO) * bp.Polynomial(b, MONO)
+        assert len(got) == na + nb - 1
+        assert (got.values == O.poly_binop("poly_mul_fast", a, b)).all()
+        if na + nb <= 20:
+            assert (got.values == O.poly_binop("poly_mul", a, b)).all()      # the reference's literal algorithm
+    with pytest.raises(bp.BpError) as e:
+        P([1, 2], LAG) * P([1, 2], LAG)                                      # todo!() in the reference
+    assert e.value.code == -5
+
+
+def test_eval(ctx):
+    assert bp.scalar_to_int(P([1, 3, 2]).coeffs_evaluate(S(2))) == 15
+    rnd = random.Random(32)
+    for n in (1, 2, 17, 256, 4097, 100000):
+        c = O.splitmix_scalars(n, rnd.randrange(2**32))
+        x = O.fr_from_int(rnd.randrange(Q))
+        assert (bp.Polynomial(c, MONO).coeffs_evaluate(x) == O.poly_eval(c, x, fast=True)).all()
+        if n <= 17:
+            assert (bp.Polynomial(c, MONO).coeffs_evaluate(x) == O.poly_eval(c, x)).all()
+    with pytest.raises(bp.BpError):
+        P([1, 2], LAG).coeffs_evaluate(S(3))
+
+
+def test_div_literals_quirk_and_random(ctx):
+    assert ints(P([-1, -1, -1, 3]) / P([-1, 1])) == [1, 2, 3]
+    assert ints(P([-1, -1, -1, 3, 0, 0]) / P([-1, 1, 0])) == [1, 2, 3]
+    assert ints(P([1, 0, 1]) / P([1, 1])) == [Q - 1, 1]
+    assert ints(P([-1, 0, 0, 0, 1]) / P([-1, 0, 1])) == [1, 1]    # zero quotient coefficient squeezed out
+    assert ints(P([5]) / P([1, 1])) == []
+    assert ints(P([0, 0]) / P([1, 1])) == []
+    with pytest.raises(bp.BpError) as e:
+        P([1, 2]) / P([0, 0])
+    assert e.value.code == -7
+    with pytest.raises(bp.BpError) as e:
+        P([1, 2], LAG) / P([1, 1], LAG)                           # polynomial.rs:523-547 test_lagrange_div panics
+    assert e.value.code == -5
+    rnd = random.Random(33)
+    # the prover's divisors: Z_H = x^n - 1 (prover.rs:450), x - zeta (prover.rs:623-638), plus general ones
+    for nq, divisor in ((9, [5, 0, 0, 7]), (40, [-1] + [0] * 7 + [1]), (3000, [-1] + [0] * 1023 + [1]),
+                        (5000, [-rnd.randrange(Q), 1]), (70, [3, 1, 4, 1, 5]), (300, [rnd.randrange(Q) for _ in range(33)])):
+        q = O.splitmix_scalars(nq, rnd.randrange(2**32))
+        dv = bp.scalars_from_ints([v % Q for v in divisor])
+        prod = O.poly_binop("poly_mul_fast", q, dv)
+        got = bp.Polynomial(prod, MONO) / bp.Polynomial(dv, MONO)
+        assert (got.values == q).all()
+        assert (got.values == O.poly_binop("poly_div", prod, dv)).all()
+        # with a remainder: quotient unchanged
+        prod2 = prod.copy()
+        prod2[0] = bp.scalar_from_int(bp.scalar_to_int(prod2[0]) + 1)
+        if len(divisor) > 1:
+            assert ((bp.Polynomial(prod2, MONO) / bp.Polynomial(dv, MONO)).values == O.poly_binop("poly_div", prod2, dv)).all()
+
+
+def test_ntt_roundtrip_methods(ctx):
+    c = O.splitmix_scalars(64, 99)
+    p = bp.Polynomial(c, MONO)
+    assert p.ntt().basis == LAG and (p.ntt().i_ntt().values == c).all()
+    with pytest.raises(bp.BpError):
+        p.i_ntt()

@@ -1,0 +1,98 @@
+"""CPU check of the product's __host__ __device__ arithmetic headers (bigint/fields/g1 .cuh): the same
+templates the kernels instantiate are compiled for the host (tests/hostcheck) with the device's 32-bit
+column multiplier selected, and compared with the oracle.  Catches logic errors before any GPU time."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.bigint_model import P, Q
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "hostcheck", "libhostcheck.so")
+
+
+@pytest.fixture(scope="module")
+def hc():
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostcheck"), "-s"])
+    lib = C.CDLL(SO)
+    for name in dir(lib):
+        pass
+    return lib
+
+
+def call(lib, name, out_words, *ins):
+    out = np.zeros(out_words, dtype=np.uint32)
+    keep = [np.ascontiguousarray(x).view(np.uint32) if isinstance(x, np.ndarray) else x for x in ins]
+    args = [out.ctypes.data] + [k.ctypes.data if isinstance(k, np.ndarray) else k for k in keep]
+    fn = getattr(lib, name)
+    fn.restype = None
+    fn.argtypes = [C.c_void_p] + [C.c_void_p if isinstance(k, np.ndarray) else (C.c_uint32 if i == 1 else C.c_int)
+                                  for i, k in enumerate(keep)]
+    fn(*args)
+    return out.view(np.uint64)
+
+
+def test_fr_ops(hc):
+    rnd = random.Random(11)
+    vals = [0, 1, Q - 1, Q - 2, 2**255 % Q] + [rnd.randrange(Q) for _ in range(60)]
+    for i in range(0, len(vals) - 1):
+        a, b = O.fr_from_int(vals[i]), O.fr_from_int(vals[i + 1])
+        assert (call(hc, "hc_fr_mul", 8, a, b) == O.fr_bin("fr_mul", a, b)).all()
+        assert (call(hc, "hc_fr_add", 8, a, b) == O.fr_bin("fr_add", a, b)).all()
+        assert (call(hc, "hc_fr_sub", 8, a, b) == O.fr_bin("fr_sub", a, b)).all()
+        assert (call(hc, "hc_fr_neg", 8, a) == O.fr_un("fr_neg", a)).all()
+        assert O.unlimbs(call(hc, "hc_fr_from_mont", 8, a)) == vals[i]
+    a = O.fr_from_int(vals[7])
+    assert (call(hc, "hc_fr_inv", 8, a) == O.fr_invert(a)[0]).all()
+
+
+def test_fp_ops(hc):
+    rnd = random.Random(12)
+    vals = [0, 1, P - 1, P - 2, (P - 1) // 2] + [rnd.randrange(P) for _ in range(60)]
+    for i in range(0, len(vals) - 1):
+        a, b = O.fp_from_int(vals[i]), O.fp_from_int(vals[i + 1])
+        assert (call(hc, "hc_fp_mul", 12, a, b) == O.fp_bin("fp_mul", a, b)).all()
+        assert (call(hc, "hc_fp_add", 12, a, b) == O.fp_bin("fp_add", a, b)).all()
+        assert (call(hc, "hc_fp_sub", 12, a, b) == O.fp_bin("fp_sub", a, b)).all()
+        assert (call(hc, "hc_fp_neg", 12, a) == O.fp_un("fp_neg", a)).all()
+    a = O.fp_from_int(vals[9])
+    assert (call(hc, "hc_fp_inv", 12, a) == O.fp_invert(a)[0]).all()
+
+
+def test_g1_ops(hc):
+    rnd = random.Random(13)
+    g = O.g1_generator()
+    pts = [g, O.g1_identity(), O.g1_double(g)] + [O.g1_mul(g, O.fr_from_int(rnd.randrange(Q))) for _ in range(4)]
+    for a in pts:
+        assert O.g1_eq(call(hc, "hc_g1_double", 36, a), O.g1_double(a))
+        for b in pts:
+            got = call(hc, "hc_g1_add", 36, a, b)
+            assert (got == O.g1_add(a, b)).all()                       # same formulas => same projective limbs
+            baff = O.g1_to_affine(b)
+            dev_aff = np.zeros(12, dtype=np.uint64) if baff[12] else baff[:12].copy()   # device identity = (0,0)
+            got = call(hc, "hc_g1_add_mixed", 36, a, dev_aff)
+            assert O.g1_eq(got, O.g1_add(a, b))
+    # P + (-P), P + P through the mixed formula
+    gaff = O.g1_to_affine(g)[:12].copy()
+    assert O.g1_eq(call(hc, "hc_g1_add_mixed", 36, g, gaff), O.g1_double(g))
+    assert O.lib.g1_is_identity(call(hc, "hc_g1_add_mixed", 36, O.g1_neg(g), gaff).ctypes.data)
+    k = rnd.randrange(Q)
+    kc = np.array(O.limbs(k, 4), dtype=np.uint64)
+    assert O.g1_eq(call(hc, "hc_g1_mul_scalar", 36, g, kc), O.g1_mul(g, O.fr_from_int(k)))
+    for small, bits in ((0, 0), (1, 1), (5, 3), (0x7ABC, 15)):
+        fn = hc.hc_g1_mul_small
+        out = np.zeros(36, dtype=np.uint32)
+        gg = g.copy()
+        fn.restype, fn.argtypes = None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        fn(out.ctypes.data, gg.ctypes.data, small, bits)
+        assert O.g1_eq(out.view(np.uint64), O.g1_mul(g, O.fr_from_int(small)))
+    aff = call(hc, "hc_g1_to_affine", 24, pts[4])
+    assert (aff == O.g1_to_affine(pts[4])[:12]).all()
+    assert (call(hc, "hc_g1_to_affine", 24, O.g1_identity()) == 0).all()
