@@ -6,6 +6,10 @@ that every symbol of the header is exported)."""
 import ctypes as C
 import os
 
+# torch bundles its own libamdhip64.so.7; importing it first makes the dynamic loader reuse that one runtime
+# for libbp_msm_ntt.so too (same SONAME).  Two HIP runtimes in one process cannot both see the GPU.
+import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libbp_msm_ntt.so")
 
