@@ -166,6 +166,10 @@ class Context:
         self.check(self._lib.bp_ntt_last_stats(self._h, C.byref(ms), C.byref(p)), "bp_ntt_last_stats")
         return {"device_ms": ms.value, "passes": p.value}
 
+    def synthetic_scalars_device(self, ptr, n, seed):
+        """fill HBM at `ptr` with n synthetic Montgomery scalars (the same stream the CPU baseline uses)"""
+        self.check(self._lib.bp_fr_synthetic_device(self._h, ptr, n, seed), "bp_fr_synthetic_device")
+
     def set_stream(self, stream_ptr):
         self.check(self._lib.bp_set_stream(self._h, stream_ptr), "bp_set_stream")
 

@@ -444,6 +444,14 @@ int bp_roots_of_unity(bp_ctx* ctx, uint64_t group_order, int scalar_fmt, void* o
   return download_fr(ctx, d, out, group_order, scalar_fmt);
 }
 
+int bp_fr_synthetic_device(bp_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
+  if (!ctx || (n && !d_out)) return BP_ERR_INVALID_ARG;
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  BP_TRY(fr_synthetic_run(ctx, (fr_t*)d_out, n, seed));
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- Polynomial
 int bp_poly_evaluate(bp_ctx* ctx, const void* coeffs, size_t n, int basis, const void* x32, int scalar_fmt, void* out32) {
   if (!ctx || !x32 || !out32 || !fmt_ok(scalar_fmt) || !basis_ok(basis) || (n && !coeffs)) return BP_ERR_INVALID_ARG;

@@ -19,6 +19,8 @@ struct FrParams {
   BP_TABLE(mod, 0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u)
   BP_TABLE(one, 0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau, 0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u)
   BP_TABLE(r2, 0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu, 0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u)
+  // R^3 (scalar.rs:183-188), used by from_u512 (scalar.rs:323-339)
+  BP_TABLE(r3, 0x439b73afu, 0xc62c1807u, 0x8cf06990u, 0x1b3e0d18u, 0xc7b5f418u, 0x73d13c71u, 0xc8db33e9u, 0x6e2a5bb9u)
   // scalar.rs:208-221
   BP_TABLE(root_of_unity, 0x5f0e466au, 0xb9b58d8cu, 0x1819d7ecu, 0x5b1b4c80u, 0x52a31e64u, 0x0af53ae3u, 0x19e9b27bu, 0x5bf3addau)
   BP_TABLE(root_of_unity_inv, 0xdcf3219au, 0x4256481au, 0x96b6cad3u, 0x45f37b7fu, 0x5f7a3b27u, 0xf9c3f1d7u, 0x658afd43u, 0x2d2fc049u)

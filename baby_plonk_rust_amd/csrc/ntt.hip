@@ -139,6 +139,12 @@ int fr_scalar_run(bp_ctx* ctx, const fr_t* a, const fr_t& s, fr_t* out, size_t n
   BP_HIP(ctx, hipGetLastError());
   return BP_OK;
 }
+int fr_synthetic_run(bp_ctx* ctx, fr_t* d_out, size_t n, uint64_t seed) {
+  if (n == 0) return BP_OK;
+  hipLaunchKernelGGL(fr_synthetic, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_out, n, seed);
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
 // out[j] = w^j, j < n   (roots_of_unity, utils.rs:45-52)
 int roots_run(bp_ctx* ctx, const fr_t& w, size_t n, fr_t* d_out) {
   if (n == 0) return BP_OK;

@@ -194,6 +194,39 @@ __global__ void __launch_bounds__(256) fr_scalar_op(const fr_t* a, fr_t s, fr_t*
   else Fr::mul(r, x, s);
   store_fr(&out[i], r);
 }
+// Synthetic uniform scalars: element i = from_u512 (scalar.rs:323-339) of eight
+// SplitMix64 outputs of the stream seeded with seed + 8*i*golden; Montgomery limbs out.
+__device__ __forceinline__ uint64_t splitmix64_next(uint64_t& s) {
+  uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) fr_synthetic(fr_t* __restrict__ out, size_t n, uint64_t seed) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t st = seed + 0x9e3779b97f4a7c15ull * 8ull * i;
+  fr_t d0, d1, r3;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint64_t z = splitmix64_next(st);
+    d0.l[2 * k] = (uint32_t)z;
+    d0.l[2 * k + 1] = (uint32_t)(z >> 32);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint64_t z = splitmix64_next(st);
+    d1.l[2 * k] = (uint32_t)z;
+    d1.l[2 * k + 1] = (uint32_t)(z >> 32);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) r3.l[k] = FrParams::r3(k);
+  // the Montgomery product needs a*b < q*R only, which holds for any 256-bit a and b < q
+  Fr::mul(d0, d0, Fr::r2());
+  Fr::mul(d1, d1, r3);
+  Fr::add(d0, d0, d1);
+  store_fr(&out[i], d0);
+}
 // in-place conversion between 32-byte LE canonical and Montgomery limbs (dir 0: to Montgomery, 1: from)
 __global__ void __launch_bounds__(256) fr_convert(fr_t* __restrict__ a, size_t n, int dir) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -103,6 +103,10 @@ int  bp_ntt_last_stats(bp_ctx* ctx, float* device_ms, uint32_t* passes);
 int  bp_root_of_unity(uint64_t group_order, int scalar_fmt, uint8_t out32[32]);
 int  bp_roots_of_unity(bp_ctx* ctx, uint64_t group_order, int scalar_fmt, void* out);
 
+/* Synthetic benchmark scalars written straight into HBM (Montgomery limbs): element i = Scalar::from_bytes_wide
+ * (scalar.rs:308-339) of 64 bytes of a SplitMix64 stream. Not in the reference. */
+int  bp_fr_synthetic_device(bp_ctx* ctx, void* d_out, size_t n, uint64_t seed);
+
 /* ---- Polynomial (src/polynomial.rs:14-380); values are n x 32-byte scalars in scalar_fmt ---------- */
 /* coeffs_evaluate (polynomial.rs:34-45); asserts Monomial basis. */
 int  bp_poly_evaluate(bp_ctx* ctx, const void* coeffs, size_t n, int basis, const void* x32, int scalar_fmt,
