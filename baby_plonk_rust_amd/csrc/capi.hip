@@ -193,8 +193,10 @@ void bp_destroy(bp_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->ws)
     if (kv.second.p) (void)hipFree(kv.second.p);
-  for (auto& kv : ctx->srs)
+  for (auto& kv : ctx->srs) {
     if (kv.second.d_points) (void)hipFree(kv.second.d_points);
+    if (kv.second.d_points28) (void)hipFree(kv.second.d_points28);
+  }
   for (auto& kv : ctx->ntt_tables) {
     (void)hipFree(kv.second.lo);
     (void)hipFree(kv.second.hi);
@@ -239,6 +241,12 @@ static int srs_register(bp_ctx* ctx, g1_affine* d, size_t n, uint64_t* handle) {
   SrsEntry e;
   e.d_points = d;
   e.n = n;
+  int rc = srs_to28_run(ctx, d, n, &e.d_points28);
+  if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BP_ERR_HIP;
+  if (rc != BP_OK) {
+    (void)hipFree(d);
+    return rc;
+  }
   *handle = ctx->next_handle++;
   ctx->srs[*handle] = e;
   return BP_OK;
@@ -319,6 +327,7 @@ int bp_srs_free(bp_ctx* ctx, uint64_t srs_handle) {
   BP_TRY(srs_find(ctx, srs_handle, &e));
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   BP_HIP(ctx, hipFree(e->d_points));
+  BP_HIP(ctx, hipFree(e->d_points28));
   ctx->srs.erase(srs_handle);
   return BP_OK;
 }
@@ -340,7 +349,7 @@ int bp_msm_g1_partial(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void
     d_scalars = d;
   }
   g1_proj r;
-  BP_TRY(msm_run(ctx, e->d_points + first, n, d_scalars, scalar_fmt, &r));
+  BP_TRY(msm_run(ctx, e->d_points + first, e->d_points28 + first, n, d_scalars, scalar_fmt, &r));
   memcpy(out144, &r, 144);
   return BP_OK;
 }

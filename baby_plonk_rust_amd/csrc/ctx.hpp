@@ -9,6 +9,7 @@
 
 #include "../../include/bp_msm_ntt.h"
 #include "g1.cuh"
+#include "g1_28.cuh"
 
 namespace bp {
 
@@ -18,7 +19,8 @@ struct DevBuf {
 };
 
 struct SrsEntry {
-  g1_affine* d_points = nullptr;
+  g1_affine* d_points = nullptr;        // 96 B/point, reference Montgomery limbs (export, generic kernels)
+  g1_affine28* d_points28 = nullptr;    // 112 B/point, 14 x 28-bit limbs, R' = 2^392 (bucket accumulation)
   size_t n = 0;
 };
 
@@ -73,7 +75,9 @@ int ws_get(bp_ctx* ctx, const char* name, size_t bytes, void** out);
 int pinned_get(bp_ctx* ctx, size_t bytes, void** out);
 
 // ---- launchers implemented in msm.hip / ntt.hip / poly.hip / srs.hip --------------------------------
-int msm_run(bp_ctx* ctx, const g1_affine* d_points, size_t n, const fr_t* d_scalars, int fmt, g1_proj* host_out);
+int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt,
+            g1_proj* host_out);
+int srs_to28_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28** d_out);
 int ntt_init_tables(bp_ctx* ctx);
 int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t log_n, int inverse, size_t batch, size_t stride);
 int fr_convert_run(bp_ctx* ctx, fr_t* d, size_t n, int dir);

@@ -1,0 +1,144 @@
+// g1_28.cuh -- the bucket-accumulation group law on the unsaturated field of fp28.cuh.
+// Same complete mixed addition as the reference (Renes-Costello-Batina Algorithm 8, g1.rs:715-752), with
+// lazy limbs; every intermediate's limb and value bounds are checked at compile time by the F28 types.
+#pragma once
+#include "fp28.cuh"
+#include "g1.cuh"
+
+namespace bp {
+
+// widen bounds (a value that satisfies tighter bounds also satisfies looser ones)
+template <class To, uint64_t A, uint32_t VA>
+BP_HD To widen28(const F28<A, VA>& a) {
+  static_assert(A <= To::limb_bound && VA <= To::value_bound, "cannot narrow bounds");
+  To r;
+#pragma unroll
+  for (int i = 0; i < N28; i++) r.l[i] = a.l[i];
+  return r;
+}
+
+// every projective coordinate that lives in a register file or in HBM between kernels has this type:
+// limbs <= 2^28 + 7, value < 6p.  All three group operations below map (C28, C28, C28) to itself.
+using C28 = F28<MASK28 + 8, 6>;
+using PtY28 = F28<MASK28 + 8, 2>;     // y or 2p - y after one normalisation
+
+struct g1_affine28 {                  // 112 bytes in HBM: x | y, 14 + 14 limbs; identity = all zero
+  F28n x, y;
+};
+struct g1_proj28 {                    // 168 bytes of limbs (stored padded to 176 B = 11 x 16 B)
+  C28 x, y, z;
+};
+constexpr int PROJ28_WORDS = 44;
+
+BP_HD g1_proj28 g1_identity28() {     // (0 : 1 : 0) with 1 = 2^392 mod p
+  g1_proj28 r;
+  fp_t one_std = Fp::one();
+  F28n one = fp_to_28(one_std);
+#pragma unroll
+  for (int i = 0; i < N28; i++) {
+    r.x.l[i] = 0;
+    r.y.l[i] = one.l[i];
+    r.z.l[i] = 0;
+  }
+  return r;
+}
+BP_HD bool g1_is_identity28(const g1_proj28& p) {     // Z == 0 mod p, Z lazy (< 6p): compare after full reduction
+  fp_t z = fp_from_28(p.z);
+  return big_is_zero(z);
+}
+BP_HD g1_affine28 g1_affine_to_28(const g1_affine& p) {
+  g1_affine28 r;
+  r.x = fp_to_28(p.x);                // (0,0) stays (0,0)
+  r.y = fp_to_28(p.y);
+  return r;
+}
+BP_HD g1_proj g1_proj_from_28(const g1_proj28& p) {
+  g1_proj r;
+  r.x = fp_from_28(p.x);
+  r.y = fp_from_28(p.y);
+  r.z = fp_from_28(p.z);
+  return r;
+}
+// y -> 2p - y when neg (kept lazy, one normalisation); limb-select keeps the wave convergent
+BP_HD PtY28 pt_y_signed(const F28n& y, bool neg) {
+  F28<0, 0> zero;
+#pragma unroll
+  for (int i = 0; i < N28; i++) zero.l[i] = 0;
+  auto ny = norm28(sub28<2, 29>(zero, y));          // 2p - y  in (p, 2p]
+  PtY28 a = widen28<PtY28>(ny), b = widen28<PtY28>(y), r;
+#pragma unroll
+  for (int i = 0; i < N28; i++) r.l[i] = neg ? a.l[i] : b.l[i];
+  return r;
+}
+
+// acc += (x2, y2)   -- RCB Algorithm 8 (g1.rs:715-752); (x2, y2) must not be the identity (caller selects)
+BP_HD void g1_add_mixed28(g1_proj28& acc, const F28n& x2, const PtY28& y2) {
+  const C28 &X1 = acc.x, &Y1 = acc.y, &Z1 = acc.z;
+  auto t0 = mul28(X1, x2);
+  auto t1 = mul28(Y1, y2);
+  auto t3 = mul28(add28(x2, y2), add28(X1, Y1));
+  auto t3s = norm28(sub28<8, 30>(t3, add28(t0, t1)));         // t3 - (t0 + t1)
+  auto t4 = add28(mul28(y2, Z1), Y1);                          // y2 Z1 + Y1
+  auto y3a = norm28(add28(mul28(x2, Z1), X1));                 // x2 Z1 + X1
+  auto t0x3 = mulk28<3>(t0);                                   // 3 t0
+  auto t2 = norm28(mulk28<12>(Z1));                            // 3b Z1
+  auto z3 = add28(t1, t2);
+  auto t1s = sub28<80, 29>(t1, t2);
+  auto y3 = norm28(mulk28<12>(y3a));                           // 3b (x2 Z1 + X1)
+  auto x3 = sub28<4, 29>(mul28(t3s, t1s), mul28(t4, y3));      // t3 t1 - t4 y3
+  auto yo = add28(mul28(t1s, z3), mul28(y3, t0x3));            // t1 z3 + y3 t0
+  auto zo = add28(mul28(z3, t4), mul28(t0x3, t3s));            // z3 t4 + t0 t3
+  acc.x = widen28<C28>(norm28(x3));
+  acc.y = widen28<C28>(norm28(yo));
+  acc.z = widen28<C28>(norm28(zo));
+}
+
+// r = a + b   -- RCB Algorithm 7 (g1.rs:670-712), complete
+BP_HD void g1_add28(g1_proj28& r, const g1_proj28& a, const g1_proj28& b) {
+  auto t0 = mul28(a.x, b.x);
+  auto t1 = mul28(a.y, b.y);
+  auto t2 = mul28(a.z, b.z);
+  auto t3 = norm28(sub28<8, 30>(mul28(add28(a.x, a.y), add28(b.x, b.y)), add28(t0, t1)));
+  auto t4 = norm28(sub28<8, 30>(mul28(add28(a.y, a.z), add28(b.y, b.z)), add28(t1, t2)));
+  auto y3a = norm28(sub28<8, 30>(mul28(add28(a.x, a.z), add28(b.x, b.z)), add28(t0, t2)));
+  auto t0x3 = mulk28<3>(t0);
+  auto t2b = norm28(mulk28<12>(t2));                            // 3b t2
+  auto z3 = add28(t1, t2b);
+  auto t1s = sub28<32, 29>(t1, t2b);
+  auto y3 = norm28(mulk28<12>(y3a));
+  auto x3 = sub28<4, 29>(mul28(t3, t1s), mul28(t4, y3));
+  auto yo = add28(mul28(t1s, z3), mul28(y3, t0x3));
+  auto zo = add28(mul28(z3, t4), mul28(t0x3, t3));
+  r.x = widen28<C28>(norm28(x3));
+  r.y = widen28<C28>(norm28(yo));
+  r.z = widen28<C28>(norm28(zo));
+}
+
+// r = 2 p   -- RCB Algorithm 9 (g1.rs:638-667)
+BP_HD void g1_double28(g1_proj28& r, const g1_proj28& p) {
+  auto t0 = mul28(p.y, p.y);
+  auto z8 = mulk28<8>(t0);
+  auto t1 = mul28(p.y, p.z);
+  auto t2 = norm28(mulk28<12>(mul28(p.z, p.z)));               // 3b Z^2
+  auto x3 = mul28(t2, z8);
+  auto y3 = add28(t0, t2);
+  auto zo = mul28(t1, z8);
+  auto t0s = sub28<80, 30>(t0, mulk28<3>(t2));                 // t0 - 3 t2
+  auto yo = add28(x3, mul28(t0s, y3));
+  auto xo = mulk28<2>(mul28(t0s, mul28(p.x, p.y)));
+  r.x = widen28<C28>(norm28(xo));
+  r.y = widen28<C28>(norm28(yo));
+  r.z = widen28<C28>(norm28(zo));
+}
+
+// r = k * p for a small non-negative integer k (< 2^nbits), MSB-first double-and-add
+BP_HD void g1_mul_small28(g1_proj28& r, const g1_proj28& p, uint32_t k, int nbits) {
+  g1_proj28 acc = g1_identity28();
+  for (int i = nbits - 1; i >= 0; i--) {
+    g1_double28(acc, acc);
+    if ((k >> i) & 1) g1_add28(acc, acc, p);
+  }
+  r = acc;
+}
+
+}  // namespace bp

@@ -2,6 +2,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "ctx.hpp"
 #include "msm_kernels.cuh"
 
@@ -72,7 +74,18 @@ static void make_plan(MsmPlan& plan, size_t n) {
   plan.seg = env_u32("BP_MSM_SEG", seg);
 }
 
-int msm_run(bp_ctx* ctx, const g1_affine* d_points, size_t n, const fr_t* d_scalars, int fmt, g1_proj* host_out) {
+// 112-byte unsaturated copy of an SRS (allocated here, owned by the SRS entry)
+int srs_to28_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28** d_out) {
+  g1_affine28* d = nullptr;
+  BP_HIP(ctx, hipMalloc((void**)&d, (n ? n : 1) * sizeof(g1_affine28)));
+  if (n) hipLaunchKernelGGL(srs_to28, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, n, d);
+  BP_HIP(ctx, hipGetLastError());
+  *d_out = d;
+  return BP_OK;
+}
+
+int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt,
+            g1_proj* host_out) {
   if (n == 0) {
     *host_out = g1_identity();
     ctx->msm_accumulate_ms = ctx->msm_total_ms = 0;
@@ -90,18 +103,20 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, size_t n, const fr_t* d_scal
 
   int16_t* digits;
   uint32_t *counts, *offsets, *cursors, *sorted;
-  g1_proj *bucket_sum, *partial, *block_out, *window_sum;
+  proj28_slot *bucket_sum, *partial, *block_out, *window_sum;
   BP_TRY(ws_get(ctx, "msm.digits", max_entries * sizeof(int16_t), (void**)&digits));
   BP_TRY(ws_get(ctx, "msm.counts", (size_t)total * 4, (void**)&counts));
   BP_TRY(ws_get(ctx, "msm.offsets", ((size_t)total + 1) * 4, (void**)&offsets));
   BP_TRY(ws_get(ctx, "msm.cursors", (size_t)total * 4, (void**)&cursors));
+  uint32_t* tile_sums;
+  BP_TRY(ws_get(ctx, "msm.tile_sums", 4096 * 4, (void**)&tile_sums));
   BP_TRY(ws_get(ctx, "msm.sorted", max_entries * 4, (void**)&sorted));
-  BP_TRY(ws_get(ctx, "msm.bucket_sum", (size_t)total * sizeof(g1_proj), (void**)&bucket_sum));
-  BP_TRY(ws_get(ctx, "msm.partial", 2 * n_chunks * sizeof(g1_proj), (void**)&partial));
-  BP_TRY(ws_get(ctx, "msm.block_out", (size_t)W * blocks_per_window * sizeof(g1_proj), (void**)&block_out));
-  BP_TRY(ws_get(ctx, "msm.window_sum", (size_t)W * sizeof(g1_proj), (void**)&window_sum));
-  g1_proj* h_windows;
-  BP_TRY(pinned_get(ctx, (size_t)W * sizeof(g1_proj), (void**)&h_windows));
+  BP_TRY(ws_get(ctx, "msm.bucket_sum", (size_t)total * sizeof(proj28_slot), (void**)&bucket_sum));
+  BP_TRY(ws_get(ctx, "msm.partial", 2 * n_chunks * sizeof(proj28_slot), (void**)&partial));
+  BP_TRY(ws_get(ctx, "msm.block_out", (size_t)W * blocks_per_window * sizeof(proj28_slot), (void**)&block_out));
+  BP_TRY(ws_get(ctx, "msm.window_sum", (size_t)W * sizeof(proj28_slot), (void**)&window_sum));
+  proj28_slot* h_windows;
+  BP_TRY(pinned_get(ctx, (size_t)W * sizeof(proj28_slot), (void**)&h_windows));
 
   static bool lds_attr_set = false;
   if (!lds_attr_set) {            // a full-window histogram at c = 16 needs 128 KiB of dynamic LDS
@@ -115,25 +130,36 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, size_t n, const fr_t* d_scal
   hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits);
   const size_t hist_bytes = (size_t)B * 4;
   hipLaunchKernelGGL(msm_count, dim3(plan.slices, W), dim3(256), hist_bytes, st, digits, plan, counts);
-  hipLaunchKernelGGL(scan_u32, dim3(1), dim3(1024), 0, st, counts, total, offsets, cursors);
+  const uint32_t n_tiles = (total + SCAN_TILE - 1) / SCAN_TILE;      // <= 4096 (total <= 2^24)
+  hipLaunchKernelGGL(scan_tile_sums, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums);
+  hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(256), 0, st, tile_sums, n_tiles, offsets + total);
+  hipLaunchKernelGGL(scan_apply, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums, offsets, cursors);
   hipLaunchKernelGGL(msm_scatter, dim3(plan.slices, W), dim3(256), hist_bytes, st, digits, plan, cursors, sorted);
   BP_HIP(ctx, hipEventRecord(ctx->ev[1], st));
-  hipLaunchKernelGGL(msm_accumulate, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, d_points, sorted, offsets, plan,
+  hipLaunchKernelGGL(msm_accumulate, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, d_points28, sorted, offsets, plan,
                      bucket_sum, partial);
   BP_HIP(ctx, hipEventRecord(ctx->ev[2], st));
   hipLaunchKernelGGL(msm_fixup, dim3((total + 255) / 256), dim3(256), 0, st, offsets, plan, bucket_sum, partial);
-  hipLaunchKernelGGL(msm_reduce, dim3(blocks_per_window, W), dim3(256), 256 * sizeof(g1_proj), st, offsets, plan, bucket_sum,
+  hipLaunchKernelGGL(msm_reduce, dim3(blocks_per_window, W), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
                      block_out);
-  hipLaunchKernelGGL(msm_window_finish, dim3((W + 63) / 64), dim3(64), 0, st, block_out, blocks_per_window, W, window_sum);
+  hipLaunchKernelGGL(msm_window_finish, dim3(W), dim3(256), 256 * sizeof(proj28_slot), st, block_out, blocks_per_window, window_sum);
   BP_HIP(ctx, hipGetLastError());
-  BP_HIP(ctx, hipMemcpyAsync(h_windows, window_sum, (size_t)W * sizeof(g1_proj), hipMemcpyDeviceToHost, st));
+  BP_HIP(ctx, hipMemcpyAsync(h_windows, window_sum, (size_t)W * sizeof(proj28_slot), hipMemcpyDeviceToHost, st));
   BP_HIP(ctx, hipEventRecord(ctx->ev[3], st));
   BP_HIP(ctx, hipStreamSynchronize(st));
   BP_HIP(ctx, hipEventElapsedTime(&ctx->msm_accumulate_ms, ctx->ev[1], ctx->ev[2]));
   BP_HIP(ctx, hipEventElapsedTime(&ctx->msm_total_ms, ctx->ev[0], ctx->ev[3]));
   ctx->msm_c = plan.c;
   ctx->msm_adds = max_entries;      // upper bound: zero digits are skipped (about n*W/2^c of them)
-  host_horner(*host_out, h_windows, W, plan.c);
+  // host epilogue: W window sums back to the reference's Montgomery limbs, then Horner (msm.rs:107-115)
+  std::vector<g1_proj> windows(W);
+  for (uint32_t w = 0; w < W; w++) {
+    g1_proj28 p;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&h_windows[w]);
+    for (int j = 0; j < N28; j++) { p.x.l[j] = src[j]; p.y.l[j] = src[N28 + j]; p.z.l[j] = src[2 * N28 + j]; }
+    windows[w] = g1_proj_from_28(p);
+  }
+  host_horner(*host_out, windows.data(), W, plan.c);
   return BP_OK;
 }
 

@@ -9,12 +9,13 @@
 //                       W signed c-bit digits (bias trick, no carry chain), written window-major.
 //   2. msm_count        per (window, slice) workgroup: LDS histogram of the 2^(c-1) buckets of one
 //                       window (c = 16 -> 128 KiB, which is why LDS size picks c), flushed to HBM.
-//   3. scan_u32         exclusive scan of all W * 2^(c-1) bucket sizes -> bucket offsets.
+//   3. scan_*           exclusive scan of all W * 2^(c-1) bucket sizes -> bucket offsets (3 launches).
 //   4. msm_scatter      same LDS histogram; one global atomic per (workgroup, bucket) reserves a range,
 //                       LDS atomics rank inside it; point indices land bucket-sorted (counting sort).
 //   5. msm_accumulate   the hot loop.  The bucket-sorted index list is cut into equal chunks, one per
 //                       lane, regardless of bucket boundaries: every lane performs the same number of
-//                       complete mixed additions (gathered 96-B affine points, accumulator in VGPRs),
+//                       complete mixed additions (gathered 112-B points of the unsaturated SRS copy, 14 x 28-bit
+//                       lazy limbs of fp28.cuh, accumulator in VGPRs),
 //                       so wave utilisation does not depend on the scalar distribution.  Runs that
 //                       cover a whole bucket are stored as the bucket sum; runs cut by a chunk edge go
 //                       to a per-lane partial slot.
@@ -26,6 +27,7 @@
 // divergent special cases.
 #pragma once
 #include "g1.cuh"
+#include "g1_28.cuh"
 
 namespace bp {
 
@@ -101,30 +103,80 @@ __global__ void __launch_bounds__(256) msm_count(const int16_t* __restrict__ dig
   }
 }
 
-// ---------------------------------------------------------------- 3. scan (single workgroup, 1024 lanes)
-// offsets[0..total] = exclusive prefix sums of counts[0..total); cursors = copy of offsets[0..total)
-__global__ void __launch_bounds__(1024) scan_u32(const uint32_t* __restrict__ counts, uint32_t total,
-                                                  uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors) {
-  __shared__ uint32_t sums[1024];
-  const uint32_t t = threadIdx.x, per = (total + 1023) / 1024;
-  const uint32_t lo = t * per < total ? t * per : total, hi = lo + per < total ? lo + per : total;
-  uint32_t s = 0;
-  for (uint32_t i = lo; i < hi; i++) s += counts[i];
-  sums[t] = s;
+// ---------------------------------------------------------------- 3. scan (three small launches)
+// offsets[0..total] = exclusive prefix sums of counts[0..total); cursors = copy of offsets[0..total).
+// Tile = 4096 counts per workgroup (256 lanes x 16).  scan_tile_sums -> scan_block_sums -> scan_apply.
+constexpr uint32_t SCAN_TILE = 4096, SCAN_PER_LANE = 16;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* lds, uint32_t& block_total) {
+  // wave-level inclusive scan by shuffles, then a 4-entry LDS hop across the waves of the workgroup
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t n = __shfl_up(incl, d, 64);
+    if (lane >= (uint32_t)d) incl += n;
+  }
+  if (lane == 63) lds[wave] = incl;
   __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {          // Hillis-Steele inclusive scan
-    uint32_t v = t >= d ? sums[t - d] : 0;
-    __syncthreads();
-    sums[t] += v;
-    __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    uint32_t x = lds[w];
+    if ((uint32_t)w < wave) base += x;
+    tot += x;
   }
-  uint32_t run = sums[t] - s;
-  for (uint32_t i = lo; i < hi; i++) {
-    offsets[i] = run;
-    cursors[i] = run;
-    run += counts[i];
+  __syncthreads();
+  block_total = tot;
+  return base + incl - v;
+}
+__global__ void __launch_bounds__(256) scan_tile_sums(const uint32_t* __restrict__ counts, uint32_t total, uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t lds[4];
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_LANE;
+  uint32_t s = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < SCAN_PER_LANE; j++) s += base + j < total ? counts[base + j] : 0;
+  uint32_t tot;
+  (void)block_exclusive_scan_256(s, lds, tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+// in-place exclusive scan of up to 256 * 16 tile sums by one workgroup; writes the grand total to *total_out
+__global__ void __launch_bounds__(256) scan_block_sums(uint32_t* __restrict__ tile_sums, uint32_t n_tiles, uint32_t* __restrict__ total_out) {
+  __shared__ uint32_t lds[4];
+  const uint32_t base = threadIdx.x * SCAN_PER_LANE;
+  uint32_t v[SCAN_PER_LANE], s = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < SCAN_PER_LANE; j++) {
+    v[j] = base + j < n_tiles ? tile_sums[base + j] : 0;
+    s += v[j];
   }
-  if (t == 1023) offsets[total] = sums[1023];
+  uint32_t tot, run = block_exclusive_scan_256(s, lds, tot);
+#pragma unroll
+  for (uint32_t j = 0; j < SCAN_PER_LANE; j++) {
+    if (base + j < n_tiles) tile_sums[base + j] = run;
+    run += v[j];
+  }
+  if (threadIdx.x == 0) *total_out = tot;
+}
+__global__ void __launch_bounds__(256) scan_apply(const uint32_t* __restrict__ counts, uint32_t total, const uint32_t* __restrict__ tile_sums,
+                                                   uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors) {
+  __shared__ uint32_t lds[4];
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER_LANE;
+  uint32_t v[SCAN_PER_LANE], s = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < SCAN_PER_LANE; j++) {
+    v[j] = base + j < total ? counts[base + j] : 0;
+    s += v[j];
+  }
+  uint32_t tot, run = tile_sums[blockIdx.x] + block_exclusive_scan_256(s, lds, tot);
+#pragma unroll
+  for (uint32_t j = 0; j < SCAN_PER_LANE; j++) {
+    if (base + j < total) {
+      offsets[base + j] = run;
+      cursors[base + j] = run;
+    }
+    run += v[j];
+  }
 }
 
 // ---------------------------------------------------------------- 4. scatter (counting sort)
@@ -170,26 +222,51 @@ __device__ __forceinline__ g1_affine load_affine(const g1_affine* __restrict__ p
   }
   return r;
 }
-__device__ __forceinline__ void store_proj(g1_proj* __restrict__ dst, const g1_proj& p) {
-  uint4* q = reinterpret_cast<uint4*>(dst);
-  const uint32_t* s = p.x.l;   // x | y | z are contiguous members
+// 112-byte point of the unsaturated SRS copy: 7 x dwordx4
+__device__ __forceinline__ g1_affine28 load_affine28(const g1_affine28* __restrict__ p) {
+  g1_affine28 r;
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 v[7];
 #pragma unroll
-  for (int j = 0; j < 9; j++) {
-    const uint32_t* f = j < 3 ? p.x.l + 4 * j : (j < 6 ? p.y.l + 4 * (j - 3) : p.z.l + 4 * (j - 6));
-    q[j] = make_uint4(f[0], f[1], f[2], f[3]);
-  }
-  (void)s;
+  for (int j = 0; j < 7; j++) v[j] = q[j];
+  uint32_t w[28];
+#pragma unroll
+  for (int j = 0; j < 7; j++) { w[4 * j] = v[j].x; w[4 * j + 1] = v[j].y; w[4 * j + 2] = v[j].z; w[4 * j + 3] = v[j].w; }
+#pragma unroll
+  for (int j = 0; j < N28; j++) { r.x.l[j] = w[j]; r.y.l[j] = w[N28 + j]; }
+  return r;
 }
-__device__ __forceinline__ g1_proj load_proj(const g1_proj* __restrict__ src) {
-  g1_proj p;
-  const uint4* q = reinterpret_cast<const uint4*>(src);
+// Projective accumulators travel between the MSM kernels as 44 words (x | y | z, 14 limbs each, + 2 pad)
+// = 11 x dwordx4, lazy limbs untouched: no conversion or reduction on the flush path.
+struct proj28_slot { uint4 q[11]; };
+__device__ __forceinline__ void store_proj28(proj28_slot* __restrict__ dst, const g1_proj28& p) {
+  uint32_t w[PROJ28_WORDS];
 #pragma unroll
-  for (int j = 0; j < 9; j++) {
-    uint4 v = q[j];
-    uint32_t* f = j < 3 ? p.x.l + 4 * j : (j < 6 ? p.y.l + 4 * (j - 3) : p.z.l + 4 * (j - 6));
-    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-  }
+  for (int j = 0; j < N28; j++) { w[j] = p.x.l[j]; w[N28 + j] = p.y.l[j]; w[2 * N28 + j] = p.z.l[j]; }
+  w[42] = 0; w[43] = 0;
+#pragma unroll
+  for (int j = 0; j < 11; j++) dst->q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+}
+__device__ __forceinline__ g1_proj28 load_proj28(const proj28_slot* __restrict__ src) {
+  uint32_t w[PROJ28_WORDS];
+#pragma unroll
+  for (int j = 0; j < 11; j++) { uint4 v = src->q[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+  g1_proj28 p;
+#pragma unroll
+  for (int j = 0; j < N28; j++) { p.x.l[j] = w[j]; p.y.l[j] = w[N28 + j]; p.z.l[j] = w[2 * N28 + j]; }
   return p;
+}
+// SRS: reference Montgomery limbs (96 B) -> unsaturated copy (112 B), once per SRS
+__global__ void __launch_bounds__(256) srs_to28(const g1_affine* __restrict__ in, size_t n, g1_affine28* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g1_affine28 r = g1_affine_to_28(load_affine(&in[i]));
+  uint4* q = reinterpret_cast<uint4*>(&out[i]);
+  uint32_t w[28];
+#pragma unroll
+  for (int j = 0; j < N28; j++) { w[j] = r.x.l[j]; w[N28 + j] = r.y.l[j]; }
+#pragma unroll
+  for (int j = 0; j < 7; j++) q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
 
 // largest g in [0, total) with offsets[g] <= p   (offsets is non-decreasing, offsets[0] = 0)
@@ -203,9 +280,9 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offse
 }
 
 __global__ void __launch_bounds__(256, 2)
-msm_accumulate(const g1_affine* __restrict__ points, const uint32_t* __restrict__ sorted,
-               const uint32_t* __restrict__ offsets, MsmPlan plan, g1_proj* __restrict__ bucket_sum,
-               g1_proj* __restrict__ partial) {
+msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restrict__ sorted,
+               const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
+               proj28_slot* __restrict__ partial) {
   const uint32_t total = plan.W * plan.B;
   const uint32_t M = offsets[total];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -217,28 +294,30 @@ msm_accumulate(const g1_affine* __restrict__ points, const uint32_t* __restrict_
   uint32_t g = bucket_of(offsets, total, p0);
   uint32_t g_end = offsets[g + 1];
   uint32_t run_start = p0;
-  g1_proj acc = g1_identity();
+  g1_proj28 acc = g1_identity28();
   for (uint32_t p = p0; p < p1; p++) {
     if (p >= g_end) {                            // leave bucket g: flush its run [run_start, p)
       const bool complete = run_start == offsets[g];    // it ended at g_end by construction
-      store_proj(complete ? &bucket_sum[g] : &partial[2 * (size_t)t + (run_start == p0 ? 0 : 1)], acc);
-      acc = g1_identity();
+      store_proj28(complete ? &bucket_sum[g] : &partial[2 * (size_t)t + (run_start == p0 ? 0 : 1)], acc);
+      acc = g1_identity28();
       run_start = p;
       do { g++; g_end = offsets[g + 1]; } while (p >= g_end);    // skip empty buckets
     }
     const uint32_t e = sorted[p];
-    g1_affine q = load_affine(&points[e & 0x7fffffffu]);
-    if (e >> 31) Fp::neg(q.y, q.y);
-    g1_add_mixed(acc, acc, q);
+    g1_affine28 q = load_affine28(&points[e & 0x7fffffffu]);
+    uint32_t nz = 0;
+#pragma unroll
+    for (int j = 0; j < N28; j++) nz |= q.x.l[j] | q.y.l[j];
+    if (nz) g1_add_mixed28(acc, q.x, pt_y_signed(q.y, (e >> 31) != 0));     // identity points (x = y = 0) add nothing
   }
   const bool complete = run_start == offsets[g] && p1 == g_end;
-  store_proj(complete ? &bucket_sum[g] : &partial[2 * (size_t)t + (run_start == p0 ? 0 : 1)], acc);
+  store_proj28(complete ? &bucket_sum[g] : &partial[2 * (size_t)t + (run_start == p0 ? 0 : 1)], acc);
 }
 
 // ---------------------------------------------------------------- 6. fixup
 __global__ void __launch_bounds__(256, 2)
-msm_fixup(const uint32_t* __restrict__ offsets, MsmPlan plan, g1_proj* __restrict__ bucket_sum,
-          const g1_proj* __restrict__ partial) {
+msm_fixup(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
+          const proj28_slot* __restrict__ partial) {
   const uint32_t total = plan.W * plan.B;
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
@@ -246,68 +325,74 @@ msm_fixup(const uint32_t* __restrict__ offsets, MsmPlan plan, g1_proj* __restric
   if (a == b) return;
   const uint32_t t_lo = a / plan.chunk, t_hi = (b - 1) / plan.chunk;
   if (t_lo == t_hi) return;                       // the whole bucket sat inside one chunk: already stored
-  g1_proj acc = g1_identity();
+  g1_proj28 acc = g1_identity28();
   for (uint32_t t = t_lo; t <= t_hi; t++) {
     const uint32_t slot = a <= t * plan.chunk ? 0 : 1;
-    g1_proj q = load_proj(&partial[2 * (size_t)t + slot]);
-    g1_add(acc, acc, q);
+    g1_proj28 q = load_proj28(&partial[2 * (size_t)t + slot]);
+    g1_add28(acc, acc, q);
   }
-  store_proj(&bucket_sum[g], acc);
+  store_proj28(&bucket_sum[g], acc);
 }
 
 // ---------------------------------------------------------------- 7. reduce: T_w = sum_b (b+1) * S_{w,b}
 // grid (blocks_per_window, W), 256 lanes; lane handles `seg` consecutive buckets.
 // out[w * gridDim.x + blockIdx.x] = this block's share.
-extern __shared__ uint32_t msm_lds_tree[];
+extern __shared__ uint4 msm_lds_tree[];
+
+__device__ __forceinline__ g1_proj28 block_tree_sum28(g1_proj28 v, uint32_t live) {
+  proj28_slot* tree = reinterpret_cast<proj28_slot*>(msm_lds_tree);
+  store_proj28(&tree[threadIdx.x], v);
+  __syncthreads();
+  uint32_t stride = 1;
+  while (stride < live) stride <<= 1;
+  for (stride >>= 1; stride > 0; stride >>= 1) {
+    if (threadIdx.x < stride && threadIdx.x + stride < live) {
+      g1_proj28 a = load_proj28(&tree[threadIdx.x]), b = load_proj28(&tree[threadIdx.x + stride]);
+      g1_add28(a, a, b);
+      store_proj28(&tree[threadIdx.x], a);
+    }
+    __syncthreads();
+  }
+  return load_proj28(&tree[0]);
+}
 
 __global__ void __launch_bounds__(256, 2)
-msm_reduce(const uint32_t* __restrict__ offsets, MsmPlan plan, const g1_proj* __restrict__ bucket_sum,
-           g1_proj* __restrict__ block_out) {
+msm_reduce(const uint32_t* __restrict__ offsets, MsmPlan plan, const proj28_slot* __restrict__ bucket_sum,
+           proj28_slot* __restrict__ block_out) {
   const uint32_t w = blockIdx.y, B = plan.B, seg = plan.seg;
   const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * seg;      // first bucket (0-based) of this lane
-  g1_proj acc = g1_identity(), wsum = g1_identity();
+  g1_proj28 acc = g1_identity28(), wsum = g1_identity28();
   if (first < B) {
     const uint32_t last = first + seg < B ? first + seg : B;
     for (uint32_t b = last; b-- > first;) {
       const size_t g = (size_t)w * B + b;
       if (offsets[g + 1] != offsets[g]) {
-        g1_proj s = load_proj(&bucket_sum[g]);
-        g1_add(acc, acc, s);
+        g1_proj28 s = load_proj28(&bucket_sum[g]);
+        g1_add28(acc, acc, s);
       }
-      g1_add(wsum, wsum, acc);                    // after the loop: sum_b (b - first + 1) * S_b
+      g1_add28(wsum, wsum, acc);                  // after the loop: sum_b (b - first + 1) * S_b
     }
     if (first != 0) {                             // + first * acc
-      g1_proj scaled;
-      g1_mul_small(scaled, acc, first, 32 - __clz(first));
-      g1_add(wsum, wsum, scaled);
+      g1_proj28 scaled;
+      g1_mul_small28(scaled, acc, first, 32 - __clz(first));
+      g1_add28(wsum, wsum, scaled);
     }
   }
-  // LDS tree over the 256 lanes
-  g1_proj* tree = reinterpret_cast<g1_proj*>(msm_lds_tree);
-  tree[threadIdx.x] = wsum;
-  __syncthreads();
-  for (uint32_t stride = blockDim.x >> 1; stride > 0; stride >>= 1) {
-    if (threadIdx.x < stride) {
-      g1_proj a = tree[threadIdx.x], b = tree[threadIdx.x + stride];
-      g1_add(a, a, b);
-      tree[threadIdx.x] = a;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) block_out[(size_t)w * gridDim.x + blockIdx.x] = tree[0];
+  g1_proj28 tot = block_tree_sum28(wsum, blockDim.x);
+  if (threadIdx.x == 0) store_proj28(&block_out[(size_t)w * gridDim.x + blockIdx.x], tot);
 }
 
-// window_sum[w] = sum of the block shares of window w (one lane per window)
-__global__ void __launch_bounds__(64) msm_window_finish(const g1_proj* __restrict__ block_out, uint32_t blocks_per_window,
-                                                         uint32_t W, g1_proj* __restrict__ window_sum) {
-  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= W) return;
-  g1_proj acc = g1_identity();
-  for (uint32_t j = 0; j < blocks_per_window; j++) {
-    g1_proj q = load_proj(&block_out[(size_t)w * blocks_per_window + j]);
-    g1_add(acc, acc, q);
+// window_sum[w] = sum of the block shares of window w: one workgroup per window, LDS tree over <= 256 shares
+__global__ void __launch_bounds__(256, 2) msm_window_finish(const proj28_slot* __restrict__ block_out, uint32_t blocks_per_window,
+                                                             proj28_slot* __restrict__ window_sum) {
+  const uint32_t w = blockIdx.x;
+  g1_proj28 v = g1_identity28();
+  for (uint32_t j = threadIdx.x; j < blocks_per_window; j += blockDim.x) {       // > 256 shares: fold first
+    g1_proj28 q = load_proj28(&block_out[(size_t)w * blocks_per_window + j]);
+    g1_add28(v, v, q);
   }
-  store_proj(&window_sum[w], acc);
+  g1_proj28 tot = block_tree_sum28(v, blocks_per_window < blockDim.x ? blocks_per_window : blockDim.x);
+  if (threadIdx.x == 0) store_proj28(&window_sum[w], tot);
 }
 
 }  // namespace bp

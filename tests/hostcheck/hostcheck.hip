@@ -25,3 +25,46 @@ void hc_g1_mul_scalar(uint32_t* r, const uint32_t* a, const uint32_t* k) { g1_pr
 void hc_g1_mul_small(uint32_t* r, const uint32_t* a, uint32_t k, int nbits) { g1_proj x, z; memcpy(&x, a, 144); g1_mul_small(z, x, k, nbits); memcpy(r, &z, 144); }
 void hc_g1_to_affine(uint32_t* r, const uint32_t* a) { g1_proj x; memcpy(&x, a, 144); g1_affine z = g1_to_affine(x); memcpy(r, &z, 96); }
 }
+
+// ---- unsaturated 14 x 28 field (fp28.cuh / g1_28.cuh) ----
+#include "../../baby_plonk_rust_amd/csrc/g1_28.cuh"
+extern "C" {
+// r (saturated Montgomery) = a * b through the 28-bit path: convert in, mul28, convert out
+void hc_fp28_mul(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+  fp_t x, y; memcpy(&x, a, 48); memcpy(&y, b, 48);
+  fp_t z = fp_from_28(mul28(fp_to_28(x), fp_to_28(y)));
+  memcpy(r, &z, 48);
+}
+void hc_fp28_roundtrip(uint32_t* r, const uint32_t* a) { fp_t x; memcpy(&x, a, 48); fp_t z = fp_from_28(fp_to_28(x)); memcpy(r, &z, 48); }
+// acc (144-byte saturated projective) += sign * affine point (96-byte saturated), n_rep times, through g1_add_mixed28
+void hc_g1_28_add_mixed(uint32_t* r, const uint32_t* acc_in, const uint32_t* pt, int neg, int reps) {
+  g1_proj a; g1_affine p; memcpy(&a, acc_in, 144); memcpy(&p, pt, 96);
+  g1_proj28 acc;
+  acc.x = widen28<C28>(fp_to_28(a.x)); acc.y = widen28<C28>(fp_to_28(a.y)); acc.z = widen28<C28>(fp_to_28(a.z));
+  g1_affine28 q = g1_affine_to_28(p);
+  for (int i = 0; i < reps; i++) g1_add_mixed28(acc, q.x, pt_y_signed(q.y, neg != 0));
+  g1_proj out = g1_proj_from_28(acc);
+  memcpy(r, &out, 144);
+}
+static g1_proj28 to28(const g1_proj& a) { g1_proj28 r; r.x = widen28<C28>(fp_to_28(a.x)); r.y = widen28<C28>(fp_to_28(a.y)); r.z = widen28<C28>(fp_to_28(a.z)); return r; }
+// r = (((a + b) + b) ... reps times) through g1_add28; doubling chain through g1_double28; small multiples
+void hc_g1_28_add(uint32_t* r, const uint32_t* a_in, const uint32_t* b_in, int reps) {
+  g1_proj a, b; memcpy(&a, a_in, 144); memcpy(&b, b_in, 144);
+  g1_proj28 x = to28(a), y = to28(b);
+  for (int i = 0; i < reps; i++) g1_add28(x, x, y);
+  g1_proj out = g1_proj_from_28(x); memcpy(r, &out, 144);
+}
+void hc_g1_28_double(uint32_t* r, const uint32_t* a_in, int reps) {
+  g1_proj a; memcpy(&a, a_in, 144);
+  g1_proj28 x = to28(a);
+  for (int i = 0; i < reps; i++) g1_double28(x, x);
+  g1_proj out = g1_proj_from_28(x); memcpy(r, &out, 144);
+}
+void hc_g1_28_mul_small(uint32_t* r, const uint32_t* a_in, uint32_t k, int nbits) {
+  g1_proj a; memcpy(&a, a_in, 144);
+  g1_proj28 x; g1_mul_small28(x, to28(a), k, nbits);
+  g1_proj out = g1_proj_from_28(x); memcpy(r, &out, 144);
+}
+int hc_g1_28_is_identity(const uint32_t* a_in) { g1_proj a; memcpy(&a, a_in, 144); return g1_is_identity28(to28(a)) ? 1 : 0; }
+void hc_g1_28_identity(uint32_t* r) { g1_proj out = g1_proj_from_28(g1_identity28()); memcpy(r, &out, 144); }
+}

@@ -96,3 +96,78 @@ def test_g1_ops(hc):
     aff = call(hc, "hc_g1_to_affine", 24, pts[4])
     assert (aff == O.g1_to_affine(pts[4])[:12]).all()
     assert (call(hc, "hc_g1_to_affine", 24, O.g1_identity()) == 0).all()
+
+
+def test_fp28_unsaturated_field(hc):
+    """fp28.cuh: 14 x 28-bit lazy limbs, R' = 2^392 -- multiply and domain conversions vs the oracle"""
+    rnd = random.Random(14)
+    vals = [0, 1, P - 1, P - 2, (P - 1) // 2, 2**380, 2**381 - 1] + [rnd.randrange(P) for _ in range(80)]
+    for i in range(len(vals) - 1):
+        a, b = O.fp_from_int(vals[i]), O.fp_from_int(vals[i + 1])
+        assert (call(hc, "hc_fp28_roundtrip", 12, a) == a).all()
+        assert (call(hc, "hc_fp28_mul", 12, a, b) == O.fp_bin("fp_mul", a, b)).all()
+
+
+def test_g1_28_mixed_add(hc):
+    """g1_28.cuh: complete mixed addition on lazy limbs, incl. identity / doubling / inverse cases and long chains"""
+    rnd = random.Random(15)
+    g = O.g1_generator()
+
+    def dev_aff(p):
+        a = O.g1_to_affine(p)
+        return np.zeros(12, dtype=np.uint64) if a[12] else a[:12].copy()
+
+    def add28(acc, pt, neg=0, reps=1):
+        fn = hc.hc_g1_28_add_mixed
+        fn.restype, fn.argtypes = None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        out = np.zeros(36, dtype=np.uint32)
+        a, q = np.ascontiguousarray(acc), np.ascontiguousarray(pt)
+        fn(out.ctypes.data, a.ctypes.data, q.ctypes.data, neg, reps)
+        return out.view(np.uint64)
+
+    ident = np.zeros(36, dtype=np.uint32)
+    hc.hc_g1_28_identity.restype, hc.hc_g1_28_identity.argtypes = None, [C.c_void_p]
+    hc.hc_g1_28_identity(ident.ctypes.data)
+    assert (ident.view(np.uint64) == O.g1_identity()).all()
+    pts = [g, O.g1_identity(), O.g1_double(g)] + [O.g1_mul(g, O.fr_from_int(rnd.randrange(Q))) for _ in range(5)]
+    for a in pts:
+        for b in pts[:1] + pts[2:]:                                   # the kernel never feeds an identity point
+            assert O.g1_eq(add28(a, dev_aff(b)), O.g1_add(a, b))
+            assert O.g1_eq(add28(a, dev_aff(b), neg=1), O.g1_add(a, O.g1_neg(b)))
+    assert O.g1_eq(add28(g, dev_aff(g)), O.g1_double(g))              # P + P
+    assert O.lib.g1_is_identity(add28(g, dev_aff(g), neg=1).ctypes.data)   # P - P
+    # bounds stay stable over a long run: 200 repeated additions = 200 * P
+    k = 200
+    assert O.g1_eq(add28(O.g1_identity(), dev_aff(pts[4]), reps=k), O.g1_mul(pts[4], O.fr_from_int(k)))
+    assert O.g1_eq(add28(pts[5], dev_aff(pts[4]), neg=1, reps=k), O.g1_add(pts[5], O.g1_neg(O.g1_mul(pts[4], O.fr_from_int(k)))))
+
+
+def test_g1_28_add_double_mul_small(hc):
+    """g1_28.cuh: complete projective add / double / small multiples on lazy limbs (used by fix-up and reduce)"""
+    rnd = random.Random(16)
+    g = O.g1_generator()
+    pts = [g, O.g1_identity(), O.g1_double(g)] + [O.g1_mul(g, O.fr_from_int(rnd.randrange(Q))) for _ in range(4)]
+
+    def run(name, argtypes, *args):
+        fn = getattr(hc, name)
+        fn.restype, fn.argtypes = None, [C.c_void_p] + argtypes
+        out = np.zeros(36, dtype=np.uint32)
+        keep = [np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a for a in args]
+        fn(out.ctypes.data, *[k.ctypes.data if isinstance(k, np.ndarray) else k for k in keep])
+        return out.view(np.uint64)
+
+    for a in pts:
+        assert O.g1_eq(run("hc_g1_28_double", [C.c_void_p, C.c_int], a, 1), O.g1_double(a))
+        for b in pts:
+            assert O.g1_eq(run("hc_g1_28_add", [C.c_void_p, C.c_void_p, C.c_int], a, b, 1), O.g1_add(a, b))
+        assert O.g1_eq(run("hc_g1_28_add", [C.c_void_p, C.c_void_p, C.c_int], a, O.g1_neg(a), 1), O.g1_identity())
+    # long chains keep the bounds: a + 150 b, 2^40 a
+    a, b = pts[3], pts[4]
+    assert O.g1_eq(run("hc_g1_28_add", [C.c_void_p, C.c_void_p, C.c_int], a, b, 150), O.g1_add(a, O.g1_mul(b, O.fr_from_int(150))))
+    assert O.g1_eq(run("hc_g1_28_double", [C.c_void_p, C.c_int], a, 40), O.g1_mul(a, O.fr_from_int(1 << 40)))
+    for k, bits in ((0, 0), (1, 1), (6, 3), (0x7FFF, 15), (0x4001, 15)):
+        assert O.g1_eq(run("hc_g1_28_mul_small", [C.c_void_p, C.c_uint32, C.c_int], a, k, bits), O.g1_mul(a, O.fr_from_int(k)))
+    isid = hc.hc_g1_28_is_identity
+    isid.restype, isid.argtypes = C.c_int, [C.c_void_p]
+    ident, gg = O.g1_identity(), g.copy()
+    assert isid(ident.ctypes.data) == 1 and isid(gg.ctypes.data) == 0
