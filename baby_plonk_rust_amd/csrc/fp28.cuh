@@ -140,6 +140,54 @@ BP_HD F28<MASK28, mul28_out_v(VA, VB)> mul28(const F28<A, VA>& a, const F28<B, V
   return r;
 }
 
+// Fused a*b + c*d with ONE Montgomery reduction: (a*b + c*d) / 2^392 mod p.  Saves the 14 x 14 reduction
+// products (and the m computations) of the second product; used for the three two-term outputs of the
+// complete addition formulas.
+template <uint64_t A, uint32_t VA, uint64_t B, uint32_t VB, uint64_t C, uint32_t VC, uint64_t D, uint32_t VD>
+BP_HD F28<MASK28, 1 + (VA * VB + VC * VD + 2047) / 2048> mul28_2(const F28<A, VA>& a, const F28<B, VB>& b, const F28<C, VC>& c,
+                                                                  const F28<D, VD>& d) {
+  static_assert((u128_t)14 * A * B + (u128_t)14 * C * D + ((u128_t)14 << 56) + ((u128_t)1 << 40) < ((u128_t)1 << 64),
+                "column overflow in mul28_2");
+  constexpr uint32_t VO = 1 + (VA * VB + VC * VD + 2047) / 2048;
+  static_assert(top_limb_bound(VO) <= MASK28, "result top limb");
+  F28<MASK28, VO> r;
+  uint32_t m[N28];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < N28; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i <= k; i++) acc += (uint64_t)c.l[i] * d.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P28::mod(k - i);
+    m[k] = ((uint32_t)acc * P28::INV) & MASK28;
+    acc += (uint64_t)m[k] * P28::mod(0);
+    acc >>= 28;
+  }
+#pragma unroll
+  for (int k = N28; k < 2 * N28 - 1; k++) {
+#pragma unroll
+    for (int i = k - N28 + 1; i < N28; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - N28 + 1; i < N28; i++) acc += (uint64_t)c.l[i] * d.l[k - i];
+#pragma unroll
+    for (int i = k - N28 + 1; i < N28; i++) acc += (uint64_t)m[i] * P28::mod(k - i);
+    r.l[k - N28] = (uint32_t)acc & MASK28;
+    acc >>= 28;
+  }
+  r.l[N28 - 1] = (uint32_t)acc;
+  return r;
+}
+// K*p - b (lazy negation, value in (0, K p])
+template <uint32_t K, int S, uint64_t B, uint32_t VB>
+BP_HD F28<kp_spread_max<K, S>(), K> neg28(const F28<B, VB>& b) {
+  F28<0, 0> zero;
+#pragma unroll
+  for (int i = 0; i < N28; i++) zero.l[i] = 0;
+  return sub28<K, S>(zero, b);
+}
+
 // ---- conversions between the saturated 12 x 32 form (fp_t) and 14 x 28 -----------------------------------
 // plain re-slicing of a 384-bit integer < 2^384 (no change of Montgomery radix)
 BP_HD F28n reslice_to28(const fp_t& a) {

@@ -85,12 +85,13 @@ BP_HD void g1_add_mixed28(g1_proj28& acc, const F28n& x2, const PtY28& y2) {
   auto z3 = add28(t1, t2);
   auto t1s = sub28<80, 29>(t1, t2);
   auto y3 = norm28(mulk28<12>(y3a));                           // 3b (x2 Z1 + X1)
-  auto x3 = sub28<4, 29>(mul28(t3s, t1s), mul28(t4, y3));      // t3 t1 - t4 y3
-  auto yo = add28(mul28(t1s, z3), mul28(y3, t0x3));            // t1 z3 + y3 t0
-  auto zo = add28(mul28(z3, t4), mul28(t0x3, t3s));            // z3 t4 + t0 t3
-  acc.x = widen28<C28>(norm28(x3));
-  acc.y = widen28<C28>(norm28(yo));
-  acc.z = widen28<C28>(norm28(zo));
+  // the three outputs are two-term products: one fused reduction each (mul28_2)
+  auto x3 = mul28_2(t3s, t1s, t4, neg28<128, 29>(y3));         // t3 t1 - t4 y3
+  auto yo = mul28_2(t1s, z3, y3, t0x3);                        // t1 z3 + y3 t0
+  auto zo = mul28_2(z3, t4, t0x3, t3s);                        // z3 t4 + t0 t3
+  acc.x = widen28<C28>(x3);
+  acc.y = widen28<C28>(yo);
+  acc.z = widen28<C28>(zo);
 }
 
 // r = a + b   -- RCB Algorithm 7 (g1.rs:670-712), complete
@@ -106,12 +107,12 @@ BP_HD void g1_add28(g1_proj28& r, const g1_proj28& a, const g1_proj28& b) {
   auto z3 = add28(t1, t2b);
   auto t1s = sub28<32, 29>(t1, t2b);
   auto y3 = norm28(mulk28<12>(y3a));
-  auto x3 = sub28<4, 29>(mul28(t3, t1s), mul28(t4, y3));
-  auto yo = add28(mul28(t1s, z3), mul28(y3, t0x3));
-  auto zo = add28(mul28(z3, t4), mul28(t0x3, t3));
-  r.x = widen28<C28>(norm28(x3));
-  r.y = widen28<C28>(norm28(yo));
-  r.z = widen28<C28>(norm28(zo));
+  auto x3 = mul28_2(t3, t1s, t4, neg28<128, 29>(y3));
+  auto yo = mul28_2(t1s, z3, y3, t0x3);
+  auto zo = mul28_2(z3, t4, t0x3, t3);
+  r.x = widen28<C28>(x3);
+  r.y = widen28<C28>(yo);
+  r.z = widen28<C28>(zo);
 }
 
 // r = 2 p   -- RCB Algorithm 9 (g1.rs:638-667)

@@ -136,8 +136,12 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
   hipLaunchKernelGGL(scan_apply, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums, offsets, cursors);
   hipLaunchKernelGGL(msm_scatter, dim3(plan.slices, W), dim3(256), hist_bytes, st, digits, plan, cursors, sorted);
   BP_HIP(ctx, hipEventRecord(ctx->ev[1], st));
-  hipLaunchKernelGGL(msm_accumulate, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, d_points28, sorted, offsets, plan,
-                     bucket_sum, partial);
+  const dim3 acc_grid((unsigned)((n_chunks + 255) / 256));
+  switch (env_u32("BP_MSM_ACC_WAVES", 2)) {
+    case 3: hipLaunchKernelGGL(msm_accumulate<3>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial); break;
+    case 4: hipLaunchKernelGGL(msm_accumulate<4>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial); break;
+    default: hipLaunchKernelGGL(msm_accumulate<2>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial);
+  }
   BP_HIP(ctx, hipEventRecord(ctx->ev[2], st));
   hipLaunchKernelGGL(msm_fixup, dim3((total + 255) / 256), dim3(256), 0, st, offsets, plan, bucket_sum, partial);
   hipLaunchKernelGGL(msm_reduce, dim3(blocks_per_window, W), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,

@@ -279,7 +279,8 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offse
   return lo;
 }
 
-__global__ void __launch_bounds__(256, 2)
+template <int WAVES>      // waves per SIMD the register allocator must leave room for
+__global__ void __launch_bounds__(256, WAVES)
 msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restrict__ sorted,
                const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
                proj28_slot* __restrict__ partial) {
