@@ -453,6 +453,16 @@ int bp_roots_of_unity(bp_ctx* ctx, uint64_t group_order, int scalar_fmt, void* o
   return download_fr(ctx, d, out, group_order, scalar_fmt);
 }
 
+int bp_fr_convert(const void* in, size_t n, int from_fmt, int to_fmt, void* out) {
+  if (!fmt_ok(from_fmt) || !fmt_ok(to_fmt) || (n && (!in || !out))) return BP_ERR_INVALID_ARG;
+  for (size_t i = 0; i < n; i++) {
+    fr_t v;
+    if (!fr_bytes_to_mont(v, (const uint8_t*)in + 32 * i, from_fmt)) return BP_ERR_BAD_SCALAR;
+    fr_mont_to_bytes((uint8_t*)out + 32 * i, v, to_fmt);
+  }
+  return BP_OK;
+}
+
 int bp_fr_synthetic_device(bp_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
   if (!ctx || (n && !d_out)) return BP_ERR_INVALID_ARG;
   BP_HIP(ctx, hipSetDevice(ctx->device));

@@ -129,12 +129,13 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
   BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4, st));
   hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits);
   const size_t hist_bytes = (size_t)B * 4;
-  hipLaunchKernelGGL(msm_count, dim3(plan.slices, W), dim3(256), hist_bytes, st, digits, plan, counts);
+  const unsigned hist_threads = B >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
+  hipLaunchKernelGGL(msm_count, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, digits, plan, counts);
   const uint32_t n_tiles = (total + SCAN_TILE - 1) / SCAN_TILE;      // <= 4096 (total <= 2^24)
   hipLaunchKernelGGL(scan_tile_sums, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums);
   hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(256), 0, st, tile_sums, n_tiles, offsets + total);
   hipLaunchKernelGGL(scan_apply, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums, offsets, cursors);
-  hipLaunchKernelGGL(msm_scatter, dim3(plan.slices, W), dim3(256), hist_bytes, st, digits, plan, cursors, sorted);
+  hipLaunchKernelGGL(msm_scatter, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, digits, plan, cursors, sorted);
   BP_HIP(ctx, hipEventRecord(ctx->ev[1], st));
   const dim3 acc_grid((unsigned)((n_chunks + 255) / 256));
   switch (env_u32("BP_MSM_ACC_WAVES", 2)) {

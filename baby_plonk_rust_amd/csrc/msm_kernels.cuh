@@ -84,7 +84,7 @@ __device__ __forceinline__ void slice_range(const MsmPlan& plan, uint32_t slice,
   if (lo > plan.n) lo = plan.n;
 }
 
-__global__ void __launch_bounds__(256) msm_count(const int16_t* __restrict__ digits, MsmPlan plan,
+__global__ void __launch_bounds__(1024) msm_count(const int16_t* __restrict__ digits, MsmPlan plan,
                                                   uint32_t* __restrict__ counts) {
   const uint32_t w = blockIdx.y, B = plan.B;
   for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) msm_lds_hist[b] = 0;
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) scan_apply(const uint32_t* __restrict__ c
 }
 
 // ---------------------------------------------------------------- 4. scatter (counting sort)
-__global__ void __launch_bounds__(256) msm_scatter(const int16_t* __restrict__ digits, MsmPlan plan,
+__global__ void __launch_bounds__(1024) msm_scatter(const int16_t* __restrict__ digits, MsmPlan plan,
                                                     uint32_t* __restrict__ cursors, uint32_t* __restrict__ sorted) {
   const uint32_t w = blockIdx.y, B = plan.B;
   for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) msm_lds_hist[b] = 0;
@@ -296,6 +296,9 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
   uint32_t g_end = offsets[g + 1];
   uint32_t run_start = p0;
   g1_proj28 acc = g1_identity28();
+  // software pipeline: the gather of entry p+1 is in flight while entry p is added
+  uint32_t e_next = sorted[p0];
+  g1_affine28 q_next = load_affine28(&points[e_next & 0x7fffffffu]);
   for (uint32_t p = p0; p < p1; p++) {
     if (p >= g_end) {                            // leave bucket g: flush its run [run_start, p)
       const bool complete = run_start == offsets[g];    // it ended at g_end by construction
@@ -304,8 +307,12 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
       run_start = p;
       do { g++; g_end = offsets[g + 1]; } while (p >= g_end);    // skip empty buckets
     }
-    const uint32_t e = sorted[p];
-    g1_affine28 q = load_affine28(&points[e & 0x7fffffffu]);
+    const uint32_t e = e_next;
+    const g1_affine28 q = q_next;
+    if (p + 1 < p1) {
+      e_next = sorted[p + 1];
+      q_next = load_affine28(&points[e_next & 0x7fffffffu]);
+    }
     uint32_t nz = 0;
 #pragma unroll
     for (int j = 0; j < N28; j++) nz |= q.x.l[j] | q.y.l[j];

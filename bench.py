@@ -30,6 +30,7 @@ import torch
 import torch.distributed as dist
 
 import baby_plonk_rust_amd as bp
+from baby_plonk_rust_amd import dist as bpd
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 MSM_BYTES_PER_UNIT = 128         # 32 B scalar + 96 B affine point per scalar-mul
@@ -101,15 +102,11 @@ def main():
     srs = ctx.srs_generate_progression(n, A0 + rank * n * D0, D0)
     scal = torch.empty(n * 4, dtype=torch.int64, device=dev)
     ctx.synthetic_scalars_device(scal.data_ptr(), n, (0x5EED0000 + args.log_n + GOLDEN * 8 * rank * n) & (2**64 - 1))
-    gathered = torch.empty(world * 144, dtype=torch.uint8, device=dev)
 
     def msm_step():
-        part = ctx.msm_partial(srs, None, device_ptr=scal.data_ptr(), n=n)
-        if world > 1:
-            mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
-            dist.all_gather_into_tensor(gathered, mine)          # the single RCCL collective: 144 B per rank
-            return bp.sum_partials(gathered.cpu().numpy().tobytes())
-        return bp.sum_partials(part)
+        # per-rank Pippenger on the resident shard, then (N > 1) the single RCCL all-gather of 144 B per rank
+        # and the N-1 complete additions on every rank (baby_plonk_rust_amd/dist.py)
+        return bpd.msm_sharded(ctx, srs, None, device_ptr=scal.data_ptr(), n=n)
 
     for _ in range(args.warmup):
         result = msm_step()

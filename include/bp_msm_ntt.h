@@ -103,6 +103,10 @@ int  bp_ntt_last_stats(bp_ctx* ctx, float* device_ms, uint32_t* passes);
 int  bp_root_of_unity(uint64_t group_order, int scalar_fmt, uint8_t out32[32]);
 int  bp_roots_of_unity(bp_ctx* ctx, uint64_t group_order, int scalar_fmt, void* out);
 
+/* Host-side format conversion of n scalars between BP_FR_BYTES_LE and BP_FR_MONT (Scalar::from_bytes / to_bytes,
+ * scalar.rs:264-304); returns BP_ERR_BAD_SCALAR for a canonical input >= q.  in == out is allowed. */
+int  bp_fr_convert(const void* in, size_t n, int from_fmt, int to_fmt, void* out);
+
 /* Synthetic benchmark scalars written straight into HBM (Montgomery limbs): element i = Scalar::from_bytes_wide
  * (scalar.rs:308-339) of 64 bytes of a SplitMix64 stream. Not in the reference. */
 int  bp_fr_synthetic_device(bp_ctx* ctx, void* d_out, size_t n, uint64_t seed);

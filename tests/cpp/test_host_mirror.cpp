@@ -1,0 +1,82 @@
+// C++ parity test of the host-side mirror (baby_plonk_rust_amd/host/baby_plonk.hpp): restates the reference's own
+// unit tests for the path -- src/setup.rs:46-116 (test_generate_srs, test_monomial_commit), src/polynomial.rs:386-521,
+// src/utils.rs:239-242 -- through the mirror's Rust-shaped API.  Needs a GPU; built and run by tests/test_gpu_cpp_mirror.py.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../baby_plonk_rust_amd/host/baby_plonk.hpp"
+
+using namespace baby_plonk;
+
+#define CHECK(cond)                                                         \
+  do {                                                                      \
+    if (!(cond)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); std::exit(1); } \
+  } while (0)
+
+static Scalar S(uint64_t v) { return Scalar::from_u64(v); }
+static Scalar neg(const Scalar& a) {                     // 0 - a through Polynomial - Polynomial
+  Polynomial z({Scalar::zero()}, Basis::Monomial), p({a}, Basis::Monomial);
+  return (z - p).values[0];
+}
+static Polynomial mono(std::vector<Scalar> v) { return Polynomial(std::move(v), Basis::Monomial); }
+static std::array<uint8_t, 32> le(uint64_t v) {
+  std::array<uint8_t, 32> b{};
+  for (int i = 0; i < 8; i++) b[i] = (uint8_t)(v >> (8 * i));
+  return b;
+}
+template <class F>
+static bool panics(F f, int code) {
+  try { f(); } catch (const Panic& p) { return p.code == code; }
+  return false;
+}
+
+int main() {
+  // ---- src/utils.rs:239-242 test_root_of_unity
+  {
+    Polynomial w({root_of_unity(4)}, Basis::Monomial);
+    Polynomial w2 = w * w, w4 = w2 * w2;
+    CHECK(w4.values[0] == S(1));
+    CHECK(w2.values[0] != S(1));
+    auto roots = roots_of_unity(8);
+    CHECK(roots.size() == 8 && roots[0] == S(1) && roots[1] == root_of_unity(8));
+  }
+  // ---- src/polynomial.rs tests
+  {
+    CHECK((mono({S(1), S(2), S(3)}) + mono({S(4), S(5), S(6)})) == mono({S(5), S(7), S(9)}));
+    CHECK((mono({S(1), S(2), S(3)}) + mono({S(4), S(5)})) == mono({S(5), S(7), S(3)}));
+    CHECK((mono({S(4), S(5), S(6)}) - mono({S(1), S(2)})) == mono({S(3), S(3), S(6)}));
+    CHECK((mono({S(1), S(2), S(3)}) * S(2)) == mono({S(2), S(4), S(6)}));
+    CHECK((mono({S(1), S(1)}) * mono({S(1), S(1)})) == mono({S(1), S(2), S(1)}));                  // (1+x)^2, :437-451
+    CHECK(mono({S(1), S(3), S(2)}).coeffs_evaluate(S(2)) == S(15));
+    // (3x^3 - x^2 - x - 1) / (x - 1) = 3x^2 + 2x + 1
+    Polynomial num = mono({neg(S(1)), neg(S(1)), neg(S(1)), S(3)}), den = mono({neg(S(1)), S(1)});
+    CHECK((num / den) == mono({S(1), S(2), S(3)}));
+    CHECK(panics([&] { Polynomial({S(1), S(2)}, Basis::Lagrange) / Polynomial({S(1), S(1)}, Basis::Lagrange); }, BP_ERR_BASIS));   // :523-547
+    CHECK(panics([&] { mono({S(1)}) / mono({Scalar::zero()}); }, BP_ERR_DIV_ZERO));
+    CHECK(panics([&] { Polynomial({S(1), S(2), S(3)}, Basis::Lagrange) + Polynomial({S(1)}, Basis::Lagrange); }, BP_ERR_LENGTH));
+    CHECK(panics([&] { ntt_381({S(1), S(2), S(3)}); }, BP_ERR_NOT_POW2));                         // utils.rs:65
+    std::vector<Scalar> v = {S(3), S(3)};
+    CHECK(i_ntt_381(ntt_381(v)) == v);                                                            // setup.rs:128-135
+    CHECK(ntt_381(v) == (std::vector<Scalar>{S(6), S(0)}));
+    CHECK(Scalar::from_bytes(S(77).to_bytes()) == S(77));
+  }
+  // ---- src/setup.rs:46-57 test_generate_srs and :60-116 test_monomial_commit
+  {
+    Setup s2 = Setup::generate_srs(8, le(2));
+    auto pts = s2.powers_of_x();
+    CHECK(pts.size() == 8);
+    // powers_of_x[i] == G * tau^i: compare with a one-point MSM of G by tau^i
+    for (uint64_t i = 0; i < 8; i++) CHECK(BucketMSM::bucket_msm({pts[0]}, {S(1ull << i)}) == pts[i]);
+    Setup s10 = Setup::generate_srs(2, le(10));
+    G1 commitment = s10.commit(mono({S(2), S(3)}));
+    CHECK(commitment == BucketMSM::bucket_msm({pts[0]}, {S(32)}));                                 // 2 g1 + 3 * 10 g1
+    CHECK(s2.commit(mono({S(0), S(1)})) == pts[1]);                                                // x -> tau G
+    CHECK(s2.commit(mono({S(0), S(0), S(1)})) == pts[2]);
+    // zip truncation (msm.rs:29): more scalars than points, fewer scalars than points
+    CHECK(BucketMSM::bucket_msm({pts[0], pts[1]}, {S(5), S(7), S(9)}) == BucketMSM::bucket_msm({pts[0]}, {S(19)}));
+    CHECK(BucketMSM::bucket_msm({pts[0], pts[1], pts[2]}, {S(5)}) == BucketMSM::bucket_msm({pts[0]}, {S(5)}));
+    CHECK(panics([&] { s2.commit(Polynomial({S(1)}, Basis::Lagrange)); }, BP_ERR_BASIS));          // setup.rs:34
+  }
+  std::printf("host mirror ok\n");
+  return 0;
+}
