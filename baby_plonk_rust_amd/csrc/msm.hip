@@ -34,25 +34,34 @@ static void make_plan(MsmPlan& plan, size_t n) {
   // for every k < q.  Take W = ceil(256 / c) and check the bound with the real q; add a window if it fails.
   static const uint32_t q_minus_1[8] = {0x00000000u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
                                         0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
-  uint32_t W = (256 + c - 1) / c;
+  // Windows 0..W-2 are signed: d_w = ((k + bias) >> cw & mask) - 2^(c-1), bias = sum_{w<W-1} 2^(c-1) 2^(cw).
+  // The top window is unsigned (digit = remaining high bits, carry included) and must fit a bucket index,
+  // i.e. be <= 2^(c-1) for every k < q.  Smallest such W:
+  uint32_t W = (255 + c - 1) / c;
+  if (W < 2) W = 2;
   for (;;) {
     uint32_t bias[10] = {0};
-    for (uint32_t w = 0; w < W; w++) {
+    for (uint32_t w = 0; w + 1 < W; w++) {
       uint32_t bit = c * w + c - 1;
       if (bit < 320) bias[bit >> 5] |= 1u << (bit & 31);
     }
     uint64_t carry = 0;
-    uint32_t sum[10];
+    uint32_t sum[11] = {0};
     for (int j = 0; j < 10; j++) {
       carry += (uint64_t)(j < 8 ? q_minus_1[j] : 0u) + bias[j];
       sum[j] = (uint32_t)carry;
       carry >>= 32;
     }
-    // highest set bit of sum must be below c*W
-    int top = -1;
-    for (int b = 319; b >= 0; b--)
-      if ((sum[b >> 5] >> (b & 31)) & 1) { top = b; break; }
-    if (top < (int)(c * W) && c * W <= 288) {
+    // top digit of the largest scalar: (q - 1 + bias) >> c (W - 1), as an exact 320-bit shift
+    const uint32_t o = c * (W - 1);
+    bool ok = o < 288;
+    uint64_t top = 0;
+    for (int bit = 319; bit >= (int)o && ok; bit--) {
+      if ((sum[bit >> 5] >> (bit & 31)) & 1) {
+        if (bit - (int)o >= 32) ok = false; else top |= 1ull << (bit - o);
+      }
+    }
+    if (ok && top <= (1ull << (c - 1))) {
       memcpy(plan.bias, bias, sizeof plan.bias);
       break;
     }
@@ -108,6 +117,11 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
   BP_TRY(ws_get(ctx, "msm.counts", (size_t)total * 4, (void**)&counts));
   BP_TRY(ws_get(ctx, "msm.offsets", ((size_t)total + 1) * 4, (void**)&offsets));
   BP_TRY(ws_get(ctx, "msm.cursors", (size_t)total * 4, (void**)&cursors));
+  // a bucket is "long" when it spans >= FIXUP_LONG chunks, so at most n_chunks / FIXUP_LONG + 1 buckets can be long
+  const uint32_t long_cap = (uint32_t)(n_chunks / FIXUP_LONG + 1);
+  uint32_t *long_count, *long_list;
+  BP_TRY(ws_get(ctx, "msm.long_count", 4, (void**)&long_count));
+  BP_TRY(ws_get(ctx, "msm.long_list", (size_t)long_cap * 4, (void**)&long_list));
   uint32_t* tile_sums;
   BP_TRY(ws_get(ctx, "msm.tile_sums", 4096 * 4, (void**)&tile_sums));
   BP_TRY(ws_get(ctx, "msm.sorted", max_entries * 4, (void**)&sorted));
@@ -127,6 +141,7 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
   hipStream_t st = ctx->stream;
   BP_HIP(ctx, hipEventRecord(ctx->ev[0], st));
   BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4, st));
+  BP_HIP(ctx, hipMemsetAsync(long_count, 0, 4, st));
   hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits);
   const size_t hist_bytes = (size_t)B * 4;
   const unsigned hist_threads = B >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
@@ -144,7 +159,10 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
     default: hipLaunchKernelGGL(msm_accumulate<2>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial);
   }
   BP_HIP(ctx, hipEventRecord(ctx->ev[2], st));
-  hipLaunchKernelGGL(msm_fixup, dim3((total + 255) / 256), dim3(256), 0, st, offsets, plan, bucket_sum, partial);
+  hipLaunchKernelGGL(msm_fixup, dim3((total + 255) / 256), dim3(256), 0, st, offsets, plan, bucket_sum, partial, long_count, long_list,
+                     long_cap);
+  hipLaunchKernelGGL(msm_fixup_long, dim3(64), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
+                     long_count, long_list, long_cap);
   hipLaunchKernelGGL(msm_reduce, dim3(blocks_per_window, W), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
                      block_out);
   hipLaunchKernelGGL(msm_window_finish, dim3(W), dim3(256), 256 * sizeof(proj28_slot), st, block_out, blocks_per_window, window_sum);

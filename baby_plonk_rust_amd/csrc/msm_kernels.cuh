@@ -42,7 +42,7 @@ struct MsmPlan {
   uint32_t chunk;      // entries per lane in msm_accumulate
   uint32_t slices;     // workgroups per window in count/scatter
   uint32_t seg;        // buckets per lane in msm_reduce
-  uint32_t bias[9];    // sum_w 2^(c-1) * 2^(c*w)
+  uint32_t bias[9];    // sum_{w < W-1} 2^(c-1) * 2^(c*w)   (the top window is unsigned)
 };
 
 // ---------------------------------------------------------------- 1. digits
@@ -66,7 +66,8 @@ __global__ void __launch_bounds__(256) msm_digits(const fr_t* __restrict__ scala
   for (uint32_t w = 0; w < plan.W; w++) {
     uint32_t o = c * w, word = o >> 5, sh = o & 31;
     uint64_t two = (uint64_t)kp[word] | ((uint64_t)kp[word + 1] << 32);
-    int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (int32_t)half;
+    // windows below the top one are signed (bias already added); the top window keeps its small unsigned value
+    int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (w + 1 < plan.W ? (int32_t)half : 0);
     digits[(size_t)w * plan.n + i] = (int16_t)d;
   }
 }
@@ -323,9 +324,18 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
 }
 
 // ---------------------------------------------------------------- 6. fixup
+// Buckets that straddle chunk edges: add their partials.  Short chains (the common case: 2-3 partials) are
+// summed by one lane; a bucket cut into more than FIXUP_LONG chunks (skewed scalars, the narrow top window)
+// is queued for msm_fixup_long, where a whole workgroup strides over its partials and tree-reduces in LDS.
+constexpr uint32_t FIXUP_LONG = 16;
+
+__device__ __forceinline__ uint32_t partial_slot(uint32_t bucket_start, uint32_t t, uint32_t chunk) {
+  return bucket_start <= t * chunk ? 0u : 1u;     // slot 0 = run that begins at the chunk start, 1 = run that ends at its end
+}
 __global__ void __launch_bounds__(256, 2)
 msm_fixup(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
-          const proj28_slot* __restrict__ partial) {
+          const proj28_slot* __restrict__ partial, uint32_t* __restrict__ long_count, uint32_t* __restrict__ long_list,
+          uint32_t long_cap) {
   const uint32_t total = plan.W * plan.B;
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
@@ -333,20 +343,48 @@ msm_fixup(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __res
   if (a == b) return;
   const uint32_t t_lo = a / plan.chunk, t_hi = (b - 1) / plan.chunk;
   if (t_lo == t_hi) return;                       // the whole bucket sat inside one chunk: already stored
+  if (t_hi - t_lo >= FIXUP_LONG) {
+    const uint32_t k = atomicAdd(long_count, 1u);
+    if (k < long_cap) {
+      long_list[k] = g;
+      return;
+    }                                             // list full (cannot happen: cap = number of buckets that can be this long)
+  }
   g1_proj28 acc = g1_identity28();
   for (uint32_t t = t_lo; t <= t_hi; t++) {
-    const uint32_t slot = a <= t * plan.chunk ? 0 : 1;
-    g1_proj28 q = load_proj28(&partial[2 * (size_t)t + slot]);
+    g1_proj28 q = load_proj28(&partial[2 * (size_t)t + partial_slot(a, t, plan.chunk)]);
     g1_add28(acc, acc, q);
   }
   store_proj28(&bucket_sum[g], acc);
 }
 
+extern __shared__ uint4 msm_lds_tree[];
+__device__ __forceinline__ g1_proj28 block_tree_sum28(g1_proj28 v, uint32_t live);
+
+// one workgroup per queued bucket
+__global__ void __launch_bounds__(256, 2)
+msm_fixup_long(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
+               const proj28_slot* __restrict__ partial, const uint32_t* __restrict__ long_count,
+               const uint32_t* __restrict__ long_list, uint32_t long_cap) {
+  const uint32_t n_long = *long_count < long_cap ? *long_count : long_cap;
+  for (uint32_t k = blockIdx.x; k < n_long; k += gridDim.x) {
+    const uint32_t g = long_list[k];
+    const uint32_t a = offsets[g], b = offsets[g + 1];
+    const uint32_t t_lo = a / plan.chunk, t_hi = (b - 1) / plan.chunk;
+    g1_proj28 acc = g1_identity28();
+    for (uint32_t t = t_lo + threadIdx.x; t <= t_hi; t += blockDim.x) {
+      g1_proj28 q = load_proj28(&partial[2 * (size_t)t + partial_slot(a, t, plan.chunk)]);
+      g1_add28(acc, acc, q);
+    }
+    g1_proj28 tot = block_tree_sum28(acc, blockDim.x);
+    if (threadIdx.x == 0) store_proj28(&bucket_sum[g], tot);
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- 7. reduce: T_w = sum_b (b+1) * S_{w,b}
 // grid (blocks_per_window, W), 256 lanes; lane handles `seg` consecutive buckets.
 // out[w * gridDim.x + blockIdx.x] = this block's share.
-extern __shared__ uint4 msm_lds_tree[];
-
 __device__ __forceinline__ g1_proj28 block_tree_sum28(g1_proj28 v, uint32_t live) {
   proj28_slot* tree = reinterpret_cast<proj28_slot*>(msm_lds_tree);
   store_proj28(&tree[threadIdx.x], v);
