@@ -202,6 +202,7 @@ void bp_destroy(bp_ctx* ctx) {
     (void)hipFree(kv.second.hi);
     if (kv.second.hi_scaled) (void)hipFree(kv.second.hi_scaled);
     if (kv.second.n_inv) (void)hipFree(kv.second.n_inv);
+    if (kv.second.n_inv_tw) (void)hipFree(kv.second.n_inv_tw);
   }
   for (auto& t : ctx->small_tw)
     if (t) (void)hipFree(t);

@@ -24,11 +24,13 @@ struct SrsEntry {
   size_t n = 0;
 };
 
-struct NttTables {       // per (log_n, inverse)
-  fr_t* lo = nullptr;    // w_N^j, j < 2^h
-  fr_t* hi = nullptr;    // w_N^(j << h), j < 2^(k-h)
-  fr_t* hi_scaled = nullptr;   // hi * N^-1 (inverse transforms, first pass)
-  fr_t* n_inv = nullptr;       // device copy of N^-1
+struct tw29_t;
+struct NttTables {       // per (log_n, inverse); entries are 48-byte 29-bit-limb twiddle records (fr29.cuh)
+  tw29_t* lo = nullptr;        // w_N^j, j < 2^h
+  tw29_t* hi = nullptr;        // w_N^(j << h), j < 2^(k-h)
+  tw29_t* hi_scaled = nullptr; // hi * N^-1 (inverse transforms, first pass)
+  tw29_t* n_inv_tw = nullptr;  // N^-1 as a twiddle record (single-pass inverses)
+  fr_t* n_inv = nullptr;       // N^-1, Montgomery (table builder input)
   uint32_t h = 0;
 };
 
@@ -42,7 +44,7 @@ struct bp_ctx {
   std::map<std::string, bp::DevBuf> ws;            // grow-only named device workspaces
   std::map<uint64_t, bp::SrsEntry> srs;
   uint64_t next_handle = 1;
-  bp::fr_t* small_tw[2] = {nullptr, nullptr};      // w_1024^j, j < 512: forward / inverse
+  bp::tw29_t* small_tw[2] = {nullptr, nullptr};    // w_1024^j, j < 512: forward / inverse
   std::map<uint32_t, bp::NttTables> ntt_tables;    // key = log_n * 2 + inverse
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   // stats of the last calls

@@ -119,20 +119,25 @@ BP_HD F28<MASK28, mul28_out_v(VA, VB)> mul28(const F28<A, VA>& a, const F28<B, V
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < N28; k++) {
+    // two independent accumulation chains per column (products | reduction terms) halve the dependent-mad depth
+    uint64_t red = 0;
 #pragma unroll
     for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P28::mod(k - i);
+    for (int i = 0; i < k; i++) red += (uint64_t)m[i] * P28::mod(k - i);
+    acc += red;
     m[k] = ((uint32_t)acc * P28::INV) & MASK28;
     acc += (uint64_t)m[k] * P28::mod(0);
     acc >>= 28;
   }
 #pragma unroll
   for (int k = N28; k < 2 * N28 - 1; k++) {
+    uint64_t red = 0;
 #pragma unroll
     for (int i = k - N28 + 1; i < N28; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-    for (int i = k - N28 + 1; i < N28; i++) acc += (uint64_t)m[i] * P28::mod(k - i);
+    for (int i = k - N28 + 1; i < N28; i++) red += (uint64_t)m[i] * P28::mod(k - i);
+    acc += red;
     r.l[k - N28] = (uint32_t)acc & MASK28;
     acc >>= 28;
   }
@@ -155,24 +160,28 @@ BP_HD F28<MASK28, 1 + (VA * VB + VC * VD + 2047) / 2048> mul28_2(const F28<A, VA
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < N28; k++) {
+    uint64_t acc2 = 0, red = 0;       // three independent chains per column
 #pragma unroll
     for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-    for (int i = 0; i <= k; i++) acc += (uint64_t)c.l[i] * d.l[k - i];
+    for (int i = 0; i <= k; i++) acc2 += (uint64_t)c.l[i] * d.l[k - i];
 #pragma unroll
-    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P28::mod(k - i);
+    for (int i = 0; i < k; i++) red += (uint64_t)m[i] * P28::mod(k - i);
+    acc += acc2 + red;
     m[k] = ((uint32_t)acc * P28::INV) & MASK28;
     acc += (uint64_t)m[k] * P28::mod(0);
     acc >>= 28;
   }
 #pragma unroll
   for (int k = N28; k < 2 * N28 - 1; k++) {
+    uint64_t acc2 = 0, red = 0;
 #pragma unroll
     for (int i = k - N28 + 1; i < N28; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-    for (int i = k - N28 + 1; i < N28; i++) acc += (uint64_t)c.l[i] * d.l[k - i];
+    for (int i = k - N28 + 1; i < N28; i++) acc2 += (uint64_t)c.l[i] * d.l[k - i];
 #pragma unroll
-    for (int i = k - N28 + 1; i < N28; i++) acc += (uint64_t)m[i] * P28::mod(k - i);
+    for (int i = k - N28 + 1; i < N28; i++) red += (uint64_t)m[i] * P28::mod(k - i);
+    acc += acc2 + red;
     r.l[k - N28] = (uint32_t)acc & MASK28;
     acc >>= 28;
   }

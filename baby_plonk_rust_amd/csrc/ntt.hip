@@ -13,16 +13,18 @@ static fr_t host_root_pow2(bool inverse, uint32_t log_order) {
   return w;
 }
 
-static int make_table(bp_ctx* ctx, const fr_t& base, uint32_t count, uint32_t shift, const fr_t* d_scale, fr_t* d_out) {
-  hipLaunchKernelGGL(ntt_make_table, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, base, count, shift, d_scale, d_out);
+static int make_table(bp_ctx* ctx, const fr_t& base, uint32_t count, uint32_t shift, const fr_t* d_scale, fr_t* d_out_fr,
+                      tw29_t* d_out_tw) {
+  hipLaunchKernelGGL(ntt_make_table, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, base, count, shift, d_scale, d_out_fr,
+                     d_out_tw);
   BP_HIP(ctx, hipGetLastError());
   return BP_OK;
 }
 
 int ntt_init_tables(bp_ctx* ctx) {
   for (int inv = 0; inv < 2; inv++) {
-    BP_HIP(ctx, hipMalloc((void**)&ctx->small_tw[inv], 512 * sizeof(fr_t)));
-    BP_TRY(make_table(ctx, host_root_pow2(inv != 0, NTT_SMALL_MAX_LOG), 512, 0, nullptr, ctx->small_tw[inv]));
+    BP_HIP(ctx, hipMalloc((void**)&ctx->small_tw[inv], 512 * sizeof(tw29_t)));
+    BP_TRY(make_table(ctx, host_root_pow2(inv != 0, NTT_SMALL_MAX_LOG), 512, 0, nullptr, nullptr, ctx->small_tw[inv]));
   }
   static bool attr = false;
   if (!attr) {
@@ -31,6 +33,12 @@ int ntt_init_tables(bp_ctx* ctx) {
     attr = true;
   }
   return BP_OK;
+}
+
+// one butterfly per lane per stage: 2^(l-1) * 8 columns lanes, capped at 1024 (a 2^8 x 8 tile owns most of the CU's LDS)
+static unsigned pass_threads(uint32_t l) {
+  unsigned t = (1u << (l - 1)) << NTT_TILE_COLS_LOG;
+  return t > 1024 ? 1024 : (t < 64 ? 64 : t);
 }
 
 static void make_ntt_plan(NttPlan& plan, uint32_t k) {
@@ -57,10 +65,10 @@ static int get_tables(bp_ctx* ctx, uint32_t k, int inverse, NttTables** out) {
   t.h = (k + 1) / 2;
   const uint32_t nlo = 1u << t.h, nhi = 1u << (k - t.h);
   const fr_t w = host_root_pow2(inverse != 0, k);
-  BP_HIP(ctx, hipMalloc((void**)&t.lo, (size_t)nlo * sizeof(fr_t)));
-  BP_HIP(ctx, hipMalloc((void**)&t.hi, (size_t)nhi * sizeof(fr_t)));
-  BP_TRY(make_table(ctx, w, nlo, 0, nullptr, t.lo));
-  BP_TRY(make_table(ctx, w, nhi, t.h, nullptr, t.hi));
+  BP_HIP(ctx, hipMalloc((void**)&t.lo, (size_t)nlo * sizeof(tw29_t)));
+  BP_HIP(ctx, hipMalloc((void**)&t.hi, (size_t)nhi * sizeof(tw29_t)));
+  BP_TRY(make_table(ctx, w, nlo, 0, nullptr, nullptr, t.lo));
+  BP_TRY(make_table(ctx, w, nhi, t.h, nullptr, nullptr, t.hi));
   if (inverse) {
     // N^-1 = (2^k)^-1 in Montgomery form (utils.rs:126: Scalar::from(n).invert())
     fr_t two = Fr::one(), n_m = Fr::one(), n_inv;
@@ -70,8 +78,10 @@ static int get_tables(bp_ctx* ctx, uint32_t k, int inverse, NttTables** out) {
     BP_HIP(ctx, hipMalloc((void**)&t.n_inv, sizeof(fr_t)));
     BP_HIP(ctx, hipMemcpyAsync(t.n_inv, &n_inv, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
     BP_HIP(ctx, hipStreamSynchronize(ctx->stream));    // n_inv lives on this stack frame
-    BP_HIP(ctx, hipMalloc((void**)&t.hi_scaled, (size_t)nhi * sizeof(fr_t)));
-    BP_TRY(make_table(ctx, w, nhi, t.h, t.n_inv, t.hi_scaled));
+    BP_HIP(ctx, hipMalloc((void**)&t.hi_scaled, (size_t)nhi * sizeof(tw29_t)));
+    BP_TRY(make_table(ctx, w, nhi, t.h, t.n_inv, nullptr, t.hi_scaled));
+    BP_HIP(ctx, hipMalloc((void**)&t.n_inv_tw, sizeof(tw29_t)));
+    BP_TRY(make_table(ctx, w, 1, 0, t.n_inv, nullptr, t.n_inv_tw));       // w^0 * N^-1
   }
   ctx->ntt_tables[key] = t;
   *out = &ctx->ntt_tables[key];
@@ -89,12 +99,12 @@ int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, si
   NttTables* tab;
   BP_TRY(get_tables(ctx, k, inverse, &tab));
   hipStream_t st = ctx->stream;
-  const fr_t* small = ctx->small_tw[inverse ? 1 : 0];
+  const tw29_t* small = ctx->small_tw[inverse ? 1 : 0];
   BP_HIP(ctx, hipEventRecord(ctx->ev[0], st));
   if (plan.P == 1) {
-    const size_t lds = (N + (N >> 1)) * sizeof(fr_t) + 16;
+    const size_t lds = (N + N) * N29 * 4 + 16;
     hipLaunchKernelGGL(ntt_small, dim3((unsigned)batch), dim3(256), lds, st, d_data, stride, k, small,
-                       inverse ? tab->n_inv : (const fr_t*)nullptr);
+                       inverse ? tab->n_inv_tw : (const tw29_t*)nullptr);
   } else {
     // ping-pong: pass 1 data -> tmp, middle passes in tmp, last pass tmp -> data
     fr_t* tmp;
@@ -104,15 +114,15 @@ int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, si
     for (uint32_t i = 0; i + 1 < plan.P; i++) {
       const uint32_t l = plan.l[i];
       s -= l;
-      const size_t lds = ((size_t)(1u << l) * (C + 1) + (1u << l) / 2) * sizeof(fr_t) + 16;
-      const fr_t* hi = (inverse && i == 0) ? tab->hi_scaled : tab->hi;     // N^-1 rides on the first twiddle
-      hipLaunchKernelGGL(ntt_pass_strided, dim3((unsigned)(N >> (l + NTT_TILE_COLS_LOG)), (unsigned)batch), dim3(256), lds, st,
+      const size_t lds = ((size_t)(1u << l) * (C + 1) + (1u << l)) * N29 * 4 + 16;
+      const tw29_t* hi = (inverse && i == 0) ? tab->hi_scaled : tab->hi;   // N^-1 rides on the first twiddle
+      hipLaunchKernelGGL(ntt_pass_strided, dim3((unsigned)(N >> (l + NTT_TILE_COLS_LOG)), (unsigned)batch), dim3(pass_threads(l)), lds, st,
                          i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp, tmp, i == 0 ? stride : N, N, k, l, s, small, tab->lo, hi,
                          tab->h);
     }
     const uint32_t l = plan.l[plan.P - 1];
-    const size_t lds = ((size_t)(1u << l) * (C + 1) + (1u << l) / 2) * sizeof(fr_t) + 16;
-    hipLaunchKernelGGL(ntt_pass_last, dim3((unsigned)(N >> (l + NTT_TILE_COLS_LOG)), (unsigned)batch), dim3(256), lds, st,
+    const size_t lds = ((size_t)(1u << l) * (C + 1) + (1u << l)) * N29 * 4 + 16;
+    hipLaunchKernelGGL(ntt_pass_last, dim3((unsigned)(N >> (l + NTT_TILE_COLS_LOG)), (unsigned)batch), dim3(pass_threads(l)), lds, st,
                        (const fr_t*)tmp, d_data, N, stride, plan, small);
   }
   BP_HIP(ctx, hipGetLastError());
@@ -148,7 +158,7 @@ int fr_synthetic_run(bp_ctx* ctx, fr_t* d_out, size_t n, uint64_t seed) {
 // out[j] = w^j, j < n   (roots_of_unity, utils.rs:45-52)
 int roots_run(bp_ctx* ctx, const fr_t& w, size_t n, fr_t* d_out) {
   if (n == 0) return BP_OK;
-  return make_table(ctx, w, (uint32_t)n, 0, nullptr, d_out);
+  return make_table(ctx, w, (uint32_t)n, 0, nullptr, d_out, nullptr);
 }
 
 }  // namespace bp

@@ -11,11 +11,12 @@
 //                from a two-level precomputed table; written back in place of d_i.
 //   pass P     : length-2^(l_P) transforms over contiguous rows; the result goes to the digit-reversed
 //                position e_1 + 2^(l_1) e_2 + ..., i.e. natural order, written in coalesced runs.
-//   A tile is 2^l x C elements (C = 8 adjacent columns = 256-B global runs) staged in LDS with a
-//   one-element row pad (conflict-free 16-B LDS accesses for both the column-major and row-major fills).
+//   A tile is 2^l x C elements (C = 8 adjacent columns = 256-B global runs) staged in LDS limb-major
+//   (9 x 29-bit limbs per element, fr29.cuh: one v_mad_u64_u32 per partial product, lazy butterflies).
 //   HBM traffic: P reads + P writes of the vector (P = 1 up to 2^10, 2 up to 2^16, 3 up to 2^24).
 #pragma once
 #include "fr_io.cuh"
+#include "fr29.cuh"
 
 namespace bp {
 
@@ -32,10 +33,27 @@ struct NttPlan {
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? __brev(x) >> (32 - bits) : 0; }
 
-// out[j] = base^(j << shift_), j < count  (table builder; base is a Montgomery Fr).  If scale != null
-// every entry is additionally multiplied by *scale (used to fold N^-1 into the high table).
+// Twiddle tables live in HBM as 48-byte records: 9 x 29-bit limbs of w * 2^261 (fr29.cuh) + 3 pad words.
+struct tw29_t { uint4 q[3]; };
+__device__ __forceinline__ fr29 load_tw29(const tw29_t* __restrict__ p) {
+  uint4 a = p->q[0], b = p->q[1], c = p->q[2];
+  fr29 r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = c.x;
+  return r;
+}
+__device__ __forceinline__ void store_tw29(tw29_t* __restrict__ p, const fr29& v) {
+  p->q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  p->q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+  p->q[2] = make_uint4(v.l[8], 0, 0, 0);
+}
+
+// out[j] = base^(j << shift_), j < count  (table builder; base is a Montgomery Fr).  If scale != null every
+// entry is additionally multiplied by *scale (folds N^-1 into a table).  Output either as plain Montgomery
+// Fr (out_fr: roots_of_unity) or as a 29-bit twiddle record (out_tw).
 __global__ void __launch_bounds__(256) ntt_make_table(fr_t base, uint32_t count, uint32_t shift_, const fr_t* scale,
-                                                       fr_t* __restrict__ out) {
+                                                       fr_t* __restrict__ out_fr, tw29_t* __restrict__ out_tw) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= count) return;
   uint64_t e = (uint64_t)j << shift_;
@@ -46,15 +64,63 @@ __global__ void __launch_bounds__(256) ntt_make_table(fr_t base, uint32_t count,
     e >>= 1;
   }
   if (scale) Fr::mul(acc, acc, *scale);
-  store_fr(&out[j], acc);
+  if (out_fr) store_fr(&out_fr[j], acc);
+  if (out_tw) store_tw29(&out_tw[j], fr29_twiddle_from_mont(acc));
 }
 
-extern __shared__ uint4 ntt_lds_raw[];
+// LDS tiles hold fr29 elements limb-major (SoA) in 64-bit pairs: limbs (2j, 2j+1) of element e at
+// ((uint2*)lds)[j * stride + e] for j < 4, limb 8 at the dword array behind them.  Adjacent lanes touch adjacent
+// 8-byte words: every ds_read_b64 / ds_write_b64 is conflict-free, 5 LDS instructions per element.
+extern __shared__ uint32_t ntt_lds_raw[];
+__device__ __forceinline__ fr29 lds_ld29(const uint32_t* base, uint32_t stride, uint32_t e) {
+  fr29 r;
+  const uint2* p2 = reinterpret_cast<const uint2*>(base);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    uint2 v = p2[j * stride + e];
+    r.l[2 * j] = v.x;
+    r.l[2 * j + 1] = v.y;
+  }
+  r.l[8] = base[8 * stride + e];
+  return r;
+}
+__device__ __forceinline__ void lds_st29(uint32_t* base, uint32_t stride, uint32_t e, const fr29& v) {
+  uint2* p2 = reinterpret_cast<uint2*>(base);
+#pragma unroll
+  for (int j = 0; j < 4; j++) p2[j * stride + e] = make_uint2(v.l[2 * j], v.l[2 * j + 1]);
+  base[8 * stride + e] = v.l[8];
+}
+// (u, v) <- (u + v, u - v), both back to the < 2q / normalised-limb invariant (twiddle = 1, no multiplication)
+__device__ __forceinline__ void fr29_butterfly_notwiddle(fr29& u, fr29& v) {
+  fr29 s = fr29_add_lazy(u, v);
+  fr29 d, d2;
+  uint32_t borrow = fr29_sub_exact(d, u, [&](int i) { return v.l[i]; });         // u - v, exact
+  fr29 t;                                                                         // u - v + 2q for the negative case
+#pragma unroll
+  for (int i = 0; i < N29; i++) t.l[i] = d.l[i] + Q29::two_q(i);
+  d2 = fr29_carry(t);
+  d2.l[N29 - 1] &= MASK29;                                                        // drop the 2^261 wrap of the borrow
+#pragma unroll
+  for (int i = 0; i < N29; i++) v.l[i] = borrow ? d2.l[i] : d.l[i];
+  u = s;
+}
 
-// In-LDS radix-2 decimation-in-frequency transform of length L = 2^l on every column of a tile
-// [L][CP] (CP = padded column count, C live columns).  Result of output index e sits at row bitrev(e).
-// tw[j] = w_L^j for j < L/2 (LDS).
-__device__ __forceinline__ void lds_ntt_dif(fr_t* tile, const fr_t* tw, uint32_t l, uint32_t cl, uint32_t CP) {
+// In-LDS radix-2 decimation-in-frequency transform of length L = 2^l on every column of a tile [L][CP]
+// (CP = padded column count, C = 2^cl live columns).  Result of output index e sits at row bitrev(e).
+// tw (LDS, SoA with stride L): stage s reads its twiddles w_L^(j << s), j < half = L >> (s+1), from the contiguous
+// run starting at L - 2*half, so the lanes of a wave read adjacent words whatever the stage (a single table
+// indexed j << s puts every j of a late stage on one bank).
+__device__ __forceinline__ void lds_fill_stage_twiddles(uint32_t* tw, uint32_t l, const tw29_t* __restrict__ small_tw) {
+  const uint32_t L = 1u << l;
+  for (uint32_t x = threadIdx.x; x + 1 < L; x += blockDim.x) {
+    // x in [L - 2*half, L - half)  <=>  stage s with half = L >> (s+1); j = x - (L - 2*half)
+    const uint32_t rem = L - x;                           // in (half, 2*half]
+    const uint32_t hl = 31 - __clz(rem - 1);              // floor(log2(rem - 1)) : half = 2^hl when rem - 1 >= half
+    const uint32_t half = 1u << hl, s = l - hl - 1, j = x - (L - 2 * half);
+    lds_st29(tw, L, x, load_tw29(&small_tw[(j << s) << (NTT_SMALL_MAX_LOG - l)]));
+  }
+}
+__device__ __forceinline__ void lds_ntt_dif(uint32_t* tile, uint32_t tstride, const uint32_t* tw, uint32_t l, uint32_t cl, uint32_t CP) {
   const uint32_t L = 1u << l, C = 1u << cl, nbf = (L >> 1) << cl;
   for (uint32_t s = 0; s < l; s++) {
     const uint32_t hl = l - s - 1, half = 1u << hl;
@@ -62,75 +128,75 @@ __device__ __forceinline__ void lds_ntt_dif(fr_t* tile, const fr_t* tw, uint32_t
       const uint32_t c = b & (C - 1), jp = b >> cl;
       const uint32_t blk = jp >> hl, j = jp & (half - 1);
       const uint32_t i0 = (blk * 2 * half + j) * CP + c, i1 = i0 + half * CP;
-      fr_t u = tile[i0], v = tile[i1], t;
-      Fr::add(t, u, v);
-      tile[i0] = t;
-      Fr::sub(t, u, v);
-      if (j != 0) Fr::mul(t, t, tw[j << s]);
-      tile[i1] = t;
+      fr29 u = lds_ld29(tile, tstride, i0), v = lds_ld29(tile, tstride, i1);
+      if (half == 1) {                               // last stage: every twiddle is 1 (uniform branch)
+        fr29_butterfly_notwiddle(u, v);
+      } else {
+        fr29 w = lds_ld29(tw, L, L - 2 * half + j);
+        fr29_butterfly(u, v, w);
+      }
+      lds_st29(tile, tstride, i0, u);
+      lds_st29(tile, tstride, i1, v);
     }
     __syncthreads();
   }
 }
 
 // Single-pass transform: N = 2^k <= 2^10, one workgroup per transform (blockIdx.x = batch index).
-// small_tw[j] = w_1024^j (forward or inverse table), scale = N^-1 (Montgomery) or null.
+// small_tw[j] = w_1024^j (forward or inverse table), scale = N^-1 as a twiddle record, or null.
 __global__ void __launch_bounds__(256) ntt_small(fr_t* __restrict__ data, size_t stride, uint32_t k,
-                                                  const fr_t* __restrict__ small_tw, const fr_t* scale) {
-  fr_t* tile = reinterpret_cast<fr_t*>(ntt_lds_raw);
-  const uint32_t N = 1u << k;
-  fr_t* tw = tile + N;
+                                                  const tw29_t* __restrict__ small_tw, const tw29_t* scale) {
+  const uint32_t N = 1u << k, tstride = N;
+  uint32_t* tile = ntt_lds_raw;
+  uint32_t* tw = tile + N29 * tstride;
   fr_t* base = data + (size_t)blockIdx.x * stride;
-  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) tile[i] = load_fr(&base[i]);
-  for (uint32_t j = threadIdx.x; j < (N >> 1); j += blockDim.x) tw[j] = load_fr(&small_tw[j << (NTT_SMALL_MAX_LOG - k)]);
+  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) lds_st29(tile, tstride, i, fr29_from_sat(load_fr(&base[i])));
+  lds_fill_stage_twiddles(tw, k, small_tw);
   __syncthreads();
-  lds_ntt_dif(tile, tw, k, 0, 1);
-  fr_t sc;
-  if (scale) sc = *scale;
+  lds_ntt_dif(tile, tstride, tw, k, 0, 1);
+  fr29 sc;
+  if (scale) sc = load_tw29(scale);
   for (uint32_t e = threadIdx.x; e < N; e += blockDim.x) {
-    fr_t v = tile[bitrev(e, k)];
-    if (scale) Fr::mul(v, v, sc);
-    store_fr(&base[e], v);
+    fr29 v = lds_ld29(tile, tstride, bitrev(e, k));
+    if (scale) v = fr29_mul(v, sc);
+    store_fr(&base[e], fr29_to_sat_canonical(v));
   }
 }
 
-// w_N^E from the two-level table (lo[E & (2^h-1)], hi[E >> h])
-__device__ __forceinline__ fr_t twiddle_lookup(const fr_t* __restrict__ lo, const fr_t* __restrict__ hi, uint32_t h, uint64_t E) {
-  fr_t a = load_fr(&lo[E & ((1u << h) - 1u)]), b = load_fr(&hi[E >> h]), r;
-  Fr::mul(r, a, b);
-  return r;
+// w_N^E from the two-level table (lo[E & (2^h-1)], hi[E >> h]), 29-bit twiddle form
+__device__ __forceinline__ fr29 twiddle_lookup(const tw29_t* __restrict__ lo, const tw29_t* __restrict__ hi, uint32_t h, uint64_t E) {
+  return fr29_mul(load_tw29(&lo[E & ((1u << h) - 1u)]), load_tw29(&hi[E >> h]));
 }
 
 // Strided pass (every pass but the last).  grid.x = tiles, grid.y = batch.
 //   l      digit width, s = bits below the digit, mlog = l + s, k = log2 N
 //   element (hi, d, r): address hi * 2^mlog + d * 2^s + r; tile = all d x C consecutive r.
-__global__ void __launch_bounds__(256) ntt_pass_strided(const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride,
+__global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride,
                                                          uint32_t k, uint32_t l, uint32_t s,
-                                                         const fr_t* __restrict__ small_tw, const fr_t* __restrict__ tw_lo,
-                                                         const fr_t* __restrict__ tw_hi, uint32_t h) {
+                                                         const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo,
+                                                         const tw29_t* __restrict__ tw_hi, uint32_t h) {
   constexpr uint32_t C = 1u << NTT_TILE_COLS_LOG, CP = C + 1;
-  const uint32_t L = 1u << l, mlog = l + s;
-  fr_t* tile = reinterpret_cast<fr_t*>(ntt_lds_raw);
-  fr_t* tw = tile + L * CP;
+  const uint32_t L = 1u << l, mlog = l + s, tstride = L * CP;
+  uint32_t* tile = ntt_lds_raw;
+  uint32_t* tw = tile + N29 * tstride;
   const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
   const uint32_t tiles_per_hi = 1u << (s - NTT_TILE_COLS_LOG);
   const uint32_t hi = blockIdx.x / tiles_per_hi, r0 = (blockIdx.x % tiles_per_hi) << NTT_TILE_COLS_LOG;
   const size_t base = ((size_t)hi << mlog) + r0;
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t c = x % C, d = x / C;
-    tile[d * CP + c] = load_fr(&src[soff + base + ((size_t)d << s) + c]);
+    lds_st29(tile, tstride, d * CP + c, fr29_from_sat(load_fr(&src[soff + base + ((size_t)d << s) + c])));
   }
-  for (uint32_t j = threadIdx.x; j < (L >> 1); j += blockDim.x) tw[j] = load_fr(&small_tw[j << (NTT_SMALL_MAX_LOG - l)]);
+  lds_fill_stage_twiddles(tw, l, small_tw);
   __syncthreads();
-  lds_ntt_dif(tile, tw, l, NTT_TILE_COLS_LOG, CP);
+  lds_ntt_dif(tile, tstride, tw, l, NTT_TILE_COLS_LOG, CP);
   const uint32_t tshift = k - mlog;                 // w_M^x = w_N^(x << tshift)
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t c = x % C, e = x / C;
-    fr_t v = tile[bitrev(e, l) * CP + c];
+    fr29 v = lds_ld29(tile, tstride, bitrev(e, l) * CP + c);
     const uint64_t E = ((uint64_t)e * (r0 + c)) << tshift;
-    fr_t w = twiddle_lookup(tw_lo, tw_hi, h, E);     // tw_hi may carry the folded N^-1 (first pass of an inverse)
-    Fr::mul(v, v, w);
-    store_fr(&dst[doff + base + ((size_t)e << s) + c], v);
+    v = fr29_mul(v, twiddle_lookup(tw_lo, tw_hi, h, E));     // tw_hi may carry the folded N^-1 (first pass of an inverse)
+    store_fr(&dst[doff + base + ((size_t)e << s) + c], fr29_to_sat_canonical(v));
   }
 }
 
@@ -138,12 +204,12 @@ __global__ void __launch_bounds__(256) ntt_pass_strided(const fr_t* src, fr_t* d
 // Row (e_1, mid): src address (e_1 * 2^(s1 - l) + mid) * L + d, s1 = k - l_1.
 // Output index = e_1 + 2^(l_1) * rev_digits(mid) + 2^(k - l) * e_P, where mid = (e_2..e_{P-1}) is re-ordered
 // digit by digit (least significant output digit first).
-__global__ void __launch_bounds__(256) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
-                                                      size_t dst_stride, NttPlan plan, const fr_t* __restrict__ small_tw) {
+__global__ void __launch_bounds__(1024) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
+                                                      size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
   constexpr uint32_t C = 1u << NTT_TILE_COLS_LOG, CP = C + 1;
-  const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l;
-  fr_t* tile = reinterpret_cast<fr_t*>(ntt_lds_raw);
-  fr_t* tw = tile + L * CP;
+  const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l, tstride = L * CP;
+  uint32_t* tile = ntt_lds_raw;
+  uint32_t* tw = tile + N29 * tstride;
   const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
   const uint32_t midbits = k - l1 - l;              // bits of (e_2 .. e_{P-1})
   // blockIdx.x enumerates (e1_tile, mid): e_1 = e1_tile * C + c
@@ -151,11 +217,11 @@ __global__ void __launch_bounds__(256) ntt_pass_last(const fr_t* __restrict__ sr
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t d = x % L, c = x / L;
     const size_t row = ((size_t)(e1_0 + c) << midbits) + mid;
-    tile[d * CP + c] = load_fr(&src[soff + (row << l) + d]);
+    lds_st29(tile, tstride, d * CP + c, fr29_from_sat(load_fr(&src[soff + (row << l) + d])));
   }
-  for (uint32_t j = threadIdx.x; j < (L >> 1); j += blockDim.x) tw[j] = load_fr(&small_tw[j << (NTT_SMALL_MAX_LOG - l)]);
+  lds_fill_stage_twiddles(tw, l, small_tw);
   __syncthreads();
-  lds_ntt_dif(tile, tw, l, NTT_TILE_COLS_LOG, CP);
+  lds_ntt_dif(tile, tstride, tw, l, NTT_TILE_COLS_LOG, CP);
   // digit-reverse mid: mid = e_2 * 2^(l_3+..+l_{P-1}) + ... + e_{P-1}; output wants e_2 lowest.
   uint32_t mid_out = 0, shift_out = 0, rem = midbits;
   for (uint32_t i = 1; i + 1 < P; i++) {
@@ -167,8 +233,8 @@ __global__ void __launch_bounds__(256) ntt_pass_last(const fr_t* __restrict__ sr
   const size_t obase = ((size_t)mid_out << l1) + e1_0;
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t c = x % C, e = x / C;
-    fr_t v = tile[bitrev(e, l) * CP + c];
-    store_fr(&dst[doff + obase + ((size_t)e << (k - l)) + c], v);
+    fr29 v = lds_ld29(tile, tstride, bitrev(e, l) * CP + c);
+    store_fr(&dst[doff + obase + ((size_t)e << (k - l)) + c], fr29_to_sat_canonical(v));
   }
 }
 

@@ -39,6 +39,16 @@ GOLDEN = 0x9E3779B97F4A7C15
 A0, D0 = 0x1F2E3D4C5B6A79881122334455667788, 0x0102030405060708090A0B0C0D0E0F10
 
 
+def measured_traffic(key):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_hbm_traffic.json), or None when the
+    running configuration is not the profiled one"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            return json.load(f)[key]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(sample_log_n, threads_all):
     """reference-faithful CPU path (oracle restatement of src/msm.rs: c = 4, 64 windows, projective adds),
     single thread like the reference, on a bounded sample of the same synthetic workload"""
@@ -162,7 +172,8 @@ def main():
                        "msm_points_per_gpu": n, "window_bits": stats["window_bits"], "ntt_len_per_gpu": nn,
                        "parallelism": "point-range x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic("msm_accumulate_2p20_c16") if (args.log_n == 20 and stats["window_bits"] == 16) else None,
                          "kernel_ms": acc * 1e3, "algorithmic_bytes_per_launch": MSM_BYTES_PER_UNIT * n,
                          "note": "integer-ALU bound by design (11 Fp mul per bucket add); see DESIGN.md"},
             "msm_device_ms": float(np.mean(dev_ms)),

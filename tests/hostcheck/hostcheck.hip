@@ -68,3 +68,17 @@ void hc_g1_28_mul_small(uint32_t* r, const uint32_t* a_in, uint32_t k, int nbits
 int hc_g1_28_is_identity(const uint32_t* a_in) { g1_proj a; memcpy(&a, a_in, 144); return g1_is_identity28(to28(a)) ? 1 : 0; }
 void hc_g1_28_identity(uint32_t* r) { g1_proj out = g1_proj_from_28(g1_identity28()); memcpy(r, &out, 144); }
 }
+
+// ---- unsaturated 9 x 29 scalar field (fr29.cuh) ----
+#include "../../baby_plonk_rust_amd/csrc/fr29.cuh"
+extern "C" {
+// (u, v) in the reference's Montgomery form, w in Montgomery form; outputs canonical Montgomery: u+v, (u-v)*w after `reps` chained butterflies
+void hc_fr29_butterfly(uint32_t* ru, uint32_t* rv, const uint32_t* u_in, const uint32_t* v_in, const uint32_t* w_in, int reps) {
+  fr_t u, v, w; memcpy(&u, u_in, 32); memcpy(&v, v_in, 32); memcpy(&w, w_in, 32);
+  fr29 a = fr29_from_sat(u), b = fr29_from_sat(v), t = fr29_twiddle_from_mont(w);
+  for (int i = 0; i < reps; i++) fr29_butterfly(a, b, t);
+  fr_t x = fr29_to_sat_canonical(a), y = fr29_to_sat_canonical(b);
+  memcpy(ru, &x, 32); memcpy(rv, &y, 32);
+}
+void hc_fr29_roundtrip(uint32_t* r, const uint32_t* a_in) { fr_t a; memcpy(&a, a_in, 32); fr_t z = fr29_to_sat_canonical(fr29_from_sat(a)); memcpy(r, &z, 32); }
+}

@@ -171,3 +171,21 @@ def test_g1_28_add_double_mul_small(hc):
     isid.restype, isid.argtypes = C.c_int, [C.c_void_p]
     ident, gg = O.g1_identity(), g.copy()
     assert isid(ident.ctypes.data) == 1 and isid(gg.ctypes.data) == 0
+
+
+def test_fr29_lazy_butterflies(hc):
+    """fr29.cuh: 9 x 29-bit limbs, data kept in the reference's 2^256 Montgomery domain, twiddles in 2^261"""
+    rnd = random.Random(17)
+    fn = hc.hc_fr29_butterfly
+    fn.restype, fn.argtypes = None, [C.c_void_p] * 5 + [C.c_int]
+    vals = [0, 1, Q - 1, Q - 2, 2**254] + [rnd.randrange(Q) for _ in range(40)]
+    for i in range(len(vals) - 2):
+        u, v, w = (O.fr_from_int(x) for x in vals[i:i + 3])
+        assert (call(hc, "hc_fr29_roundtrip", 8, u) == u).all()
+        for reps in (1, 2, 7):
+            ru, rv = np.zeros(8, dtype=np.uint32), np.zeros(8, dtype=np.uint32)
+            fn(ru.ctypes.data, rv.ctypes.data, u.ctypes.data, v.ctypes.data, w.ctypes.data, reps)
+            eu, ev = u, v
+            for _ in range(reps):
+                eu, ev = O.fr_bin("fr_add", eu, ev), O.fr_bin("fr_mul", O.fr_bin("fr_sub", eu, ev), w)
+            assert (ru.view(np.uint64) == eu).all() and (rv.view(np.uint64) == ev).all()
