@@ -104,6 +104,8 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
   if (n >= (1ull << 31)) return fail(ctx, BP_ERR_TOO_LARGE, "MSM length >= 2^31", hipSuccess, __FILE__, __LINE__);
   MsmPlan plan;
   make_plan(plan, n);
+  if ((uint64_t)plan.W * n >= (1ull << 32))        // positions in the bucket-sorted list are 32-bit
+    return fail(ctx, BP_ERR_TOO_LARGE, "MSM length * windows >= 2^32", hipSuccess, __FILE__, __LINE__);
   const uint32_t W = plan.W, B = plan.B, total = W * B;
   const uint64_t max_entries = (uint64_t)W * n;
   const uint64_t n_chunks = (max_entries + plan.chunk - 1) / plan.chunk;
@@ -120,7 +122,7 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
   // a bucket is "long" when it spans >= FIXUP_LONG chunks, so at most n_chunks / FIXUP_LONG + 1 buckets can be long
   const uint32_t long_cap = (uint32_t)(n_chunks / FIXUP_LONG + 1);
   uint32_t *long_count, *long_list;
-  BP_TRY(ws_get(ctx, "msm.long_count", 4, (void**)&long_count));
+  BP_TRY(ws_get(ctx, "msm.long_count", 8, (void**)&long_count));     // [0] long-bucket counter, [1] scalar status
   BP_TRY(ws_get(ctx, "msm.long_list", (size_t)long_cap * 4, (void**)&long_list));
   uint32_t* tile_sums;
   BP_TRY(ws_get(ctx, "msm.tile_sums", 4096 * 4, (void**)&tile_sums));
@@ -130,7 +132,8 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
   BP_TRY(ws_get(ctx, "msm.block_out", (size_t)W * blocks_per_window * sizeof(proj28_slot), (void**)&block_out));
   BP_TRY(ws_get(ctx, "msm.window_sum", (size_t)W * sizeof(proj28_slot), (void**)&window_sum));
   proj28_slot* h_windows;
-  BP_TRY(pinned_get(ctx, (size_t)W * sizeof(proj28_slot), (void**)&h_windows));
+  BP_TRY(pinned_get(ctx, (size_t)W * sizeof(proj28_slot) + 16, (void**)&h_windows));
+  uint32_t* h_status = reinterpret_cast<uint32_t*>(h_windows + W);
 
   static bool lds_attr_set = false;
   if (!lds_attr_set) {            // a full-window histogram at c = 16 needs 128 KiB of dynamic LDS
@@ -141,8 +144,8 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
   hipStream_t st = ctx->stream;
   BP_HIP(ctx, hipEventRecord(ctx->ev[0], st));
   BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4, st));
-  BP_HIP(ctx, hipMemsetAsync(long_count, 0, 4, st));
-  hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits);
+  BP_HIP(ctx, hipMemsetAsync(long_count, 0, 8, st));
+  hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits, long_count + 1);
   const size_t hist_bytes = (size_t)B * 4;
   const unsigned hist_threads = B >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
   hipLaunchKernelGGL(msm_count, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, digits, plan, counts);
@@ -168,8 +171,10 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
   hipLaunchKernelGGL(msm_window_finish, dim3(W), dim3(256), 256 * sizeof(proj28_slot), st, block_out, blocks_per_window, window_sum);
   BP_HIP(ctx, hipGetLastError());
   BP_HIP(ctx, hipMemcpyAsync(h_windows, window_sum, (size_t)W * sizeof(proj28_slot), hipMemcpyDeviceToHost, st));
+  BP_HIP(ctx, hipMemcpyAsync(h_status, long_count + 1, 4, hipMemcpyDeviceToHost, st));
   BP_HIP(ctx, hipEventRecord(ctx->ev[3], st));
   BP_HIP(ctx, hipStreamSynchronize(st));
+  if (*h_status) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q in a canonical-bytes input", hipSuccess, __FILE__, __LINE__);
   BP_HIP(ctx, hipEventElapsedTime(&ctx->msm_accumulate_ms, ctx->ev[1], ctx->ev[2]));
   BP_HIP(ctx, hipEventElapsedTime(&ctx->msm_total_ms, ctx->ev[0], ctx->ev[3]));
   ctx->msm_c = plan.c;

@@ -48,11 +48,16 @@ struct MsmPlan {
 // ---------------------------------------------------------------- 1. digits
 // fmt 0: 32-byte little-endian canonical (Scalar::to_bytes), 1: Montgomery limbs (Scalar::to_array)
 __global__ void __launch_bounds__(256) msm_digits(const fr_t* __restrict__ scalars, int fmt, MsmPlan plan,
-                                                   int16_t* __restrict__ digits) {
+                                                   int16_t* __restrict__ digits, uint32_t* __restrict__ status) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= plan.n) return;
   fr_t k = scalars[i];
-  if (fmt == 1) Fr::from_mont(k, k);               // msm.rs:126: scalar.to_bytes() = canonical integer
+  if (fmt == 1) {
+    Fr::from_mont(k, k);                           // msm.rs:126: scalar.to_bytes() = canonical integer
+  } else {
+    fr_t t;                                        // Scalar::from_bytes rejects values >= q (scalar.rs:264-288)
+    if (!big_sub(t, k, Fr::modulus())) atomicOr(status, 1u);
+  }
   uint32_t kp[10];
   uint64_t carry = 0;
 #pragma unroll

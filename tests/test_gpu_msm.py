@@ -109,6 +109,14 @@ def test_bad_inputs(ctx):
     assert e.value.code == -3
     with pytest.raises(bp.BpError):
         ctx.msm(12345678, frs([1]))                                      # unknown handle
+    h = ctx.srs_generate_progression(4, 3, 5)
+    bad = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in (1, Q, 2, Q + 5)), dtype=np.uint8).reshape(-1, 32)
+    with pytest.raises(bp.BpError) as e:
+        ctx.msm(h, bad, fmt=bp.FR_BYTES_LE)                              # Scalar::from_bytes rejects >= q
+    assert e.value.code == -4
+    ok = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in (1, Q - 1, 2, 5)), dtype=np.uint8).reshape(-1, 32)
+    assert ctx.msm(h, ok, fmt=bp.FR_BYTES_LE) == closed_form([1, Q - 1, 2, 5], 3, 5)
+    ctx.srs_free(h)
 
 
 @pytest.mark.parametrize("logn", [10, 14, 16])
