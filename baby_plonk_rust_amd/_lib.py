@@ -17,7 +17,7 @@ BP_OK = 0
 ERRORS = {
     -1: "BP_ERR_INVALID_ARG", -2: "BP_ERR_NOT_POW2", -3: "BP_ERR_BAD_POINT", -4: "BP_ERR_BAD_SCALAR",
     -5: "BP_ERR_BASIS", -6: "BP_ERR_LENGTH", -7: "BP_ERR_DIV_ZERO", -8: "BP_ERR_NO_DEVICE", -9: "BP_ERR_HIP",
-    -10: "BP_ERR_TOO_LARGE",
+    -10: "BP_ERR_TOO_LARGE", -11: "BP_ERR_ASSERT",
 }
 FR_BYTES_LE, FR_MONT = 0, 1
 BASIS_LAGRANGE, BASIS_MONOMIAL = 0, 1
@@ -58,6 +58,7 @@ SIGNATURES = {
     "bp_poly_scalar_op": (_int, [_vp, _vp, _sz, _int, _vp, _int, _int, _vp]),
     "bp_poly_mul": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _int, _vp, _pp(_sz)]),
     "bp_poly_div": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _int, _vp, _pp(_sz)]),
+    "bp_grand_product": (_int, [_vp] + [_vp] * 6 + [_sz] + [_vp] * 4 + [_int, _vp]),
     "bp_commit": (_int, [_vp, _u64, _vp, _sz, _int, _int, _vp]),
 }
 

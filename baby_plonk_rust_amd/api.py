@@ -327,6 +327,21 @@ class Polynomial:
         return np.roll(self.values, -(n % len(self)), axis=0)
 
 
+def round_2_z(a, b, c, s1, s2, s3, beta, gamma, k1=None, k2=None, ctx=None):
+    """prover.rs:279-319: Lagrange values z_0..z_{n-1} of the permutation grand product (raises where the reference panics)"""
+    ctx = ctx or default_context()
+    cols = [_fr_array(x) for x in (a, b, c, s1, s2, s3)]
+    n = len(cols[0])
+    assert all(len(x) == n for x in cols)
+    k1 = scalar_from_int(2) if k1 is None else np.ascontiguousarray(k1, dtype=np.uint64)
+    k2 = scalar_from_int(3) if k2 is None else np.ascontiguousarray(k2, dtype=np.uint64)
+    beta, gamma = np.ascontiguousarray(beta, dtype=np.uint64), np.ascontiguousarray(gamma, dtype=np.uint64)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    ctx.check(ctx._lib.bp_grand_product(ctx._h, *[x.ctypes.data for x in cols], n, beta.ctypes.data, gamma.ctypes.data, k1.ctypes.data,
+                                        k2.ctypes.data, FR_MONT, out.ctypes.data), "round_2 grand product")
+    return out
+
+
 class Setup:
     """src/setup.rs:7-10 (G1 part; x_2 in G2 belongs to the verifier's pairing, out of scope)"""
 

@@ -590,6 +590,28 @@ int bp_poly_div(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb,
   return BP_OK;
 }
 
+int bp_grand_product(bp_ctx* ctx, const void* a, const void* b, const void* c, const void* s1, const void* s2, const void* s3, size_t n,
+                     const void* beta32, const void* gamma32, const void* k1_32, const void* k2_32, int scalar_fmt, void* z_out) {
+  if (!ctx || !fmt_ok(scalar_fmt) || !beta32 || !gamma32 || !k1_32 || !k2_32 || (n && (!a || !b || !c || !s1 || !s2 || !s3 || !z_out)))
+    return BP_ERR_INVALID_ARG;
+  if (n == 0) return BP_OK;
+  if (n > ((size_t)1 << 25)) return fail(ctx, BP_ERR_TOO_LARGE, "grand product longer than 2^25", hipSuccess, __FILE__, __LINE__);
+  fr_t beta, gamma, k1, k2, root;
+  if (!fr_bytes_to_mont(beta, (const uint8_t*)beta32, scalar_fmt) || !fr_bytes_to_mont(gamma, (const uint8_t*)gamma32, scalar_fmt) ||
+      !fr_bytes_to_mont(k1, (const uint8_t*)k1_32, scalar_fmt) || !fr_bytes_to_mont(k2, (const uint8_t*)k2_32, scalar_fmt))
+    return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q", hipSuccess, __FILE__, __LINE__);
+  host_root_of_unity(root, n);                                   // roots_of_unity(group_order), utils.rs:45-52
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  fr_t* cols;
+  BP_TRY(ws_get(ctx, "io.gp_cols", 7 * n * sizeof(fr_t), (void**)&cols));
+  const void* src[6] = {a, b, c, s1, s2, s3};
+  for (int j = 0; j < 6; j++) BP_HIP(ctx, hipMemcpyAsync(cols + (size_t)j * n, src[j], n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
+  if (scalar_fmt == BP_FR_BYTES_LE) BP_TRY(fr_convert_run(ctx, cols, 6 * n, 0));
+  fr_t* z = cols + 6 * n;
+  BP_TRY(grand_product_run(ctx, cols, cols + n, cols + 2 * n, cols + 3 * n, cols + 4 * n, cols + 5 * n, n, beta, gamma, k1, k2, root, z));
+  return download_fr(ctx, z, z_out, n, scalar_fmt);
+}
+
 int bp_commit(bp_ctx* ctx, uint64_t srs_handle, const void* coeffs, size_t n, int basis, int scalar_fmt, uint8_t out96[96]) {
   if (!ctx || !basis_ok(basis)) return BP_ERR_INVALID_ARG;
   if (basis != BP_BASIS_MONOMIAL) return fail(ctx, BP_ERR_BASIS, "commit needs the Monomial basis (setup.rs:34)", hipSuccess, __FILE__, __LINE__);

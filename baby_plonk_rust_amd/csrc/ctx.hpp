@@ -88,6 +88,9 @@ int fr_scalar_run(bp_ctx* ctx, const fr_t* a, const fr_t& s, fr_t* out, size_t n
 int poly_eval_run(bp_ctx* ctx, const fr_t* d_coeffs, size_t n, const fr_t& x, fr_t* host_out);
 int poly_div_run(bp_ctx* ctx, fr_t* d_a, size_t na, const fr_t* d_b, size_t nb, const fr_t* host_b, fr_t* d_q, size_t nq);
 int fr_synthetic_run(bp_ctx* ctx, fr_t* d_out, size_t n, uint64_t seed);
+int fr_scan_mul_run(bp_ctx* ctx, const fr_t* d_in, size_t n, int reverse, int inclusive, fr_t* d_out, fr_t* d_total);
+int grand_product_run(bp_ctx* ctx, const fr_t* a, const fr_t* b, const fr_t* c, const fr_t* s1, const fr_t* s2, const fr_t* s3, size_t n,
+                      const fr_t& beta, const fr_t& gamma, const fr_t& k1, const fr_t& k2, const fr_t& root, fr_t* d_z);
 int roots_run(bp_ctx* ctx, const fr_t& w, size_t n, fr_t* d_out);
 int srs_decode_run(bp_ctx* ctx, const uint8_t* d_bytes, size_t n, g1_affine* d_out);
 int srs_encode_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, uint8_t* d_bytes);

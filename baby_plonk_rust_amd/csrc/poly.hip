@@ -62,4 +62,46 @@ int poly_div_run(bp_ctx* ctx, fr_t* d_a, size_t na, const fr_t* d_b, size_t nb, 
   return BP_OK;
 }
 
+// out = scan of `in` by products; *d_total (device, 1 element) receives the product of all n elements
+int fr_scan_mul_run(bp_ctx* ctx, const fr_t* d_in, size_t n, int reverse, int inclusive, fr_t* d_out, fr_t* d_total) {
+  const uint32_t n_tiles = (uint32_t)((n + SCANM_TILE - 1) / SCANM_TILE);
+  if (n_tiles > 256 * 64) return fail(ctx, BP_ERR_TOO_LARGE, "scan longer than 2^25", hipSuccess, __FILE__, __LINE__);
+  fr_t* tiles;
+  BP_TRY(ws_get(ctx, reverse ? "poly.scan_tiles_r" : "poly.scan_tiles_f", (size_t)(n_tiles ? n_tiles : 1) * sizeof(fr_t), (void**)&tiles));
+  const size_t lds = 256 * sizeof(fr_t);
+  if (n_tiles) hipLaunchKernelGGL(fr_scan_tile_products, dim3(n_tiles), dim3(256), lds, ctx->stream, d_in, n, reverse, tiles);
+  hipLaunchKernelGGL(fr_scan_tiles, dim3(1), dim3(256), lds, ctx->stream, tiles, n_tiles, d_total);
+  if (n_tiles) hipLaunchKernelGGL(fr_scan_apply, dim3(n_tiles), dim3(256), lds, ctx->stream, d_in, n, reverse, inclusive, tiles, d_out);
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
+
+// prover.rs:279-319 on device-resident Montgomery columns; d_z receives n values (z_0 .. z_{n-1})
+int grand_product_run(bp_ctx* ctx, const fr_t* a, const fr_t* b, const fr_t* c, const fr_t* s1, const fr_t* s2, const fr_t* s3, size_t n,
+                      const fr_t& beta, const fr_t& gamma, const fr_t& k1, const fr_t& k2, const fr_t& root, fr_t* d_z) {
+  if (n == 0) return BP_OK;
+  fr_t *roots, *num, *den, *pn, *sd, *totals;
+  BP_TRY(ws_get(ctx, "gp.roots", n * sizeof(fr_t), (void**)&roots));
+  BP_TRY(ws_get(ctx, "gp.num", n * sizeof(fr_t), (void**)&num));
+  BP_TRY(ws_get(ctx, "gp.den", n * sizeof(fr_t), (void**)&den));
+  BP_TRY(ws_get(ctx, "gp.pn", n * sizeof(fr_t), (void**)&pn));
+  BP_TRY(ws_get(ctx, "gp.sd", n * sizeof(fr_t), (void**)&sd));
+  BP_TRY(ws_get(ctx, "gp.totals", 2 * sizeof(fr_t), (void**)&totals));
+  BP_TRY(roots_run(ctx, root, n, roots));                                      // roots_of_unity(group_order), prover.rs:282
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(grand_product_terms, dim3(blocks), dim3(256), 0, ctx->stream, a, b, c, s1, s2, s3, roots, n, beta, gamma, k1, k2, num, den);
+  BP_TRY(fr_scan_mul_run(ctx, num, n, 0, 0, pn, totals));                      // exclusive prefix products of the numerators
+  BP_TRY(fr_scan_mul_run(ctx, den, n, 1, 1, sd, totals + 1));                  // inclusive suffix products of the denominators
+  fr_t h_tot[2];
+  BP_HIP(ctx, hipMemcpyAsync(h_tot, totals, 2 * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (big_is_zero(h_tot[1])) return fail(ctx, BP_ERR_DIV_ZERO, "round 2: a permutation denominator is zero (invert().unwrap())", hipSuccess, __FILE__, __LINE__);
+  if (!big_eq(h_tot[0], h_tot[1])) return fail(ctx, BP_ERR_ASSERT, "round 2: z_n != 1 (prover.rs:319)", hipSuccess, __FILE__, __LINE__);
+  fr_t td_inv;
+  fr_invert(td_inv, h_tot[1]);
+  hipLaunchKernelGGL(grand_product_combine, dim3(blocks), dim3(256), 0, ctx->stream, pn, sd, td_inv, n, d_z);
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
+
 }  // namespace bp

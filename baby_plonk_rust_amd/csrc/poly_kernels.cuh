@@ -126,6 +126,115 @@ __global__ void __launch_bounds__(256) poly_div_binomial_apply(size_t nq, size_t
   }
 }
 
+// ---- multiplicative scans (prefix / suffix products) and the round-2 grand product (prover.rs:279-319) -----------
+// Tile = 256 lanes x SCANM_PER_LANE elements.  reverse != 0 scans from the last element backwards (suffix products).
+constexpr uint32_t SCANM_PER_LANE = 8, SCANM_TILE = 256 * SCANM_PER_LANE;
+
+// exclusive product scan across the 256 lanes of a workgroup; returns the product of the lanes before this one
+__device__ __forceinline__ fr_t block_exclusive_scan_mul(const fr_t& v, fr_t& block_total) {
+  fr_t* buf = reinterpret_cast<fr_t*>(poly_lds_raw);
+  buf[threadIdx.x] = v;
+  __syncthreads();
+  for (uint32_t d = 1; d < blockDim.x; d <<= 1) {            // Hillis-Steele, inclusive
+    fr_t mine = buf[threadIdx.x], other = Fr::one();
+    const bool has = threadIdx.x >= d;
+    if (has) other = buf[threadIdx.x - d];
+    __syncthreads();
+    if (has) {
+      Fr::mul(mine, mine, other);
+      buf[threadIdx.x] = mine;
+    }
+    __syncthreads();
+  }
+  block_total = buf[blockDim.x - 1];
+  fr_t excl = threadIdx.x ? buf[threadIdx.x - 1] : Fr::one();
+  __syncthreads();
+  return excl;
+}
+__device__ __forceinline__ size_t scan_index(size_t pos, size_t n, int reverse) { return reverse ? n - 1 - pos : pos; }
+
+__global__ void __launch_bounds__(256) fr_scan_tile_products(const fr_t* __restrict__ in, size_t n, int reverse, fr_t* __restrict__ tile_prod) {
+  const size_t base = (size_t)blockIdx.x * SCANM_TILE + (size_t)threadIdx.x * SCANM_PER_LANE;
+  fr_t p = Fr::one();
+  for (uint32_t j = 0; j < SCANM_PER_LANE; j++)
+    if (base + j < n) {
+      fr_t v = load_fr(&in[scan_index(base + j, n, reverse)]);
+      Fr::mul(p, p, v);
+    }
+  fr_t tot;
+  (void)block_exclusive_scan_mul(p, tot);
+  if (threadIdx.x == 0) store_fr(&tile_prod[blockIdx.x], tot);
+}
+// in-place exclusive scan of the tile products by one workgroup (n_tiles <= 256 * 64); total -> *total_out
+__global__ void __launch_bounds__(256) fr_scan_tiles(fr_t* __restrict__ tile_prod, uint32_t n_tiles, fr_t* __restrict__ total_out) {
+  const uint32_t per = (n_tiles + 255) / 256, lo = threadIdx.x * per;
+  fr_t p = Fr::one();
+  for (uint32_t j = 0; j < per; j++)
+    if (lo + j < n_tiles) {
+      fr_t v = load_fr(&tile_prod[lo + j]);
+      Fr::mul(p, p, v);
+    }
+  fr_t tot, run = block_exclusive_scan_mul(p, tot);
+  for (uint32_t j = 0; j < per; j++)
+    if (lo + j < n_tiles) {
+      fr_t v = load_fr(&tile_prod[lo + j]);
+      store_fr(&tile_prod[lo + j], run);
+      Fr::mul(run, run, v);
+    }
+  if (threadIdx.x == 0) store_fr(total_out, tot);
+}
+// out[idx] = product of the elements before (exclusive) or up to (inclusive) idx in scan order
+__global__ void __launch_bounds__(256) fr_scan_apply(const fr_t* __restrict__ in, size_t n, int reverse, int inclusive,
+                                                      const fr_t* __restrict__ tile_prefix, fr_t* __restrict__ out) {
+  const size_t base = (size_t)blockIdx.x * SCANM_TILE + (size_t)threadIdx.x * SCANM_PER_LANE;
+  fr_t v[SCANM_PER_LANE], p = Fr::one();
+  for (uint32_t j = 0; j < SCANM_PER_LANE; j++) {
+    v[j] = base + j < n ? load_fr(&in[scan_index(base + j, n, reverse)]) : Fr::one();
+    Fr::mul(p, p, v[j]);
+  }
+  fr_t tot, run = block_exclusive_scan_mul(p, tot), tp = load_fr(&tile_prefix[blockIdx.x]);
+  Fr::mul(run, run, tp);
+  for (uint32_t j = 0; j < SCANM_PER_LANE; j++) {
+    if (base + j >= n) break;
+    fr_t incl;
+    Fr::mul(incl, run, v[j]);
+    store_fr(&out[scan_index(base + j, n, reverse)], inclusive ? incl : run);
+    run = incl;
+  }
+}
+// numerators and denominators of the permutation argument (prover.rs:286-317; Rlc = self + other*beta + gamma, utils.rs:161-169)
+__global__ void __launch_bounds__(256) grand_product_terms(const fr_t* __restrict__ a, const fr_t* __restrict__ b, const fr_t* __restrict__ c,
+                                                            const fr_t* __restrict__ s1, const fr_t* __restrict__ s2, const fr_t* __restrict__ s3,
+                                                            const fr_t* __restrict__ roots, size_t n, fr_t beta, fr_t gamma, fr_t k1, fr_t k2,
+                                                            fr_t* __restrict__ num, fr_t* __restrict__ den) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fr_t w = load_fr(&roots[i]), wb, t, u, nu, de;
+  fr_t ai = load_fr(&a[i]), bi = load_fr(&b[i]), ci = load_fr(&c[i]);
+  Fr::mul(wb, w, beta);                 // beta * w^i
+  Fr::add(t, ai, wb); Fr::add(nu, t, gamma);
+  Fr::mul(u, wb, k1); Fr::add(t, bi, u); Fr::add(t, t, gamma); Fr::mul(nu, nu, t);
+  Fr::mul(u, wb, k2); Fr::add(t, ci, u); Fr::add(t, t, gamma); Fr::mul(nu, nu, t);
+  fr_t si = load_fr(&s1[i]);
+  Fr::mul(u, si, beta); Fr::add(t, ai, u); Fr::add(de, t, gamma);
+  si = load_fr(&s2[i]);
+  Fr::mul(u, si, beta); Fr::add(t, bi, u); Fr::add(t, t, gamma); Fr::mul(de, de, t);
+  si = load_fr(&s3[i]);
+  Fr::mul(u, si, beta); Fr::add(t, ci, u); Fr::add(t, t, gamma); Fr::mul(de, de, t);
+  store_fr(&num[i], nu);
+  store_fr(&den[i], de);
+}
+// z_i = (prod_{j<i} num_j) * (prod_{j>=i} den_j) * (prod_all den)^-1
+__global__ void __launch_bounds__(256) grand_product_combine(const fr_t* __restrict__ pn, const fr_t* __restrict__ sd, fr_t td_inv, size_t n,
+                                                              fr_t* __restrict__ z) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fr_t x = load_fr(&pn[i]), y = load_fr(&sd[i]);
+  Fr::mul(x, x, y);
+  Fr::mul(x, x, td_inv);
+  store_fr(&z[i], x);
+}
+
 // General long division, one workgroup: rem (na values, modified in place) / b (nb values, lead != 0).
 // q has na - nb + 1 slots.  Sequential over quotient coefficients, parallel over the divisor.
 __global__ void __launch_bounds__(1024) poly_div_general(fr_t* __restrict__ rem, size_t na, const fr_t* __restrict__ b, size_t nb,

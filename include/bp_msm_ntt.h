@@ -44,7 +44,8 @@ enum {
   BP_ERR_DIV_ZERO = -7,      /* polynomial.rs:347-348   division by the zero polynomial (unwrap on None) */
   BP_ERR_NO_DEVICE = -8,     /* no usable GPU / HIP runtime error at init */
   BP_ERR_HIP = -9,           /* HIP runtime error; bp_last_error() has the text */
-  BP_ERR_TOO_LARGE = -10     /* size beyond the supported range (NTT > 2^28, MSM >= 2^31 points) */
+  BP_ERR_TOO_LARGE = -10,    /* size beyond the supported range (NTT > 2^28, MSM >= 2^31 points) */
+  BP_ERR_ASSERT = -11        /* a protocol assert_eq! of the reference failed (prover.rs:319  z_n == 1) */
 };
 enum { BP_FR_BYTES_LE = 0, BP_FR_MONT = 1 };
 enum { BP_BASIS_LAGRANGE = 0, BP_BASIS_MONOMIAL = 1 };   /* polynomial.rs:8-11 */
@@ -131,6 +132,15 @@ int  bp_poly_mul(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb
  * (zero quotient coefficients are squeezed out).  out needs na slots. */
 int  bp_poly_div(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb, int basis, int scalar_fmt,
                  void* out, size_t* n_out);
+/* Round-2 permutation grand product (prover.rs:279-319), "next" row f2 of SURVEY.md section 8.  Six Lagrange-basis
+ * columns of n values (witness a, b, c and sigma s1, s2, s3), challenges beta, gamma and coset shifts k1, k2
+ * (prover.rs:99-100: 2 and 3) as 32-byte scalars in scalar_fmt.  z_out receives z_0 .. z_{n-1} (z_0 = 1).
+ * BP_ERR_DIV_ZERO where a denominator is zero (invert().unwrap()), BP_ERR_ASSERT where z_n != 1 (:319).
+ * One batched inversion for all 3n denominators: z_i = prefix(num)_i * suffix(den)_i / prod(den). */
+int  bp_grand_product(bp_ctx* ctx, const void* a, const void* b, const void* c, const void* s1, const void* s2, const void* s3,
+                      size_t n, const void* beta32, const void* gamma32, const void* k1_32, const void* k2_32, int scalar_fmt,
+                      void* z_out);
+
 /* Setup::commit (setup.rs:32-37): asserts Monomial basis, MSM of the coefficients against the SRS. */
 int  bp_commit(bp_ctx* ctx, uint64_t srs_handle, const void* coeffs, size_t n, int basis, int scalar_fmt,
                uint8_t out96[96]);

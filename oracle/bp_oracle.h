@@ -129,6 +129,9 @@ size_t poly_mul_fast(fr_t *out, const fr_t *a, size_t na, const fr_t *b, size_t 
 /* Division as written in the reference (quotient only, incl. its zero-coefficient quirk).
  * returns quotient length, or (size_t)-1 where the reference panics. out needs na slots. */
 size_t poly_div(fr_t *out, const fr_t *a, size_t na, const fr_t *b, size_t nb);
+/* src/prover.rs:279-319 round-2 grand product (Lagrange values of z, n entries) */
+int prover_round2_z(fr_t *z_out, const fr_t *a, const fr_t *b, const fr_t *c, const fr_t *s1, const fr_t *s2,
+                    const fr_t *s3, size_t n, const fr_t *beta, const fr_t *gamma, const fr_t *k1, const fr_t *k2);
 
 /* ---- helpers for tests / bench (not in the reference) ---- */
 void oracle_splitmix_scalars(fr_t *out, size_t n, uint64_t seed);     /* from_bytes_wide of a counter PRNG */

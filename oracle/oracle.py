@@ -63,6 +63,7 @@ def _load():
         "poly_add": (sz, [vp, vp, sz, vp, sz, i32]), "poly_sub": (sz, [vp, vp, sz, vp, sz, i32]),
         "poly_mul": (sz, [vp, vp, sz, vp, sz]), "poly_mul_fast": (sz, [vp, vp, sz, vp, sz]),
         "poly_div": (sz, [vp, vp, sz, vp, sz]),
+        "prover_round2_z": (i32, [vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]),
         "oracle_splitmix_scalars": (None, [vp, sz, u64]),
         "oracle_points_progression": (None, [vp, sz, vp, vp]),
         "oracle_points_to_bytes96": (None, [vp, vp, sz]), "oracle_proj_from_bytes96": (None, [vp, vp, sz]),
@@ -404,3 +405,17 @@ def dot_progression(scalars, a_int, d_int):
     out, a, d = u64(4), fr_from_int(a_int), fr_from_int(d_int)
     lib.oracle_dot_progression(_p(out), _p(scalars), len(scalars), _p(a), _p(d))
     return fr_to_int(out)
+
+
+def round2_z(a, b, c, s1, s2, s3, beta, gamma, k1=None, k2=None):
+    """src/prover.rs:279-319; all arrays [n,4] Montgomery; returns z values [n,4] or raises where the reference panics"""
+    cols = [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in (a, b, c, s1, s2, s3)]
+    n = len(cols[0])
+    out = u64((n, 4))
+    k1 = fr_from_int(2) if k1 is None else arr(k1)
+    k2 = fr_from_int(3) if k2 is None else arr(k2)
+    beta, gamma = arr(beta), arr(gamma)
+    rc = lib.prover_round2_z(_p(out), *[_p(x) for x in cols], n, _p(beta), _p(gamma), _p(k1), _p(k2))
+    if rc != 0:
+        raise AssertionError("round_2: " + ("zero denominator" if rc == -1 else "z_n != 1"))
+    return out

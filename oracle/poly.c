@@ -132,3 +132,43 @@ size_t poly_div(fr_t *out, const fr_t *a, size_t na, const fr_t *b, size_t nb) {
     free(r); free(q);
     return ql;
 }
+
+/* src/utils.rs:161-169 -- Rlc for Scalar: self + other * beta + gamma */
+static void rlc(fr_t *r, const fr_t *self, const fr_t *other, const fr_t *beta, const fr_t *gamma) {
+    fr_t t;
+    fr_mul(&t, other, beta);
+    fr_add(&t, self, &t);
+    fr_add(r, &t, gamma);
+}
+/* src/prover.rs:279-319 -- round 2's permutation grand product z(x) in the Lagrange basis, as written:
+ * z_0 = 1, z_{i+1} = z_i * prod(numerators) * prod(inverted denominators); asserts z_n == 1 and pops it.
+ * returns 0, -1 where a denominator is zero (invert().unwrap() panics), -2 where the final assert fails. */
+int prover_round2_z(fr_t *z_out, const fr_t *a, const fr_t *b, const fr_t *c, const fr_t *s1, const fr_t *s2,
+                    const fr_t *s3, size_t n, const fr_t *beta, const fr_t *gamma, const fr_t *k1, const fr_t *k2) {
+    fr_t *roots = malloc((n ? n : 1) * sizeof *roots);
+    fr_t cur, t, u, one;
+    ntt_roots_of_unity(roots, n);
+    fr_from_u64(&one, 1);
+    cur = one;
+    int rc = 0;
+    for (size_t i = 0; i < n && rc == 0; i++) {
+        z_out[i] = cur;
+        rlc(&t, &a[i], &roots[i], beta, gamma);
+        fr_mul(&cur, &cur, &t);
+        fr_mul(&u, &roots[i], k1);
+        rlc(&t, &b[i], &u, beta, gamma);
+        fr_mul(&cur, &cur, &t);
+        fr_mul(&u, &roots[i], k2);
+        rlc(&t, &c[i], &u, beta, gamma);
+        fr_mul(&cur, &cur, &t);
+        const fr_t *w[3] = {&a[i], &b[i], &c[i]}, *s[3] = {&s1[i], &s2[i], &s3[i]};
+        for (int j = 0; j < 3; j++) {
+            rlc(&t, w[j], s[j], beta, gamma);
+            if (!fr_invert(&t, &t)) { rc = -1; break; }
+            fr_mul(&cur, &cur, &t);
+        }
+    }
+    if (rc == 0 && !fr_eq(&cur, &one)) rc = -2;
+    free(roots);
+    return rc;
+}
