@@ -1,0 +1,132 @@
+"""-m gpu: the reference prover's five rounds (src/prover.rs:177-647), restated call by call in tests/prover_rounds.py,
+executed on the GPU library and on the CPU oracle for the toy circuit of tests/verify_proof_test.rs (group order 8,
+SRS = 14 powers of tau = 101, witness a=3 b=4 c=16 d=5 e=80) with fixed blinders and challenges.  Every intermediate
+polynomial, evaluation and commitment must agree byte for byte; the resulting proof must satisfy the verifier's final
+equation (src/verifier.rs:80-192), checked in G1 with the known tau."""
+import random
+
+import numpy as np
+import pytest
+
+import baby_plonk_rust_amd as bp
+from oracle import oracle as O
+from tests import bigint_model as M
+from tests import prover_rounds as PR
+
+pytestmark = pytest.mark.gpu
+Q = M.Q
+
+
+def toy_circuit(n=8):
+    """tests/verify_proof_test.rs:21-35 + SURVEY.md appendix A: rows (e,-,-) / (a,b,c) / (c,d,e), five empty rows"""
+    w = {"a": 3, "b": 4, "c": 16, "d": 5, "e": 80}
+    wires = [("e", None, None), ("a", "b", "c"), ("c", "d", "e")] + [(None, None, None)] * (n - 3)
+    sel = dict(ql=[1, 0, 0], qr=[0, -1, 0], qm=[0, -1, -1], qo=[0, 1, 1], qc=[0, 0, 0])
+    pk = {k: [x % Q for x in v] + [0] * (n - 3) for k, v in sel.items()}
+    cols = [[w.get(row[j], 0) if row[j] else 0 for row in wires] for j in range(3)]
+    om = M.omega(n)
+    label = lambda col, row: (col + 1) * pow(om, row, Q) % Q          # utils.rs:29-36
+    groups = {}
+    for row, ws in enumerate(wires):
+        for col, name in enumerate(ws):
+            groups.setdefault(name, []).append((col, row))              # program.rs:92-99: equal names share a cycle
+    sig = [[0] * n for _ in range(3)]
+    for cells in groups.values():
+        for j, (col, row) in enumerate(cells):
+            ncol, nrow = cells[(j + 1) % len(cells)]
+            sig[col][row] = label(ncol, nrow)
+    pk.update(s1=sig[0], s2=sig[1], s3=sig[2])
+    public = [(-80) % Q] + [0] * (n - 1)                                 # prover.rs:114-127
+    return cols, pk, public
+
+
+def decode(b96):
+    return None if b96[0] & 0x40 else (int.from_bytes(b96[:48], "big"), int.from_bytes(b96[48:], "big"))
+
+
+def g1_only_verify(n, tau, proof, ev, ch, vk, public_inputs):
+    """src/verifier.rs:80-192 with the pairing check e(A, [tau]_2) == e(B, [1]_2) replaced by tau * A == B"""
+    beta, gamma, alpha, zeta, nu, mu = (ch[k] for k in ("beta", "gamma", "alpha", "zeta", "nu", "mu"))
+    mul = lambda k, P: M.ec_mul(k % Q, P) if P is not None else None
+    add = M.ec_add
+    neg = lambda P: None if P is None else (P[0], (-P[1]) % M.P)
+    z_h_zeta = (pow(zeta, n, Q) - 1) % Q
+    omega = M.omega(n)
+    l1 = M.dft([1] + [0] * (n - 1), inverse=True)
+    l_1_zeta = sum(c * pow(zeta, i, Q) for i, c in enumerate(l1)) % Q
+    pi = M.dft([(-x) % Q for x in public_inputs] + [0] * (n - len(public_inputs)), inverse=True)
+    pi_eval = sum(c * pow(zeta, i, Q) for i, c in enumerate(pi)) % Q
+    a_bar, b_bar, c_bar, s1_bar, s2_bar, zw_bar = (ev[k] for k in ("a_bar", "b_bar", "c_bar", "s1_bar", "s2_bar", "z_omega_bar"))
+    rl = lambda s, o: (s + o * beta + gamma) % Q
+    r_0 = (pi_eval - l_1_zeta * alpha * alpha - alpha * rl(a_bar, s1_bar) * rl(b_bar, s2_bar) * (c_bar + gamma) * zw_bar) % Q
+    d1 = add(add(add(add(mul(a_bar * b_bar, vk["qm"]), mul(a_bar, vk["ql"])), mul(b_bar, vk["qr"])), mul(c_bar, vk["qo"])), vk["qc"])
+    d2 = mul(rl(a_bar, zeta) * rl(b_bar, PR.K1 * zeta) * rl(c_bar, PR.K2 * zeta) * alpha + l_1_zeta * alpha * alpha + mu, proof["z_1"])
+    d3 = mul(rl(a_bar, s1_bar) * rl(b_bar, s2_bar) * alpha * beta * zw_bar, vk["s3"])
+    d4 = mul(z_h_zeta, add(add(proof["t_lo_1"], mul(pow(zeta, n, Q), proof["t_mid_1"])), mul(pow(zeta, 2 * n, Q), proof["t_hi_1"])))
+    d = add(add(add(d1, d2), neg(d3)), neg(d4))
+    f = d
+    for k, P in enumerate((proof["a_1"], proof["b_1"], proof["c_1"], vk["s1"], vk["s2"]), start=1):
+        f = add(f, mul(pow(nu, k, Q), P))
+    e_scalar = (nu * a_bar + nu**2 * b_bar + nu**3 * c_bar + nu**4 * s1_bar + nu**5 * s2_bar + mu * zw_bar - r_0) % Q
+    e = M.ec_mul(e_scalar)
+    lhs = mul(tau, add(proof["w_zeta_1"], mul(mu, proof["w_zeta_omega_1"])))
+    rhs = add(add(add(mul(zeta, proof["w_zeta_1"]), mul(mu * zeta * omega, proof["w_zeta_omega_1"])), f), neg(e))
+    return lhs == rhs
+
+
+def run_rounds(B, n, cols, pk, public, blinders, ch, z_fn):
+    st = PR.ProverState(B, n, pk, blinders)
+    proof = {}
+    proof["a_1"], proof["b_1"], proof["c_1"] = PR.round_1(st, cols[0], cols[1], cols[2], public)
+    st.rand.update(beta=ch["beta"], gamma=ch["gamma"])
+    proof["z_1"] = PR.round_2(st, z_fn)
+    st.rand["alpha"] = ch["alpha"]
+    proof["t_lo_1"], proof["t_mid_1"], proof["t_hi_1"] = PR.round_3(st)
+    st.rand["zeta"] = ch["zeta"]
+    ev = PR.round_4(st)
+    st.rand["nu"] = ch["nu"]
+    proof["w_zeta_1"], proof["w_zeta_omega_1"] = PR.round_5(st)
+    return st, proof, ev
+
+
+def test_toy_circuit_rounds_gpu_vs_oracle_and_verify():
+    n, tau = 8, 101
+    cols, pk, public = toy_circuit(n)
+    rnd = random.Random(2024)
+    blinders = [rnd.randrange(1, Q) for _ in range(11)]
+    ch = {k: rnd.randrange(1, Q) for k in ("beta", "gamma", "alpha", "zeta", "nu", "mu")}
+
+    setup = bp.Setup.generate_srs(n + 6, tau)                           # verify_proof_test.rs:16
+    gpu = PR.GpuBackend(setup)
+    cpu = PR.OracleBackend(O.proj_from_bytes96(setup.powers_of_x()))
+
+    st_g, proof_g, ev_g = run_rounds(gpu, n, cols, pk, public, blinders, ch, lambda *a: bp.round_2_z(*a))
+    st_c, proof_c, ev_c = run_rounds(cpu, n, cols, pk, public, blinders, ch, lambda *a: O.round2_z(*a))
+
+    # every logged intermediate agrees bit for bit
+    for rk in ("round_1", "round_2", "round_3", "round_4", "round_5"):
+        for name, val in st_c.log[rk].items():
+            got = st_g.log[rk][name]
+            if isinstance(val, np.ndarray):
+                assert got.shape == val.shape and (got == val).all(), (rk, name)
+            else:
+                assert got == val, (rk, name)
+    assert proof_g == proof_c and ev_g == ev_c
+    # polynomial lengths of SURVEY.md appendix A
+    assert len(st_g.log["round_1"]["a_coeff"]) == n + 2 and len(st_g.log["round_2"]["z_coeff"]) == n + 3
+    assert len(st_g.log["round_3"]["t"]) == 3 * n + 6 and len(st_g.log["round_3"]["t_hi"]) == n + 6
+    assert len(st_g.log["round_5"]["w_zeta_omega"]) == n + 2
+
+    # 624-byte proof: 9 compressed points (verifier.rs:23-40 field order) then 6 little-endian scalars
+    order = ("a_1", "b_1", "c_1", "z_1", "t_lo_1", "t_mid_1", "t_hi_1", "w_zeta_1", "w_zeta_omega_1")
+    blob = b"".join(M.enc48(decode(proof_g[k])) for k in order) + b"".join(
+        ev_g[k].to_bytes(32, "little") for k in ("a_bar", "b_bar", "c_bar", "s1_bar", "s2_bar", "z_omega_bar"))
+    assert len(blob) == 624
+
+    # the verifier's final equation holds for this proof (G1-only form for known tau)
+    vk = {k: decode(gpu.commit(gpu.Polynomial(gpu.i_ntt_381(PR.SV(pk[k])), gpu.MONO))) for k in pk}    # verifier.rs:61-68
+    pts = {k: decode(v) for k, v in proof_g.items()}
+    assert g1_only_verify(n, tau, pts, ev_g, ch, vk, [80])
+    # and fails when an evaluation is tampered with
+    bad = dict(ev_g, a_bar=(ev_g["a_bar"] + 1) % Q)
+    assert not g1_only_verify(n, tau, pts, bad, ch, vk, [80])
