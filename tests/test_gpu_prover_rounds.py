@@ -130,3 +130,61 @@ def test_toy_circuit_rounds_gpu_vs_oracle_and_verify():
     # and fails when an evaluation is tampered with
     bad = dict(ev_g, a_bar=(ev_g["a_bar"] + 1) % Q)
     assert not g1_only_verify(n, tau, pts, bad, ch, vk, [80])
+
+
+def prove_with_blinding(B, n, cols, pk, public, blinders, z_fn):
+    """src/prover.rs:106-176 with the blinders as an argument (the reference draws them from thread_rng, :108-110) and the
+    Fiat-Shamir challenges from the Merlin transcript exactly as src/transcript.rs derives them"""
+    from tests.merlin_transcript import PlonkTranscript
+    comp = lambda b96: M.enc48(decode(b96))
+    tr = PlonkTranscript()
+    st = PR.ProverState(B, n, pk, blinders)
+    proof = {}
+    proof["a_1"], proof["b_1"], proof["c_1"] = PR.round_1(st, cols[0], cols[1], cols[2], public)
+    st.rand["beta"], st.rand["gamma"] = tr.round_1(comp(proof["a_1"]), comp(proof["b_1"]), comp(proof["c_1"]))
+    proof["z_1"] = PR.round_2(st, z_fn)
+    st.rand["alpha"] = tr.round_2(comp(proof["z_1"]))
+    proof["t_lo_1"], proof["t_mid_1"], proof["t_hi_1"] = PR.round_3(st)
+    st.rand["zeta"] = tr.round_3(comp(proof["t_lo_1"]), comp(proof["t_mid_1"]), comp(proof["t_hi_1"]))
+    ev = PR.round_4(st)
+    st.rand["nu"] = tr.round_4(ev["a_bar"], ev["b_bar"], ev["c_bar"], ev["s1_bar"], ev["s2_bar"], ev["z_omega_bar"])
+    proof["w_zeta_1"], proof["w_zeta_omega_1"] = PR.round_5(st)
+    order = ("a_1", "b_1", "c_1", "z_1", "t_lo_1", "t_mid_1", "t_hi_1", "w_zeta_1", "w_zeta_omega_1")
+    blob = b"".join(comp(proof[k]) for k in order) + b"".join(
+        ev[k].to_bytes(32, "little") for k in ("a_bar", "b_bar", "c_bar", "s1_bar", "s2_bar", "z_omega_bar"))
+    return proof, ev, blob
+
+
+def compute_challenges(proof, ev):
+    """src/verifier.rs:193-209"""
+    from tests.merlin_transcript import PlonkTranscript
+    comp = lambda b96: M.enc48(decode(b96))
+    tr = PlonkTranscript()
+    beta, gamma = tr.round_1(comp(proof["a_1"]), comp(proof["b_1"]), comp(proof["c_1"]))
+    alpha = tr.round_2(comp(proof["z_1"]))
+    zeta = tr.round_3(comp(proof["t_lo_1"]), comp(proof["t_mid_1"]), comp(proof["t_hi_1"]))
+    nu = tr.round_4(ev["a_bar"], ev["b_bar"], ev["c_bar"], ev["s1_bar"], ev["s2_bar"], ev["z_omega_bar"])
+    mu = tr.round_5(comp(proof["w_zeta_1"]), comp(proof["w_zeta_omega_1"]))
+    return dict(beta=beta, gamma=gamma, alpha=alpha, zeta=zeta, nu=nu, mu=mu)
+
+
+def test_toy_circuit_deterministic_proof_bytes_and_verify():
+    """prove -> 624 proof bytes on the GPU path == on the oracle path; the verifier (challenges recomputed from the proof)
+    accepts -- the reference's tests/verify_proof_test.rs, made reproducible"""
+    n, tau = 8, 101
+    cols, pk, public = toy_circuit(n)
+    blinders = [random.Random(99).randrange(1, Q) for _ in range(11)]
+    setup = bp.Setup.generate_srs(n + 6, tau)
+    gpu = PR.GpuBackend(setup)
+    cpu = PR.OracleBackend(O.proj_from_bytes96(setup.powers_of_x()))
+    proof_g, ev_g, blob_g = prove_with_blinding(gpu, n, cols, pk, public, blinders, lambda *a: bp.round_2_z(*a))
+    proof_c, ev_c, blob_c = prove_with_blinding(cpu, n, cols, pk, public, blinders, lambda *a: O.round2_z(*a))
+    assert blob_g == blob_c and len(blob_g) == 624
+    import hashlib, os
+    golden = open(os.path.join(os.path.dirname(__file__), "golden", "toy_proof_blinders_seed99.sha256")).read().strip()
+    assert hashlib.sha256(blob_g).hexdigest() == golden          # committed fixture (made by the oracle path on the CPU)
+    vk = {k: decode(gpu.commit(gpu.Polynomial(gpu.i_ntt_381(PR.SV(pk[k])), gpu.MONO))) for k in pk}
+    ch = compute_challenges(proof_g, ev_g)
+    assert g1_only_verify(n, tau, {k: decode(v) for k, v in proof_g.items()}, ev_g, ch, vk, [80])
+    # a different public input is rejected
+    assert not g1_only_verify(n, tau, {k: decode(v) for k, v in proof_g.items()}, ev_g, ch, vk, [81])
