@@ -60,6 +60,16 @@ SIGNATURES = {
     "bp_poly_div": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _int, _vp, _pp(_sz)]),
     "bp_grand_product": (_int, [_vp] + [_vp] * 6 + [_sz] + [_vp] * 4 + [_int, _vp]),
     "bp_commit": (_int, [_vp, _u64, _vp, _sz, _int, _int, _vp]),
+    "bp_poly_add_device": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _vp, _pp(_sz)]),
+    "bp_poly_sub_device": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _vp, _pp(_sz)]),
+    "bp_poly_scalar_op_device": (_int, [_vp, _vp, _sz, _int, _vp, _int, _vp]),
+    "bp_poly_mul_device": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _vp, _pp(_sz)]),
+    "bp_poly_div_device": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _vp, _pp(_sz)]),
+    "bp_poly_evaluate_device": (_int, [_vp, _vp, _sz, _int, _vp, _vp]),
+    "bp_poly_scale_powers_device": (_int, [_vp, _vp, _sz, _vp, _vp]),
+    "bp_roots_of_unity_device": (_int, [_vp, _u64, _vp]),
+    "bp_grand_product_device": (_int, [_vp] + [_vp] * 6 + [_sz] + [_vp] * 4 + [_vp]),
+    "bp_commit_device": (_int, [_vp, _u64, _vp, _sz, _int, _vp]),
 }
 
 _lib = None

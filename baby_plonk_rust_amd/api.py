@@ -327,6 +327,137 @@ class Polynomial:
         return np.roll(self.values, -(n % len(self)), axis=0)
 
 
+class DevicePolynomial:
+    """polynomial.rs:14-17 with the coefficient / value vector resident in HBM (torch CUDA tensor, int64 [n, 4] =
+    Montgomery limbs).  Same operators and rules as Polynomial; nothing but O(1) scalars crosses PCIe."""
+
+    def __init__(self, values, basis, ctx=None):
+        import torch
+        self.ctx = ctx or default_context()
+        assert basis in (BASIS_LAGRANGE, BASIS_MONOMIAL)
+        self.basis = basis
+        if isinstance(values, torch.Tensor):
+            self.t = values
+        else:
+            host = _fr_array(values) if len(values) else np.zeros((0, 4), dtype=np.uint64)
+            self.t = torch.from_numpy(host.view(np.int64).copy()).to(torch.device("cuda", self.ctx.device))
+            torch.cuda.current_stream().synchronize()
+
+    @staticmethod
+    def empty(n, basis, ctx):
+        import torch
+        return DevicePolynomial(torch.empty((max(n, 1), 4), dtype=torch.int64, device=torch.device("cuda", ctx.device))[:n], basis, ctx)
+
+    def __len__(self):
+        return self.t.shape[0]
+
+    @property
+    def values(self):
+        return self.t.cpu().numpy().view(np.uint64)
+
+    def _ptr(self):
+        return self.t.data_ptr() if len(self) else 0
+
+    def _binop(self, other, fn, name, out_len):
+        if self.basis != other.basis:
+            raise BpError(-5, name, "Basis must be the same")
+        out = DevicePolynomial.empty(out_len, self.basis, self.ctx)
+        n = C.c_size_t()
+        c = self.ctx
+        c.check(fn(c._h, self._ptr(), len(self), other._ptr(), len(other), self.basis, out._ptr(), C.byref(n)), name)
+        out.t = out.t[: n.value]
+        return out
+
+    def _scalar(self, s, op, name):
+        s = np.ascontiguousarray(s, dtype=np.uint64).reshape(4)
+        out = DevicePolynomial.empty(len(self), self.basis, self.ctx)
+        c = self.ctx
+        c.check(c._lib.bp_poly_scalar_op_device(c._h, self._ptr(), len(self), self.basis, s.ctypes.data, op, out._ptr()), name)
+        return out
+
+    def __add__(self, o):
+        if isinstance(o, DevicePolynomial):
+            return self._binop(o, self.ctx._lib.bp_poly_add_device, "Polynomial + Polynomial", max(len(self), len(o)))
+        return self._scalar(o, 0, "Polynomial + Scalar")
+
+    def __sub__(self, o):
+        if isinstance(o, DevicePolynomial):
+            return self._binop(o, self.ctx._lib.bp_poly_sub_device, "Polynomial - Polynomial", max(len(self), len(o)))
+        return self._scalar(o, 1, "Polynomial - Scalar")
+
+    def __mul__(self, o):
+        if isinstance(o, DevicePolynomial):
+            return self._binop(o, self.ctx._lib.bp_poly_mul_device, "Polynomial * Polynomial", len(self) + len(o))
+        return self._scalar(o, 2, "Polynomial * Scalar")
+
+    def __truediv__(self, o):
+        return self._binop(o, self.ctx._lib.bp_poly_div_device, "Polynomial / Polynomial", max(len(self), 1))
+
+    def coeffs_evaluate(self, x):
+        x = np.ascontiguousarray(x, dtype=np.uint64).reshape(4)
+        out = np.zeros(4, dtype=np.uint64)
+        c = self.ctx
+        c.check(c._lib.bp_poly_evaluate_device(c._h, self._ptr(), len(self), self.basis, x.ctypes.data, out.ctypes.data), "coeffs_evaluate")
+        return out
+
+    def _transform(self, inverse, need, to):
+        if self.basis != need:
+            raise BpError(-5, "Polynomial.ntt/i_ntt", "wrong basis")
+        n = len(self)
+        if n == 0 or n & (n - 1):
+            raise BpError(-2, "ntt_381", "length %d is not a power of two" % n)
+        out = DevicePolynomial(self.t.clone(), to, self.ctx)
+        import torch
+        torch.cuda.current_stream().synchronize()
+        self.ctx.ntt_device(out._ptr(), n.bit_length() - 1, inverse=inverse)
+        return out
+
+    def ntt(self):
+        return self._transform(False, BASIS_MONOMIAL, BASIS_LAGRANGE)
+
+    def i_ntt(self):
+        return self._transform(True, BASIS_LAGRANGE, BASIS_MONOMIAL)
+
+    def scale_powers(self, w):
+        """p(x) -> p(w x)  (prover.rs:661-674)"""
+        w = np.ascontiguousarray(w, dtype=np.uint64).reshape(4)
+        out = DevicePolynomial.empty(len(self), self.basis, self.ctx)
+        c = self.ctx
+        c.check(c._lib.bp_poly_scale_powers_device(c._h, self._ptr(), len(self), w.ctypes.data, out._ptr()), "scale_powers")
+        return out
+
+    def slice(self, lo, hi=None):
+        return DevicePolynomial(self.t[lo:hi].contiguous(), self.basis, self.ctx)
+
+
+def commit_device(setup, poly):
+    """Setup::commit (setup.rs:32-37) of an HBM-resident polynomial"""
+    c = setup.ctx
+    out = np.zeros(96, dtype=np.uint8)
+    c.check(c._lib.bp_commit_device(c._h, setup.handle, poly._ptr(), len(poly), poly.basis, out.ctypes.data), "Setup.commit")
+    return bytes(out)
+
+
+def round_2_z_device(a, b, c, s1, s2, s3, beta, gamma, k1=None, k2=None):
+    """prover.rs:279-319 on DevicePolynomial columns -> DevicePolynomial (Lagrange)"""
+    ctx = a.ctx
+    n = len(a)
+    k1 = scalar_from_int(2) if k1 is None else np.ascontiguousarray(k1, dtype=np.uint64)
+    k2 = scalar_from_int(3) if k2 is None else np.ascontiguousarray(k2, dtype=np.uint64)
+    beta, gamma = np.ascontiguousarray(beta, dtype=np.uint64), np.ascontiguousarray(gamma, dtype=np.uint64)
+    out = DevicePolynomial.empty(n, BASIS_LAGRANGE, ctx)
+    ctx.check(ctx._lib.bp_grand_product_device(ctx._h, a._ptr(), b._ptr(), c._ptr(), s1._ptr(), s2._ptr(), s3._ptr(), n, beta.ctypes.data,
+                                               gamma.ctypes.data, k1.ctypes.data, k2.ctypes.data, out._ptr()), "round_2 grand product")
+    return out
+
+
+def roots_of_unity_device(n, ctx=None):
+    ctx = ctx or default_context()
+    out = DevicePolynomial.empty(n, BASIS_LAGRANGE, ctx)
+    ctx.check(ctx._lib.bp_roots_of_unity_device(ctx._h, n, out._ptr()), "roots_of_unity")
+    return out
+
+
 def round_2_z(a, b, c, s1, s2, s3, beta, gamma, k1=None, k2=None, ctx=None):
     """prover.rs:279-319: Lagrange values z_0..z_{n-1} of the permutation grand product (raises where the reference panics)"""
     ctx = ctx or default_context()

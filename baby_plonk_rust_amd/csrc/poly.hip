@@ -30,15 +30,14 @@ int poly_eval_run(bp_ctx* ctx, const fr_t* d_coeffs, size_t n, const fr_t& x, fr
 
 // True polynomial quotient of a (na coeffs, a[na-1] != 0) by b (nb coeffs, b[nb-1] != 0), na >= nb.
 // d_a is clobbered by the general path.  host_b = host copy of b (to pick the fast path).
-int poly_div_run(bp_ctx* ctx, fr_t* d_a, size_t na, const fr_t* d_b, size_t nb, const fr_t* host_b, fr_t* d_q, size_t nq) {
-  bool binomial = nb >= 2;
-  for (size_t i = 1; i + 1 < nb && binomial; i++) binomial = big_is_zero(host_b[i]);
+int poly_div_run(bp_ctx* ctx, fr_t* d_a, size_t na, const fr_t* d_b, size_t nb, const fr_t& b0, const fr_t& b_lead, bool binomial,
+                 fr_t* d_q, size_t nq) {
   fr_t lead_inv;
-  fr_invert(lead_inv, host_b[nb - 1]);
+  fr_invert(lead_inv, b_lead);
   if (binomial) {
     const size_t m = nb - 1;
     fr_t f;
-    Fr::mul(f, host_b[0], lead_inv);
+    Fr::mul(f, b0, lead_inv);
     Fr::neg(f, f);                                   // f = -b0 / bm
     const size_t max_len = (nq + m - 1) / m;
     const uint32_t K = 32;
@@ -58,6 +57,26 @@ int poly_div_run(bp_ctx* ctx, fr_t* d_a, size_t na, const fr_t* d_b, size_t nb, 
   } else {
     hipLaunchKernelGGL(poly_div_general, dim3(1), dim3(1024), 0, ctx->stream, d_a, na, d_b, nb, lead_inv, d_q);
   }
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
+
+// effective length (trailing zeros trimmed) and the number of non-zero entries in [lo, hi)
+int fr_nonzero_stats_run(bp_ctx* ctx, const fr_t* d_a, size_t n, size_t lo, size_t hi, size_t* eff_len, size_t* nonzero_in_range) {
+  unsigned long long* d_out;
+  BP_TRY(ws_get(ctx, "poly.nzstats", 16, (void**)&d_out));
+  BP_HIP(ctx, hipMemsetAsync(d_out, 0, 16, ctx->stream));
+  if (n) hipLaunchKernelGGL(fr_nonzero_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_a, n, lo, hi, d_out);
+  unsigned long long h[2];
+  BP_HIP(ctx, hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, ctx->stream));
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *eff_len = (size_t)h[0];
+  if (nonzero_in_range) *nonzero_in_range = (size_t)h[1];
+  return BP_OK;
+}
+int fr_scale_powers_run(bp_ctx* ctx, const fr_t* d_a, size_t n, const fr_t& w, fr_t* d_out) {
+  if (n == 0) return BP_OK;
+  hipLaunchKernelGGL(fr_scale_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_a, n, w, d_out);
   BP_HIP(ctx, hipGetLastError());
   return BP_OK;
 }

@@ -235,6 +235,26 @@ __global__ void __launch_bounds__(256) grand_product_combine(const fr_t* __restr
   store_fr(&z[i], x);
 }
 
+// ---- helpers of the device-resident polynomial pipeline -------------------------------------------------------
+// out[0] = 1 + index of the last non-zero element (0 when all are zero); out[1] = number of non-zero elements in [lo, hi)
+__global__ void __launch_bounds__(256) fr_nonzero_stats(const fr_t* __restrict__ a, size_t n, size_t lo, size_t hi, unsigned long long* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fr_t v = load_fr(&a[i]);
+  if (!big_is_zero(v)) {
+    atomicMax(&out[0], (unsigned long long)(i + 1));
+    if (i >= lo && i < hi) atomicAdd(&out[1], 1ull);
+  }
+}
+// out[i] = a[i] * w^i   (p(x) -> p(w x); prover.rs:661-674 monomial_z_to_z_omega)
+__global__ void __launch_bounds__(256) fr_scale_powers(const fr_t* __restrict__ a, size_t n, fr_t w, fr_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fr_t v = load_fr(&a[i]), p = fr_pow_u64(w, i);
+  Fr::mul(v, v, p);
+  store_fr(&out[i], v);
+}
+
 // General long division, one workgroup: rem (na values, modified in place) / b (nb values, lead != 0).
 // q has na - nb + 1 slots.  Sequential over quotient coefficients, parallel over the divisor.
 __global__ void __launch_bounds__(1024) poly_div_general(fr_t* __restrict__ rem, size_t na, const fr_t* __restrict__ b, size_t nb,

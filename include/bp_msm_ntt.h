@@ -141,6 +141,23 @@ int  bp_grand_product(bp_ctx* ctx, const void* a, const void* b, const void* c, 
                       size_t n, const void* beta32, const void* gamma32, const void* k1_32, const void* k2_32, int scalar_fmt,
                       void* z_out);
 
+/* ---- the same operators on HBM-resident data (Montgomery limbs) -------------------
+ * d_* are device pointers (hipMalloc / torch CUDA tensors); scalars and results of O(1) size stay on the host.
+ * Semantics, length rules, quirks and error codes are those of the host-pointer entry points above. */
+int  bp_poly_add_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b, size_t nb, int basis, void* d_out, size_t* n_out);
+int  bp_poly_sub_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b, size_t nb, int basis, void* d_out, size_t* n_out);
+int  bp_poly_scalar_op_device(bp_ctx* ctx, const void* d_a, size_t n, int basis, const void* s32_mont, int op, void* d_out);
+int  bp_poly_mul_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b, size_t nb, int basis, void* d_out, size_t* n_out);
+int  bp_poly_div_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b, size_t nb, int basis, void* d_out, size_t* n_out);
+int  bp_poly_evaluate_device(bp_ctx* ctx, const void* d_coeffs, size_t n, int basis, const void* x32_mont, void* out32_mont);
+/* out[i] = a[i] * w^i, i.e. p(x) -> p(w x)  (prover.rs:661-674 monomial_z_to_z_omega) */
+int  bp_poly_scale_powers_device(bp_ctx* ctx, const void* d_a, size_t n, const void* w32_mont, void* d_out);
+int  bp_roots_of_unity_device(bp_ctx* ctx, uint64_t group_order, void* d_out);
+int  bp_grand_product_device(bp_ctx* ctx, const void* d_a, const void* d_b, const void* d_c, const void* d_s1, const void* d_s2,
+                             const void* d_s3, size_t n, const void* beta32, const void* gamma32, const void* k1_32,
+                             const void* k2_32, void* d_z);
+int  bp_commit_device(bp_ctx* ctx, uint64_t srs_handle, const void* d_coeffs, size_t n, int basis, uint8_t out96[96]);
+
 /* Setup::commit (setup.rs:32-37): asserts Monomial basis, MSM of the coefficients against the SRS. */
 int  bp_commit(bp_ctx* ctx, uint64_t srs_handle, const void* coeffs, size_t n, int basis, int scalar_fmt,
                uint8_t out96[96]);

@@ -101,7 +101,24 @@ class OracleBackend:
 
     def commit(self, poly):                                      # setup.rs:32-37
         assert poly.basis == 1
-        return O.g1_bytes96(O.bucket_msm(self.srs, poly.values, 256, 4))
+        return O.g1_bytes96(O.bucket_msm(self.srs, poly.values, 256, 4, threads=self.threads))
+
+    threads = 1
+
+    def i_ntt_poly(self, values_poly):
+        return self.Polynomial(O.ntt_fast(values_poly.values, inverse=True), 1)
+
+    def roots_poly_lagrange(self, n):
+        return self.Polynomial(self.roots_of_unity(n), 0)
+
+    def round2_z(self, a, b, c, s1, s2, s3, beta, gamma):
+        return self.Polynomial(O.round2_z(a.values, b.values, c.values, s1.values, s2.values, s3.values, beta, gamma), 0)
+
+    def scale_powers(self, z, omega):
+        return generic_scale_powers(self, z, omega)
+
+    def slice(self, p, lo, hi=None):
+        return self.Polynomial(p.values[lo:hi], p.basis)
 
 
 class GpuBackend:
@@ -122,16 +139,75 @@ class GpuBackend:
     def commit(self, poly):
         return self.setup.commit(poly)
 
+    def i_ntt_poly(self, values_poly):
+        return self.Polynomial(self.bp.i_ntt_381(values_poly.values), 1)
+
+    def roots_poly_lagrange(self, n):
+        return self.Polynomial(self.bp.roots_of_unity(n), 0)
+
+    def round2_z(self, a, b, c, s1, s2, s3, beta, gamma):
+        return self.Polynomial(self.bp.round_2_z(a.values, b.values, c.values, s1.values, s2.values, s3.values, beta, gamma), 0)
+
+    def scale_powers(self, z, omega):
+        return generic_scale_powers(self, z, omega)
+
+    def slice(self, p, lo, hi=None):
+        return self.Polynomial(p.values[lo:hi], p.basis)
+
+
+class GpuDeviceBackend:
+    """the HIP library with every polynomial resident in HBM (baby_plonk_rust_amd.DevicePolynomial): the quotient /
+    linearisation pipeline of SURVEY.md section 8f row 1 -- only O(1) scalars and the 96-byte commitments cross PCIe"""
+    MONO, LAG = 1, 0
+
+    def __init__(self, setup):
+        import baby_plonk_rust_amd as bp
+        self.bp, self.setup = bp, setup
+        self.Polynomial = lambda values, basis: bp.DevicePolynomial(values, basis, setup.ctx)
+
+    def commit(self, poly):
+        return self.bp.commit_device(self.setup, poly)
+
+    def i_ntt_poly(self, values_poly):
+        return values_poly.i_ntt()
+
+    def roots_poly_lagrange(self, n):
+        return self.bp.roots_of_unity_device(n, self.setup.ctx)
+
+    def round2_z(self, a, b, c, s1, s2, s3, beta, gamma):
+        return self.bp.round_2_z_device(a, b, c, s1, s2, s3, beta, gamma)
+
+    def scale_powers(self, z, omega):
+        return z.scale_powers(S(omega))
+
+    def slice(self, p, lo, hi=None):
+        return p.slice(lo, hi)
+
 
 # ------------------------------------------------------------------------------------------------------------------
+def generic_scale_powers(B, z, omega):
+    """prover.rs:661-674 monomial_z_to_z_omega: coefficient i times omega^i"""
+    vals, p = [], 1
+    for v in ints(z.values):
+        vals.append(v * p % Q)
+        p = p * omega % Q
+    return B.Polynomial(SV(vals), B.MONO)
+
+
 class ProverState:
     """prover.rs:50-62 minus the circuit front-end: the preprocessed columns are given as Lagrange value lists (ints)"""
 
-    def __init__(self, B, n, pk, blinders):
+    def __init__(self, B, n, pk, blinders, logging=True):
         self.B, self.n, self.b = B, n, blinders                 # blinders: 11 ints (prover.rs:110)
         P = B.Polynomial
-        self.pk = {k: P(SV(v), B.LAG) for k, v in pk.items()}   # ql qr qm qo qc s1 s2 s3 (program.rs:34-50)
-        self.rand, self.wp, self.evals, self.log = {}, {}, {}, {}
+        as_limbs = lambda v: v if isinstance(v, np.ndarray) else SV(v)
+        self.pk = {k: P(as_limbs(v), B.LAG) for k, v in pk.items()}   # ql qr qm qo qc s1 s2 s3 (program.rs:34-50)
+        self.rand, self.wp, self.evals, self.log, self.logging = {}, {}, {}, {}, logging
+
+    def record(self, rk, **kw):
+        """keep intermediates for byte-for-byte comparison (polynomials are downloaded; off for large-n timing runs)"""
+        if self.logging:
+            self.log[rk] = {k: (v.values if hasattr(v, "values") else v) for k, v in kw.items()}
 
     def z_h(self):                                               # x^n - 1 (prover.rs:229-235)
         return self.B.Polynomial(SV([-1] + [0] * (self.n - 1) + [1]), self.B.MONO)
@@ -145,64 +221,53 @@ def rlc(p, other, beta, gamma):
 def round_1(st, a_values, b_values, c_values, public_values):
     """prover.rs:177-277 (witness lookup replaced by the three value columns); public_values: prover.rs:114-127"""
     B, P = st.B, st.B.Polynomial
-    st.public_input_poly = P(SV(public_values), B.LAG)
+    as_limbs = lambda v: v if isinstance(v, np.ndarray) else SV(v)
+    st.public_input_poly = P(as_limbs(public_values), B.LAG)
     z_h = st.z_h()
     b1, b2, b3, b4, b5, b6 = st.b[0:6]
-    a, b, c = P(SV(a_values), B.LAG), P(SV(b_values), B.LAG), P(SV(c_values), B.LAG)
+    a, b, c = P(as_limbs(a_values), B.LAG), P(as_limbs(b_values), B.LAG), P(as_limbs(c_values), B.LAG)
     a_coeff = P(SV([b2, b1]), B.MONO) * z_h + a.i_ntt()
     b_coeff = P(SV([b4, b3]), B.MONO) * z_h + b.i_ntt()
     c_coeff = P(SV([b6, b5]), B.MONO) * z_h + c.i_ntt()
     st.wp.update(a=a, b=b, c=c, a_coeff=a_coeff, b_coeff=b_coeff, c_coeff=c_coeff, z_h_coeff=z_h)
     out = (B.commit(a_coeff), B.commit(b_coeff), B.commit(c_coeff))
-    st.log["round_1"] = dict(a_coeff=a_coeff.values, b_coeff=b_coeff.values, c_coeff=c_coeff.values, commits=out)
+    st.record("round_1", a_coeff=a_coeff, b_coeff=b_coeff, c_coeff=c_coeff, commits=out)
     return out
 
 
-def round_2(st, z_values_fn):
-    """prover.rs:279-368; z_values_fn(a, b, c, s1, s2, s3, beta, gamma) -> z Lagrange values [n, 4]"""
+def round_2(st, z_values_fn=None):
+    """prover.rs:279-368 (the grand product loop :286-319 is the backend's round2_z)"""
     B, P = st.B, st.B.Polynomial
     beta, gamma = st.rand["beta"], st.rand["gamma"]
-    zv = z_values_fn(st.wp["a"].values, st.wp["b"].values, st.wp["c"].values, st.pk["s1"].values, st.pk["s2"].values,
-                     st.pk["s3"].values, S(beta), S(gamma))
-    z = P(zv, B.LAG)
+    z = B.round2_z(st.wp["a"], st.wp["b"], st.wp["c"], st.pk["s1"], st.pk["s2"], st.pk["s3"], S(beta), S(gamma))
     b7, b8, b9 = st.b[6:9]
     z_coeff = P(SV([b9, b8, b7]), B.MONO) * st.wp["z_h_coeff"] + z.i_ntt()
     st.wp.update(z=z, z_coeff=z_coeff)
     z_1 = B.commit(z_coeff)
-    st.log["round_2"] = dict(z=zv, z_coeff=z_coeff.values, commit=z_1)
+    st.record("round_2", z=z, z_coeff=z_coeff, commit=z_1)
     return z_1
-
-
-def monomial_z_to_z_omega(B, z, omega):
-    """prover.rs:661-674: coefficient i times omega^i"""
-    vals, p = [], 1
-    for v in ints(z.values):
-        vals.append(v * p % Q)
-        p = p * omega % Q
-    return B.Polynomial(SV(vals), B.MONO)
 
 
 def round_3(st):
     """prover.rs:370-500"""
     B, P, n = st.B, st.B.Polynomial, st.n
-    coeff = {k: P(B.i_ntt_381(st.pk[k].values), B.MONO) for k in ("s1", "s2", "s3", "ql", "qr", "qm", "qo", "qc")}
+    coeff = {k: B.i_ntt_poly(st.pk[k]) for k in ("s1", "s2", "s3", "ql", "qr", "qm", "qo", "qc")}
     a, b, c, z = st.wp["a_coeff"], st.wp["b_coeff"], st.wp["c_coeff"], st.wp["z_coeff"]
     l1 = P(SV([1] + [0] * (n - 1)), B.LAG)
     z_h = st.z_h()
     gate = (a * coeff["ql"] + b * coeff["qr"] + a * b * coeff["qm"] + c * coeff["qo"]
             + st.public_input_poly.i_ntt() + coeff["qc"])
-    roots_poly = P(B.i_ntt_381(B.roots_of_unity(n)), B.MONO)
+    roots_poly = B.i_ntt_poly(B.roots_poly_lagrange(n))
     omega = root_of_unity(n)
-    z_omega = monomial_z_to_z_omega(B, z, omega)
+    z_omega = B.scale_powers(z, omega)                                     # prover.rs:661-674
     beta, gamma, alpha = st.rand["beta"], st.rand["gamma"], st.rand["alpha"]
     perm = ((rlc(a, roots_poly, beta, gamma) * rlc(b, roots_poly * S(K1), beta, gamma) * rlc(c, roots_poly * S(K2), beta, gamma)) * z
             - (rlc(a, coeff["s1"], beta, gamma) * rlc(b, coeff["s2"], beta, gamma) * rlc(c, coeff["s3"], beta, gamma)) * z_omega)
-    l1_coeff = P(B.i_ntt_381(l1.values), B.MONO)
+    l1_coeff = B.i_ntt_poly(l1)
     first_row = (z - S(1)) * l1_coeff
     all_constraints = gate + perm * S(alpha) + first_row * S(alpha * alpha % Q)
     t = all_constraints / z_h
-    tv = t.values
-    t_lo, t_mid, t_hi = P(tv[0:n], B.MONO), P(tv[n:2 * n], B.MONO), P(tv[2 * n:], B.MONO)      # prover.rs:649-659
+    t_lo, t_mid, t_hi = B.slice(t, 0, n), B.slice(t, n, 2 * n), B.slice(t, 2 * n)                # prover.rs:649-659
     b10, b11 = st.b[9], st.b[10]
     x_pow_n = P(SV([0] * n + [1]), B.MONO)
     t_lo = t_lo + x_pow_n * S(b10)
@@ -211,7 +276,7 @@ def round_3(st):
     st.pk_coeff = coeff
     st.wp.update(z_omega_coeff=z_omega, t_lo_coeff=t_lo, t_mid_coeff=t_mid, t_hi_coeff=t_hi)
     out = (B.commit(t_lo), B.commit(t_mid), B.commit(t_hi))
-    st.log["round_3"] = dict(t=tv, t_lo=t_lo.values, t_mid=t_mid.values, t_hi=t_hi.values, commits=out)
+    st.record("round_3", t=t, t_lo=t_lo, t_mid=t_mid, t_hi=t_hi, commits=out)
     return out
 
 
@@ -222,7 +287,7 @@ def round_4(st):
               c_bar=st.wp["c_coeff"].coeffs_evaluate(zeta), s1_bar=st.pk_coeff["s1"].coeffs_evaluate(zeta),
               s2_bar=st.pk_coeff["s2"].coeffs_evaluate(zeta), z_omega_bar=st.wp["z_omega_coeff"].coeffs_evaluate(zeta))
     st.evals = {k: O.fr_to_int(v) for k, v in ev.items()}
-    st.log["round_4"] = dict(st.evals)
+    st.record("round_4", **st.evals)
     return st.evals
 
 
@@ -240,7 +305,7 @@ def round_5(st):
     r2 = (z * S(a_bar + zeta * beta + gamma) * S(b_bar + zeta * beta * K1 + gamma) * S(c_bar + zeta * beta * K2 + gamma)
           - (pk["s3"].i_ntt() * S(beta) + S(c_bar) + S(gamma)) * S(a_bar + s1_bar * beta + gamma) * S(b_bar + s2_bar * beta + gamma)
           * S(z_omega_bar))
-    l1_coeff = P(B.i_ntt_381(SV([1] + [0] * (n - 1))), B.MONO)
+    l1_coeff = B.i_ntt_poly(P(SV([1] + [0] * (n - 1)), B.LAG))
     r3 = (z - S(1)) * l1_coeff.coeffs_evaluate(S(zeta))
     z_h = st.z_h()
     omega = root_of_unity(n)
@@ -254,5 +319,5 @@ def round_5(st):
               / P(SV([-zeta, 1]), B.MONO))
     w_zeta_omega = (z - S(z_omega_bar)) / P(SV([-(zeta * omega), 1]), B.MONO)
     out = (B.commit(w_zeta), B.commit(w_zeta_omega))
-    st.log["round_5"] = dict(r=r_coeff.values, w_zeta=w_zeta.values, w_zeta_omega=w_zeta_omega.values, commits=out)
+    st.record("round_5", r=r_coeff, w_zeta=w_zeta, w_zeta_omega=w_zeta_omega, commits=out)
     return out

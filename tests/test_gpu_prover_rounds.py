@@ -52,10 +52,10 @@ def g1_only_verify(n, tau, proof, ev, ch, vk, public_inputs):
     neg = lambda P: None if P is None else (P[0], (-P[1]) % M.P)
     z_h_zeta = (pow(zeta, n, Q) - 1) % Q
     omega = M.omega(n)
-    l1 = M.dft([1] + [0] * (n - 1), inverse=True)
-    l_1_zeta = sum(c * pow(zeta, i, Q) for i, c in enumerate(l1)) % Q
-    pi = M.dft([(-x) % Q for x in public_inputs] + [0] * (n - len(public_inputs)), inverse=True)
-    pi_eval = sum(c * pow(zeta, i, Q) for i, c in enumerate(pi)) % Q
+    # L_i(zeta) = omega^i (zeta^n - 1) / (n (zeta - omega^i)): the value verifier.rs:91-104 obtains by i_ntt + coeffs_evaluate
+    lag = lambda i: pow(omega, i, Q) * z_h_zeta % Q * pow(n * (zeta - pow(omega, i, Q)) % Q, Q - 2, Q) % Q
+    l_1_zeta = lag(0)
+    pi_eval = sum((-x) * lag(i) for i, x in enumerate(public_inputs)) % Q
     a_bar, b_bar, c_bar, s1_bar, s2_bar, zw_bar = (ev[k] for k in ("a_bar", "b_bar", "c_bar", "s1_bar", "s2_bar", "z_omega_bar"))
     rl = lambda s, o: (s + o * beta + gamma) % Q
     r_0 = (pi_eval - l_1_zeta * alpha * alpha - alpha * rl(a_bar, s1_bar) * rl(b_bar, s2_bar) * (c_bar + gamma) * zw_bar) % Q
@@ -74,12 +74,12 @@ def g1_only_verify(n, tau, proof, ev, ch, vk, public_inputs):
     return lhs == rhs
 
 
-def run_rounds(B, n, cols, pk, public, blinders, ch, z_fn):
-    st = PR.ProverState(B, n, pk, blinders)
+def run_rounds(B, n, cols, pk, public, blinders, ch, z_fn=None, logging=True):
+    st = PR.ProverState(B, n, pk, blinders, logging)
     proof = {}
     proof["a_1"], proof["b_1"], proof["c_1"] = PR.round_1(st, cols[0], cols[1], cols[2], public)
     st.rand.update(beta=ch["beta"], gamma=ch["gamma"])
-    proof["z_1"] = PR.round_2(st, z_fn)
+    proof["z_1"] = PR.round_2(st)
     st.rand["alpha"] = ch["alpha"]
     proof["t_lo_1"], proof["t_mid_1"], proof["t_hi_1"] = PR.round_3(st)
     st.rand["zeta"] = ch["zeta"]
@@ -132,17 +132,17 @@ def test_toy_circuit_rounds_gpu_vs_oracle_and_verify():
     assert not g1_only_verify(n, tau, pts, bad, ch, vk, [80])
 
 
-def prove_with_blinding(B, n, cols, pk, public, blinders, z_fn):
+def prove_with_blinding(B, n, cols, pk, public, blinders, z_fn=None, logging=True):
     """src/prover.rs:106-176 with the blinders as an argument (the reference draws them from thread_rng, :108-110) and the
     Fiat-Shamir challenges from the Merlin transcript exactly as src/transcript.rs derives them"""
     from tests.merlin_transcript import PlonkTranscript
     comp = lambda b96: M.enc48(decode(b96))
     tr = PlonkTranscript()
-    st = PR.ProverState(B, n, pk, blinders)
+    st = PR.ProverState(B, n, pk, blinders, logging)
     proof = {}
     proof["a_1"], proof["b_1"], proof["c_1"] = PR.round_1(st, cols[0], cols[1], cols[2], public)
     st.rand["beta"], st.rand["gamma"] = tr.round_1(comp(proof["a_1"]), comp(proof["b_1"]), comp(proof["c_1"]))
-    proof["z_1"] = PR.round_2(st, z_fn)
+    proof["z_1"] = PR.round_2(st)
     st.rand["alpha"] = tr.round_2(comp(proof["z_1"]))
     proof["t_lo_1"], proof["t_mid_1"], proof["t_hi_1"] = PR.round_3(st)
     st.rand["zeta"] = tr.round_3(comp(proof["t_lo_1"]), comp(proof["t_mid_1"]), comp(proof["t_hi_1"]))
@@ -188,3 +188,55 @@ def test_toy_circuit_deterministic_proof_bytes_and_verify():
     assert g1_only_verify(n, tau, {k: decode(v) for k, v in proof_g.items()}, ev_g, ch, vk, [80])
     # a different public input is rejected
     assert not g1_only_verify(n, tau, {k: decode(v) for k, v in proof_g.items()}, ev_g, ch, vk, [81])
+
+
+def synthetic_circuit(n, seed):
+    """n multiplication gates z_i = x_i * y_i chained by copy constraints x_{i+1} = z_i (qm = -1, qo = 1, as the
+    reference's parser emits for `c <== a * b`, assembly.rs:30-81); no public inputs"""
+    rnd = random.Random(seed)
+    x = rnd.randrange(Q)
+    cols = [[0] * n for _ in range(3)]
+    for i in range(n):
+        y = rnd.randrange(Q)
+        cols[0][i], cols[1][i], cols[2][i] = x, y, x * y % Q
+        x = cols[2][i]
+    zero = [0] * n
+    pk = dict(ql=zero, qr=zero, qm=[Q - 1] * n, qo=[1] * n, qc=zero)
+    om = M.omega(n)
+    pw = [1] * n
+    for i in range(1, n):
+        pw[i] = pw[i - 1] * om % Q
+    lab = lambda col, row: (col + 1) * pw[row] % Q
+    s1, s2, s3 = [lab(0, i) for i in range(n)], [lab(1, i) for i in range(n)], [lab(2, i) for i in range(n)]
+    for i in range(n - 1):                      # cycle {(C, i), (A, i+1)}
+        s3[i], s1[i + 1] = lab(0, i + 1), lab(2, i)
+    pk.update(s1=s1, s2=s2, s3=s3)
+    return cols, pk, [0] * n
+
+
+def test_device_resident_pipeline_toy_and_synthetic():
+    """the same five rounds with every polynomial resident in HBM (DevicePolynomial)"""
+    import hashlib, os
+    # toy circuit: identical proof bytes (committed fixture)
+    n, tau = 8, 101
+    cols, pk, public = toy_circuit(n)
+    blinders = [random.Random(99).randrange(1, Q) for _ in range(11)]
+    setup = bp.Setup.generate_srs(n + 6, tau)
+    dev = PR.GpuDeviceBackend(setup)
+    proof, ev, blob = prove_with_blinding(dev, n, cols, pk, public, blinders)
+    golden = open(os.path.join(os.path.dirname(__file__), "golden", "toy_proof_blinders_seed99.sha256")).read().strip()
+    assert hashlib.sha256(blob).hexdigest() == golden
+    # synthetic 2^10-gate circuit: device-resident == host-pointer GPU path == oracle path, and the proof verifies
+    n, tau = 1 << 10, 0x1234567
+    cols, pk, public = synthetic_circuit(n, 5)
+    setup = bp.Setup.generate_srs(n + 6, tau)
+    dev, gpu = PR.GpuDeviceBackend(setup), PR.GpuBackend(setup)
+    cpu = PR.OracleBackend(O.proj_from_bytes96(setup.powers_of_x()))
+    cpu.threads = 16
+    proof_d, ev_d, blob_d = prove_with_blinding(dev, n, cols, pk, public, blinders, logging=False)
+    proof_g, ev_g, blob_g = prove_with_blinding(gpu, n, cols, pk, public, blinders, logging=False)
+    proof_c, ev_c, blob_c = prove_with_blinding(cpu, n, cols, pk, public, blinders, logging=False)
+    assert blob_d == blob_g == blob_c
+    vk = {k: decode(dev.commit(dev.i_ntt_poly(dev.Polynomial(PR.SV(pk[k]), dev.LAG)))) for k in pk}
+    ch = compute_challenges(proof_d, ev_d)
+    assert g1_only_verify(n, tau, {k: decode(v) for k, v in proof_d.items()}, ev_d, ch, vk, [])
