@@ -49,8 +49,12 @@ int poly_div_run(bp_ctx* ctx, fr_t* d_a, size_t na, const fr_t* d_b, size_t nb, 
     hipLaunchKernelGGL(poly_div_binomial_local, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, d_a, nq, m, f,
                        lead_inv, K, chunks, d_q, head);
     if (chunks > 1) {
-      hipLaunchKernelGGL(poly_div_binomial_carry, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, nq, m, f, K, chunks,
-                         head, carry);
+      if (chunks > 64 && m <= 4096)          // long chains: a workgroup per chain
+        hipLaunchKernelGGL(poly_div_binomial_carry_wg, dim3((unsigned)m), dim3(256), 512 * sizeof(fr_t), ctx->stream, nq, m, f, K, chunks,
+                           head, carry);
+      else
+        hipLaunchKernelGGL(poly_div_binomial_carry, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, nq, m, f, K, chunks,
+                           head, carry);
       hipLaunchKernelGGL(poly_div_binomial_apply, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, nq, m, f, K, chunks,
                          carry, d_q);
     }

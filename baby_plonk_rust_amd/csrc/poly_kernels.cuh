@@ -107,6 +107,53 @@ __global__ void __launch_bounds__(256) poly_div_binomial_carry(size_t nq, size_t
     Fr::add(c, head, t);
   }
 }
+// Long chains (small m, e.g. the linear divisors x - zeta of prover.rs:623-638): one workgroup per chain.  Lane t owns
+// the run of chunks [t*S, (t+1)*S): it first composes its run into an affine map carry_out = A * carry_in + B, lane 0
+// chains the 256 maps, then every lane replays its run writing the per-chunk carries.  Sequential depth 2S + 256
+// instead of the number of chunks.
+__global__ void __launch_bounds__(256) poly_div_binomial_carry_wg(size_t nq, size_t m, fr_t f, uint32_t K, size_t chunks_per_chain,
+                                                                   const fr_t* __restrict__ chunk_head, fr_t* __restrict__ carry) {
+  const size_t r = blockIdx.x;
+  if (r >= m || r >= nq) return;
+  const size_t len = (nq - r + m - 1) / m;
+  const size_t S = (chunks_per_chain + blockDim.x - 1) / blockDim.x;
+  const size_t ck0 = (size_t)threadIdx.x * S, ck1 = ck0 + S < chunks_per_chain ? ck0 + S : chunks_per_chain;
+  const fr_t fK = fr_pow_u64(f, K);
+  fr_t A = Fr::one(), B = Fr::zero();
+  for (size_t ck = ck0; ck < ck1; ck++) {
+    const size_t j_hi = len > ck * K ? len - ck * K : 0;
+    if (j_hi == 0) break;
+    const size_t j_lo = j_hi > K ? j_hi - K : 0;
+    fr_t head = load_fr(&chunk_head[ck * m + r]), fp = (j_hi - j_lo == K) ? fK : fr_pow_u64(f, j_hi - j_lo);
+    Fr::mul(A, A, fp);                       // carry_out = head + fp * (A_prev * c + B_prev)
+    Fr::mul(B, B, fp);
+    Fr::add(B, B, head);
+  }
+  fr_t* buf = reinterpret_cast<fr_t*>(poly_lds_raw);         // [0..255] = A, [256..511] = B, then carry-in per lane
+  buf[threadIdx.x] = A;
+  buf[blockDim.x + threadIdx.x] = B;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fr_t c = Fr::zero();
+    for (uint32_t t = 0; t < blockDim.x; t++) {
+      fr_t a = buf[t], b = buf[blockDim.x + t], nc;
+      buf[t] = c;                            // carry into lane t's run
+      Fr::mul(nc, a, c);
+      Fr::add(c, nc, b);
+    }
+  }
+  __syncthreads();
+  fr_t c = buf[threadIdx.x];
+  for (size_t ck = ck0; ck < ck1; ck++) {
+    store_fr(&carry[ck * m + r], c);
+    const size_t j_hi = len > ck * K ? len - ck * K : 0;
+    if (j_hi == 0) break;
+    const size_t j_lo = j_hi > K ? j_hi - K : 0;
+    fr_t head = load_fr(&chunk_head[ck * m + r]), fp = (j_hi - j_lo == K) ? fK : fr_pow_u64(f, j_hi - j_lo), t;
+    Fr::mul(t, c, fp);
+    Fr::add(c, head, t);
+  }
+}
 __global__ void __launch_bounds__(256) poly_div_binomial_apply(size_t nq, size_t m, fr_t f, uint32_t K, size_t chunks_per_chain,
                                                                 const fr_t* __restrict__ carry, fr_t* __restrict__ q) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,11 +286,17 @@ __global__ void __launch_bounds__(256) grand_product_combine(const fr_t* __restr
 // out[0] = 1 + index of the last non-zero element (0 when all are zero); out[1] = number of non-zero elements in [lo, hi)
 __global__ void __launch_bounds__(256) fr_nonzero_stats(const fr_t* __restrict__ a, size_t n, size_t lo, size_t hi, unsigned long long* __restrict__ out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  fr_t v = load_fr(&a[i]);
-  if (!big_is_zero(v)) {
-    atomicMax(&out[0], (unsigned long long)(i + 1));
-    if (i >= lo && i < hi) atomicAdd(&out[1], 1ull);
+  bool nz = false;
+  if (i < n) {
+    fr_t v = load_fr(&a[i]);
+    nz = !big_is_zero(v);
+  }
+  // one atomic pair per wave instead of one per element
+  const unsigned long long mask = __ballot(nz), in_range = __ballot(nz && i >= lo && i < hi);
+  if ((threadIdx.x & 63) == 0 && mask) {
+    const size_t wave_base = i;                                  // lane 0 of the wave
+    atomicMax(&out[0], (unsigned long long)(wave_base + (64 - __clzll(mask))));
+    if (in_range) atomicAdd(&out[1], (unsigned long long)__popcll(in_range));
   }
 }
 // out[i] = a[i] * w^i   (p(x) -> p(w x); prover.rs:661-674 monomial_z_to_z_omega)

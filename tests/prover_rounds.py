@@ -25,7 +25,20 @@ def S(v):
 
 
 def SV(vals):
-    return O.fr_array_from_ints([v % Q for v in vals])
+    """list of ints -> Montgomery limbs [n, 4]; zeros (the bulk of x^n - 1, L_1, x^n ...) cost nothing"""
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        if v:
+            out[i] = O.fr_from_int(v % Q)
+    return out
+
+
+def sparse(length, entries):
+    """limbs of a length-`length` vector that is zero except for {index: int}"""
+    out = np.zeros((length, 4), dtype=np.uint64)
+    for i, v in entries.items():
+        out[i] = O.fr_from_int(v % Q)
+    return out
 
 
 def ints(values):
@@ -210,7 +223,7 @@ class ProverState:
             self.log[rk] = {k: (v.values if hasattr(v, "values") else v) for k, v in kw.items()}
 
     def z_h(self):                                               # x^n - 1 (prover.rs:229-235)
-        return self.B.Polynomial(SV([-1] + [0] * (self.n - 1) + [1]), self.B.MONO)
+        return self.B.Polynomial(sparse(self.n + 1, {0: -1, self.n: 1}), self.B.MONO)
 
 
 def rlc(p, other, beta, gamma):
@@ -253,7 +266,7 @@ def round_3(st):
     B, P, n = st.B, st.B.Polynomial, st.n
     coeff = {k: B.i_ntt_poly(st.pk[k]) for k in ("s1", "s2", "s3", "ql", "qr", "qm", "qo", "qc")}
     a, b, c, z = st.wp["a_coeff"], st.wp["b_coeff"], st.wp["c_coeff"], st.wp["z_coeff"]
-    l1 = P(SV([1] + [0] * (n - 1)), B.LAG)
+    l1 = P(sparse(n, {0: 1}), B.LAG)
     z_h = st.z_h()
     gate = (a * coeff["ql"] + b * coeff["qr"] + a * b * coeff["qm"] + c * coeff["qo"]
             + st.public_input_poly.i_ntt() + coeff["qc"])
@@ -269,7 +282,7 @@ def round_3(st):
     t = all_constraints / z_h
     t_lo, t_mid, t_hi = B.slice(t, 0, n), B.slice(t, n, 2 * n), B.slice(t, 2 * n)                # prover.rs:649-659
     b10, b11 = st.b[9], st.b[10]
-    x_pow_n = P(SV([0] * n + [1]), B.MONO)
+    x_pow_n = P(sparse(n + 1, {n: 1}), B.MONO)
     t_lo = t_lo + x_pow_n * S(b10)
     t_mid = t_mid + (x_pow_n * S(b11) - S(b10))
     t_hi = t_hi + S(-b11)
@@ -305,7 +318,7 @@ def round_5(st):
     r2 = (z * S(a_bar + zeta * beta + gamma) * S(b_bar + zeta * beta * K1 + gamma) * S(c_bar + zeta * beta * K2 + gamma)
           - (pk["s3"].i_ntt() * S(beta) + S(c_bar) + S(gamma)) * S(a_bar + s1_bar * beta + gamma) * S(b_bar + s2_bar * beta + gamma)
           * S(z_omega_bar))
-    l1_coeff = B.i_ntt_poly(P(SV([1] + [0] * (n - 1)), B.LAG))
+    l1_coeff = B.i_ntt_poly(P(sparse(n, {0: 1}), B.LAG))
     r3 = (z - S(1)) * l1_coeff.coeffs_evaluate(S(zeta))
     z_h = st.z_h()
     omega = root_of_unity(n)

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] rehearsal: the reference prover's rounds 1-5 (restated in tests/prover_rounds.py) on a synthetic
+n-gate circuit with every polynomial resident in HBM (DevicePolynomial), random SRS (tau known so the proof can be checked
+in G1), Merlin challenges.  Prints one JSON line per size: seconds per proof, proofs/s, and whether the proof verifies.
+Measurement script -- the prover logic lives in tests/ because the transcript / circuit front-end are out of the product's
+scope; what is timed is the product's MSM / NTT / polynomial / grand-product kernels under the reference's call pattern."""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import baby_plonk_rust_amd as bp
+from baby_plonk_rust_amd import _lib
+from tests import bigint_model as M
+from tests import prover_rounds as PR
+from tests.test_gpu_prover_rounds import compute_challenges, decode, g1_only_verify, prove_with_blinding
+
+Q = M.Q
+
+
+def ints_to_mont(vals):
+    raw = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).copy()
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    rc = _lib.load().bp_fr_convert(raw.ctypes.data, len(vals), 0, 1, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def synthetic(n, seed):
+    rnd = random.Random(seed)
+    x = rnd.randrange(Q)
+    A, Bc, Cc = [0] * n, [0] * n, [0] * n
+    for i in range(n):
+        y = rnd.getrandbits(250)
+        A[i], Bc[i], Cc[i] = x, y, x * y % Q
+        x = Cc[i]
+    om = M.omega(n)
+    pw = [1] * n
+    for i in range(1, n):
+        pw[i] = pw[i - 1] * om % Q
+    s1, s2, s3 = list(pw), [2 * v % Q for v in pw], [3 * v % Q for v in pw]
+    for i in range(n - 1):
+        s3[i], s1[i + 1] = pw[i + 1], 3 * pw[i] % Q
+    zero = np.zeros((n, 4), dtype=np.uint64)
+    pk = dict(ql=zero, qr=zero, qm=ints_to_mont([Q - 1] * n), qo=ints_to_mont([1] * n), qc=zero,
+              s1=ints_to_mont(s1), s2=ints_to_mont(s2), s3=ints_to_mont(s3))
+    return [ints_to_mont(A), ints_to_mont(Bc), ints_to_mont(Cc)], pk, zero.copy()
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--log-n", type=int, nargs="+", default=[12, 16])
+ap.add_argument("--reps", type=int, default=2)
+args = ap.parse_args()
+for k in args.log_n:
+    n, tau = 1 << k, 0x1234567 + k
+    t0 = time.perf_counter()
+    cols, pk, public = synthetic(n, k)
+    setup = bp.Setup.generate_srs(n + 6, tau)
+    dev = PR.GpuDeviceBackend(setup)
+    blinders = [random.Random(k).randrange(1, Q) for _ in range(11)]
+    t_setup = time.perf_counter() - t0
+    times = []
+    for _ in range(args.reps):
+        t1 = time.perf_counter()
+        proof, ev, blob = prove_with_blinding(dev, n, cols, pk, public, blinders, logging=False)
+        times.append(time.perf_counter() - t1)
+    vk = {name: decode(dev.commit(dev.i_ntt_poly(dev.Polynomial(pk[name], dev.LAG)))) for name in pk}
+    ok = g1_only_verify(n, tau, {name: decode(v) for name, v in proof.items()}, ev, compute_challenges(proof, ev), vk, [])
+    print(json.dumps({"gates": n, "seconds_per_proof": min(times), "proofs_per_s": 1.0 / min(times), "verifies": bool(ok),
+                      "proof_bytes": len(blob), "setup_seconds": t_setup,
+                      "note": "includes uploading the witness / selector columns; SRS generation and circuit synthesis excluded"}), flush=True)
+    setup.ctx.srs_free(setup.handle)
