@@ -199,3 +199,17 @@ def test_full_size_2p20_closed_form(ctx):
     p1, p2 = ctx.msm_partial(h, sc), ctx.msm_partial(h, sc2)
     assert bp.sum_partials(p1 + p2) == ctx.msm(h, both)
     ctx.srs_free(h)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 31, 32, 33, 100, 257, 1000, 4097, 30000])
+def test_odd_sizes_vs_oracle(ctx, n):
+    """the toy proof commits to 9..14 coefficients; nothing here assumes powers of two"""
+    a, d = 99991 + n, 31337
+    h = ctx.srs_generate_progression(n + 3, a, d)                 # SRS longer than the scalar vector (zip truncation)
+    sc = O.splitmix_scalars(n, 0xABC0 + n)
+    got = ctx.msm(h, sc)
+    assert got == M.enc96(M.ec_mul(oracle_dot(sc, a, d)))
+    if n <= 1000:
+        aff = O.points_progression(n, a, d)
+        assert got == O.g1_bytes96(O.bucket_msm(O.affine_to_proj(aff), sc, threads=NTHREADS))
+    ctx.srs_free(h)

@@ -115,3 +115,44 @@ def test_ntt_roundtrip_methods(ctx):
     assert p.ntt().basis == LAG and (p.ntt().i_ntt().values == c).all()
     with pytest.raises(bp.BpError):
         p.i_ntt()
+
+
+def test_canonical_byte_format_paths(ctx):
+    """BP_FR_BYTES_LE (Scalar::to_bytes) in and out for every host-pointer operator"""
+    import ctypes as C
+    rnd = random.Random(34)
+    lib, h = ctx._lib, ctx._h
+    le = lambda vals: np.frombuffer(b"".join((v % Q).to_bytes(32, "little") for v in vals), dtype=np.uint8).copy()
+    back = lambda buf, n: [int.from_bytes(bytes(buf[32 * i: 32 * i + 32]), "little") for i in range(n)]
+    a, b = [rnd.randrange(Q) for _ in range(7)], [rnd.randrange(Q) for _ in range(4)]
+    A, B = le(a), le(b)
+    out, n = np.zeros(32 * 16, dtype=np.uint8), C.c_size_t()
+    ctx.check(lib.bp_poly_mul(h, A.ctypes.data, 7, B.ctypes.data, 4, MONO, bp.FR_BYTES_LE, out.ctypes.data, C.byref(n)), "mul")
+    want = [0] * 10
+    for i, x in enumerate(a):
+        for j, y in enumerate(b):
+            want[i + j] = (want[i + j] + x * y) % Q
+    assert n.value == 10 and back(out, 10) == want
+    prod = le(want)
+    ctx.check(lib.bp_poly_div(h, prod.ctypes.data, 10, B.ctypes.data, 4, MONO, bp.FR_BYTES_LE, out.ctypes.data, C.byref(n)), "div")
+    assert n.value == 7 and back(out, 7) == a
+    ctx.check(lib.bp_poly_add(h, A.ctypes.data, 7, B.ctypes.data, 4, MONO, bp.FR_BYTES_LE, out.ctypes.data, C.byref(n)), "add")
+    assert back(out, 7) == [(x + (b[i] if i < 4 else 0)) % Q for i, x in enumerate(a)]
+    ctx.check(lib.bp_poly_sub(h, A.ctypes.data, 7, B.ctypes.data, 4, MONO, bp.FR_BYTES_LE, out.ctypes.data, C.byref(n)), "sub")
+    assert back(out, 7) == [(x - (b[i] if i < 4 else 0)) % Q for i, x in enumerate(a)]
+    x = le([12345])
+    r = np.zeros(32, dtype=np.uint8)
+    ctx.check(lib.bp_poly_evaluate(h, A.ctypes.data, 7, MONO, x.ctypes.data, bp.FR_BYTES_LE, r.ctypes.data), "eval")
+    assert back(r, 1) == [sum(v * pow(12345, i, Q) for i, v in enumerate(a)) % Q]
+    ctx.check(lib.bp_poly_scalar_op(h, A.ctypes.data, 7, LAG, x.ctypes.data, 2, bp.FR_BYTES_LE, out.ctypes.data), "scalar mul")
+    assert back(out, 7) == [v * 12345 % Q for v in a]
+    # NTT in canonical bytes with a batch
+    data = le([rnd.randrange(Q) for _ in range(32)])
+    orig = back(data, 32)
+    ctx.check(lib.bp_ntt_fr(h, data.ctypes.data, 3, 0, bp.FR_BYTES_LE, 4, 8), "ntt batch")
+    from tests import bigint_model as M
+    for bidx in range(4):
+        assert back(data, 32)[8 * bidx: 8 * bidx + 8] == M.dft(orig[8 * bidx: 8 * bidx + 8])
+    # a non-canonical scalar argument is rejected
+    bad = np.frombuffer((Q + 1).to_bytes(32, "little"), dtype=np.uint8).copy()
+    assert lib.bp_poly_evaluate(h, A.ctypes.data, 7, MONO, bad.ctypes.data, bp.FR_BYTES_LE, r.ctypes.data) == -4
