@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--ntt-log-n", type=int, default=20, help="NTT length per GPU = 2^ntt_log_n")
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                                                      "the N > 1 control flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,17 +98,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > n_dev:
+        raise SystemExit("bench.py: %d ranks but %d GPUs (one process per GPU)" % (world, n_dev))
+    dev_index = local_rank % max(n_dev, 1)            # == local_rank except in a gloo rehearsal
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    ctx = bp.Context(local_rank)
+    ctx = bp.Context(dev_index)
     n = 1 << args.log_n
     # this rank's point range [rank*n, (rank+1)*n) of the global progression, resident in HBM
     srs = ctx.srs_generate_progression(n, A0 + rank * n * D0, D0)
@@ -149,7 +158,7 @@ def main():
     ntt_passes = ctx.ntt_stats()["passes"]
 
     if world > 1:
-        t = torch.tensor([elapsed, ntt_elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, ntt_elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, ntt_elapsed = float(t[0]), float(t[1])
 
