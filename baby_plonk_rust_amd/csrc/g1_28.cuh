@@ -30,14 +30,17 @@ struct g1_proj28 {                    // 168 bytes of limbs (stored padded to 17
 };
 constexpr int PROJ28_WORDS = 44;
 
-BP_HD g1_proj28 g1_identity28() {     // (0 : 1 : 0) with 1 = 2^392 mod p
+// 1 in the 28-bit Montgomery domain: 2^392 mod p, radix 2^28 (a literal table: the conversion through the saturated
+// multiplier would otherwise run on every bucket flush of every wave)
+struct One28 {
+  BP_TABLE(limb, 0x347fcb8u, 0xd800000u, 0x002b119u, 0x0cde6d2u, 0xc7212e0u, 0x83a2090u, 0x037669fu, 0xda0f73eu, 0x9b09b42u, 0x1297bb0u, 0x515d98fu, 0x012ca7cu, 0x659fcfau, 0x000577au)
+};
+BP_HD g1_proj28 g1_identity28() {     // (0 : 1 : 0)
   g1_proj28 r;
-  fp_t one_std = Fp::one();
-  F28n one = fp_to_28(one_std);
 #pragma unroll
   for (int i = 0; i < N28; i++) {
     r.x.l[i] = 0;
-    r.y.l[i] = one.l[i];
+    r.y.l[i] = One28::limb(i);
     r.z.l[i] = 0;
   }
   return r;
