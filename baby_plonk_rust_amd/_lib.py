@@ -39,6 +39,9 @@ SIGNATURES = {
     "bp_srs_len": (_int, [_vp, _u64, _pp(_sz)]),
     "bp_srs_export": (_int, [_vp, _u64, _sz, _sz, _vp]),
     "bp_srs_free": (_int, [_vp, _u64]),
+    "bp_srs_precompute": (_int, [_vp, _u64, _u32]),
+    "bp_srs_table_info": (_int, [_vp, _u64, _pp(_u32), _pp(_u32), _pp(_u64)]),
+    "bp_msm_last_used_tables": (_int, [_vp]),
     "bp_msm_g1": (_int, [_vp, _u64, _vp, _sz, _int, _vp]),
     "bp_msm_g1_partial": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),
     "bp_g1_sum_partials": (_int, [_vp, _sz, _vp]),

@@ -16,10 +16,14 @@ Scalars travel as numpy uint64 arrays of shape [n, 4]: the reference's Montgomer
 scalar.rs:35-40).  Points travel in the 96-byte uncompressed encoding (g1.rs:246-260)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _lib
 from ._lib import BASIS_LAGRANGE, BASIS_MONOMIAL, FR_BYTES_LE, FR_MONT, BpError
+
+SRS_TABLES_OFF = 1      # bp_srs_precompute(window_bits): drop the fixed-base tables
 
 Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 _R = pow(2, 256, Q)
@@ -115,6 +119,17 @@ class Context:
     def srs_free(self, handle):
         self.check(self._lib.bp_srs_free(self._h, handle), "bp_srs_free")
 
+    def srs_precompute(self, handle, window_bits=0):
+        """fixed-base window tables T[w][i] = 2^(c w) P_i for an SRS that serves many MSMs (0 = auto width,
+        SRS_TABLES_OFF drops them)"""
+        self.check(self._lib.bp_srs_precompute(self._h, handle, window_bits), "bp_srs_precompute")
+        return self.srs_table_info(handle)
+
+    def srs_table_info(self, handle):
+        c, w, b = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        self.check(self._lib.bp_srs_table_info(self._h, handle, C.byref(c), C.byref(w), C.byref(b)), "bp_srs_table_info")
+        return {"window_bits": c.value, "windows": w.value, "bytes": b.value}
+
     def msm(self, handle, scalars, fmt=FR_MONT):
         s = _fr_array(scalars) if fmt == FR_MONT else np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
         out = np.zeros(96, dtype=np.uint8)
@@ -135,7 +150,8 @@ class Context:
     def msm_stats(self):
         a, t, adds, c = C.c_float(), C.c_float(), C.c_uint64(), C.c_uint32()
         self.check(self._lib.bp_msm_last_stats(self._h, C.byref(a), C.byref(t), C.byref(adds), C.byref(c)), "bp_msm_last_stats")
-        return {"accumulate_ms": a.value, "device_ms": t.value, "mixed_adds": adds.value, "window_bits": c.value}
+        return {"accumulate_ms": a.value, "device_ms": t.value, "mixed_adds": adds.value, "window_bits": c.value,
+                "tables": self._lib.bp_msm_last_used_tables(self._h) == 1}
 
     def ntt(self, values, inverse=False, fmt=FR_MONT):
         """one vector; raises like the reference's assert!(is_power_of_two(n)) (utils.rs:65,108)"""
@@ -474,21 +490,25 @@ def round_2_z(a, b, c, s1, s2, s3, beta, gamma, k1=None, k2=None, ctx=None):
 
 
 class Setup:
-    """src/setup.rs:7-10 (G1 part; x_2 in G2 belongs to the verifier's pairing, out of scope)"""
+    """src/setup.rs:7-10 (G1 part; x_2 in G2 belongs to the verifier's pairing, out of scope).
+    A Setup serves every commitment of a prover, so it builds the SRS's fixed-base window tables once
+    (bp_srs_precompute) unless tables=False or BP_SRS_TABLES=0."""
 
-    def __init__(self, handle, ctx):
+    def __init__(self, handle, ctx, tables=True):
         self.handle, self.ctx = handle, ctx
+        if tables and os.environ.get("BP_SRS_TABLES", "1") != "0":
+            ctx.srs_precompute(handle, 0)
 
     @staticmethod
-    def generate_srs(powers, tau_int, ctx=None):
+    def generate_srs(powers, tau_int, ctx=None, tables=True):
         """setup.rs:12-31: [G, tau G, ..., tau^(powers-1) G], generated and kept on the GPU"""
         ctx = ctx or default_context()
-        return Setup(ctx.srs_generate(powers, tau_int), ctx)
+        return Setup(ctx.srs_generate(powers, tau_int), ctx, tables)
 
     @staticmethod
-    def from_points(points96, ctx=None):
+    def from_points(points96, ctx=None, tables=True):
         ctx = ctx or default_context()
-        return Setup(ctx.srs_load(points96), ctx)
+        return Setup(ctx.srs_load(points96), ctx, tables)
 
     def powers_of_x(self):
         return self.ctx.srs_export(self.handle)

@@ -64,6 +64,21 @@ void host_horner(g1_proj& out, const g1_proj* window_sums, uint32_t W, uint32_t 
   out = acc;
 }
 
+// planes[w * c + 0] = A_w, planes[w * c + 1 + j] = T_{w,j} (j < c - 1):
+//   out = sum_w 2^(c w) (A_w + sum_j 2^j T_{w,j}),  one pass from the top bit position down
+void host_plane_horner(g1_proj& out, const g1_proj* planes, uint32_t W, uint32_t c) {
+  g1_proj acc = g1_identity();
+  for (uint32_t w = W; w-- > 0;) {
+    const g1_proj* p = planes + (size_t)w * c;
+    for (uint32_t j = c; j-- > 0;) {
+      g1_double(acc, acc);
+      if (j + 1 < c) g1_add(acc, acc, p[1 + j]);           // bit position c - 1 of the window carries no plane
+    }
+    g1_add(acc, acc, p[0]);
+  }
+  out = acc;
+}
+
 static void fp_to_be48_host(uint8_t* b, const fp_t& a) {
   for (int i = 0; i < 12; i++) {
     uint8_t* p = b + 4 * (11 - i);
@@ -329,7 +344,41 @@ int bp_srs_free(bp_ctx* ctx, uint64_t srs_handle) {
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   BP_HIP(ctx, hipFree(e->d_points));
   BP_HIP(ctx, hipFree(e->d_points28));
+  if (e->d_table) BP_HIP(ctx, hipFree(e->d_table));
   ctx->srs.erase(srs_handle);
+  return BP_OK;
+}
+
+int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  SrsEntry* e;
+  BP_TRY(srs_find(ctx, srs_handle, &e));
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (e->d_table) {
+    BP_HIP(ctx, hipFree(e->d_table));
+    e->d_table = nullptr;
+    e->table_c = e->table_W = 0;
+  }
+  if (window_bits == BP_SRS_TABLES_OFF) return BP_OK;
+  uint32_t c = window_bits;
+  if (c == 0) {                       // auto: reduction work 2^c stays below the bucket-add work W * n
+    c = 4;
+    while (c < 16 && (1ull << (c + 1)) <= 4 * (uint64_t)e->n) c++;
+  }
+  if (c < 4 || c > 16) return fail(ctx, BP_ERR_INVALID_ARG, "window_bits must be 0 (auto), 1 (off) or 4..16", hipSuccess, __FILE__, __LINE__);
+  BP_TRY(srs_tables_run(ctx, e->d_points, e->d_points28, e->n, c, &e->d_table, &e->table_W));
+  e->table_c = c;
+  return BP_OK;
+}
+
+int bp_srs_table_info(bp_ctx* ctx, uint64_t srs_handle, uint32_t* window_bits, uint32_t* windows, uint64_t* bytes) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  SrsEntry* e;
+  BP_TRY(srs_find(ctx, srs_handle, &e));
+  if (window_bits) *window_bits = e->table_c;
+  if (windows) *windows = e->table_W;
+  if (bytes) *bytes = e->d_table ? (uint64_t)e->table_W * e->n * sizeof(g1_affine28) : 0;
   return BP_OK;
 }
 
@@ -350,7 +399,10 @@ int bp_msm_g1_partial(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void
     d_scalars = d;
   }
   g1_proj r;
-  BP_TRY(msm_run(ctx, e->d_points + first, e->d_points28 + first, n, d_scalars, scalar_fmt, &r));
+  // fixed-base tables pay once the bucket adds outweigh the fixed 2^table_c reduction
+  const bool tables = e->d_table && 8 * (uint64_t)n >= (1ull << e->table_c);
+  if (tables) BP_TRY(msm_run(ctx, e->d_table + first, n, d_scalars, scalar_fmt, e->table_c, e->n, &r));
+  else BP_TRY(msm_run(ctx, e->d_points28 + first, n, d_scalars, scalar_fmt, 0, 0, &r));
   memcpy(out144, &r, 144);
   return BP_OK;
 }
@@ -385,6 +437,7 @@ int bp_g1_bytes96_to_partial(const uint8_t in96[96], uint8_t out144[144]) {
   return BP_OK;
 }
 
+int bp_msm_last_used_tables(bp_ctx* ctx) { return ctx ? (ctx->msm_tables ? 1 : 0) : BP_ERR_INVALID_ARG; }
 int bp_msm_last_stats(bp_ctx* ctx, float* accumulate_ms, float* total_device_ms, uint64_t* mixed_adds, uint32_t* window_bits) {
   if (!ctx) return BP_ERR_INVALID_ARG;
   if (accumulate_ms) *accumulate_ms = ctx->msm_accumulate_ms;

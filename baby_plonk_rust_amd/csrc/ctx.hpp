@@ -21,6 +21,8 @@ struct DevBuf {
 struct SrsEntry {
   g1_affine* d_points = nullptr;        // 96 B/point, reference Montgomery limbs (export, generic kernels)
   g1_affine28* d_points28 = nullptr;    // 112 B/point, 14 x 28-bit limbs, R' = 2^392 (bucket accumulation)
+  g1_affine28* d_table = nullptr;       // optional fixed-base tables: row w = 2^(table_c w) * SRS, table_W rows of n points
+  uint32_t table_c = 0, table_W = 0;
   size_t n = 0;
 };
 
@@ -51,6 +53,7 @@ struct bp_ctx {
   float msm_accumulate_ms = 0, msm_total_ms = 0;
   uint64_t msm_adds = 0;
   uint32_t msm_c = 0;
+  bool msm_tables = false;
   float ntt_ms = 0;
   uint32_t ntt_passes = 0;
   void* pinned = nullptr;                          // small pinned staging buffer (window sums etc.)
@@ -77,8 +80,10 @@ int ws_get(bp_ctx* ctx, const char* name, size_t bytes, void** out);
 int pinned_get(bp_ctx* ctx, size_t bytes, void** out);
 
 // ---- launchers implemented in msm.hip / ntt.hip / poly.hip / srs.hip --------------------------------
-int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt,
+int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
             g1_proj* host_out);
+int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points28, size_t n, uint32_t c, g1_affine28** d_table,
+                   uint32_t* windows);
 int srs_to28_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28** d_out);
 int ntt_init_tables(bp_ctx* ctx);
 int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t log_n, int inverse, size_t batch, size_t stride);
@@ -101,6 +106,7 @@ int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t
 
 // ---- host-side helpers (host.cpp part of capi.hip) ---------------------------------------------------
 void host_horner(g1_proj& out, const g1_proj* window_sums, uint32_t W, uint32_t c);
+void host_plane_horner(g1_proj& out, const g1_proj* planes, uint32_t W, uint32_t c);
 void host_encode96(uint8_t out96[96], const g1_proj& p);
 bool host_decode96(g1_proj& out, const uint8_t in96[96]);
 

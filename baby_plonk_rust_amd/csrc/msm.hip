@@ -21,13 +21,15 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
 
 // Window width: minimise W * (n + 2 * 2^(c-1)) (bucket adds + reduction adds), bounded by the int16 digit
 // array and by the 128 KiB LDS histogram (c <= 16).
-static void make_plan(MsmPlan& plan, size_t n) {
+// table_c != 0: the SRS carries fixed-base window tables built for that width (row length table_stride)
+static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_stride) {
   memset(&plan, 0, sizeof plan);
   plan.n = (uint32_t)n;
   uint32_t c = n < 32 ? 4 : ilog2_floor(n) - 3;
   if (c < 4) c = 4;
   if (c > MSM_MAX_C) c = MSM_MAX_C;
   c = env_u32("BP_MSM_C", c);
+  if (table_c) c = table_c;
   if (c < 2) c = 2;
   if (c > MSM_MAX_C) c = MSM_MAX_C;
   // digits d_w = ((k + bias) >> c*w & mask) - 2^(c-1) with bias = sum_w 2^(c-1) 2^(cw); needs k + bias < 2^(cW)
@@ -70,16 +72,20 @@ static void make_plan(MsmPlan& plan, size_t n) {
   plan.c = c;
   plan.W = W;
   plan.B = 1u << (c - 1);
+  plan.total = table_c ? plan.B : W * plan.B;
+  plan.wbuckets = table_c ? 0 : plan.B;
+  plan.wpoints = table_c ? (uint32_t)table_stride : 0;
   const uint64_t entries = (uint64_t)W * n;
   uint32_t chunk = 4;
-  while (chunk < 64 && entries / chunk > 262144) chunk <<= 1;
+  // tables: B buckets hold all W * n entries, so chunks grow with n to keep ~8 partial runs per bucket for the fix-up
+  while (chunk < (table_c ? 1024u : 64u) && entries / chunk > 262144) chunk <<= 1;
   plan.chunk = env_u32("BP_MSM_CHUNK", chunk);
   uint32_t slices = 1024 / W;
   if (slices < 1) slices = 1;
   while (slices > 1 && n / slices < 1024) slices >>= 1;
   plan.slices = slices;
   uint32_t seg = 1;
-  while (seg < 32 && (uint64_t)W * plan.B / seg > 65536) seg <<= 1;
+  while (seg < 32 && plan.total / seg > 65536) seg <<= 1;
   plan.seg = env_u32("BP_MSM_SEG", seg);
 }
 
@@ -93,7 +99,37 @@ int srs_to28_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28** d_o
   return BP_OK;
 }
 
-int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt,
+uint32_t msm_table_windows(uint32_t c) {
+  MsmPlan plan;
+  make_plan(plan, 1, c, 1);
+  return plan.W;
+}
+
+// table[w * n + i] = 2^(c w) P_i; row 0 is the unsaturated SRS copy itself
+int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points28, size_t n, uint32_t c, g1_affine28** d_table,
+                   uint32_t* windows) {
+  const uint32_t W = msm_table_windows(c);
+  if ((uint64_t)W * n >= (1ull << 31))
+    return fail(ctx, BP_ERR_TOO_LARGE, "fixed-base tables: windows * points >= 2^31", hipSuccess, __FILE__, __LINE__);
+  g1_affine28* t = nullptr;
+  BP_HIP(ctx, hipMalloc((void**)&t, (size_t)W * (n ? n : 1) * sizeof(g1_affine28)));
+  if (n) {
+    BP_HIP(ctx, hipMemcpyAsync(t, d_points28, n * sizeof(g1_affine28), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(srs_window_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_points, n, c, W, t);
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(t);
+    return fail(ctx, BP_ERR_HIP, "srs_window_tables", e, __FILE__, __LINE__);
+  }
+  *d_table = t;
+  *windows = W;
+  return BP_OK;
+}
+
+// d_points28: the unsaturated SRS copy, or (table_c != 0) row 0 of its fixed-base tables with rows table_stride apart
+int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
             g1_proj* host_out) {
   if (n == 0) {
     *host_out = g1_identity();
@@ -103,14 +139,16 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
   }
   if (n >= (1ull << 31)) return fail(ctx, BP_ERR_TOO_LARGE, "MSM length >= 2^31", hipSuccess, __FILE__, __LINE__);
   MsmPlan plan;
-  make_plan(plan, n);
+  make_plan(plan, n, table_c, table_stride);
   if ((uint64_t)plan.W * n >= (1ull << 32))        // positions in the bucket-sorted list are 32-bit
     return fail(ctx, BP_ERR_TOO_LARGE, "MSM length * windows >= 2^32", hipSuccess, __FILE__, __LINE__);
-  const uint32_t W = plan.W, B = plan.B, total = W * B;
+  const uint32_t W = plan.W, B = plan.B, total = plan.total, Wr = table_c ? 1 : W;   // Wr: windows left after accumulation
   const uint64_t max_entries = (uint64_t)W * n;
   const uint64_t n_chunks = (max_entries + plan.chunk - 1) / plan.chunk;
-  const uint32_t lanes_per_window = (B + plan.seg - 1) / plan.seg;
-  const uint32_t blocks_per_window = (lanes_per_window + 255) / 256;
+  // bucket reduction: running sums per window, or (tables: one bucket set) the bit-plane tree in two stages of l1 + l2 levels
+  const uint32_t l1 = plan.c - 1 < PLANES_BLOCK_LOG ? plan.c - 1 : PLANES_BLOCK_LOG, l2 = plan.c - 1 - l1;
+  const uint32_t blocks_per_window = table_c ? 1u << l2 : ((B + plan.seg - 1) / plan.seg + 255) / 256;
+  const uint32_t per_block = table_c ? l1 + 1 : 1, per_window = table_c ? plan.c : 1;     // slots
 
   int16_t* digits;
   uint32_t *counts, *offsets, *cursors, *sorted;
@@ -129,14 +167,16 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
   BP_TRY(ws_get(ctx, "msm.sorted", max_entries * 4, (void**)&sorted));
   BP_TRY(ws_get(ctx, "msm.bucket_sum", (size_t)total * sizeof(proj28_slot), (void**)&bucket_sum));
   BP_TRY(ws_get(ctx, "msm.partial", 2 * n_chunks * sizeof(proj28_slot), (void**)&partial));
-  BP_TRY(ws_get(ctx, "msm.block_out", (size_t)W * blocks_per_window * sizeof(proj28_slot), (void**)&block_out));
-  BP_TRY(ws_get(ctx, "msm.window_sum", (size_t)W * sizeof(proj28_slot), (void**)&window_sum));
+  const uint32_t n_planes = Wr * per_window;        // tables: A and the c - 1 bit planes; else one sum per window
+  BP_TRY(ws_get(ctx, "msm.block_out", (size_t)Wr * blocks_per_window * per_block * sizeof(proj28_slot), (void**)&block_out));
+  BP_TRY(ws_get(ctx, "msm.window_sum", (size_t)n_planes * sizeof(proj28_slot), (void**)&window_sum));
   proj28_slot* h_windows;
-  BP_TRY(pinned_get(ctx, (size_t)W * sizeof(proj28_slot) + 16, (void**)&h_windows));
-  uint32_t* h_status = reinterpret_cast<uint32_t*>(h_windows + W);
+  BP_TRY(pinned_get(ctx, (size_t)n_planes * sizeof(proj28_slot) + 16, (void**)&h_windows));
+  uint32_t* h_status = reinterpret_cast<uint32_t*>(h_windows + n_planes);
 
   static bool lds_attr_set = false;
-  if (!lds_attr_set) {            // a full-window histogram at c = 16 needs 128 KiB of dynamic LDS
+  if (!lds_attr_set) {            // a full-window histogram at c = 16 needs 128 KiB of dynamic LDS, the plane tree 88 KiB
+    BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_planes_block, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_count, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     lds_attr_set = true;
@@ -166,11 +206,17 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
                      long_cap);
   hipLaunchKernelGGL(msm_fixup_long, dim3(64), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
                      long_count, long_list, long_cap);
-  hipLaunchKernelGGL(msm_reduce, dim3(blocks_per_window, W), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
-                     block_out);
-  hipLaunchKernelGGL(msm_window_finish, dim3(W), dim3(256), 256 * sizeof(proj28_slot), st, block_out, blocks_per_window, window_sum);
+  if (table_c) {
+    hipLaunchKernelGGL(msm_planes_block, dim3(blocks_per_window, Wr), dim3(256), 512 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
+                       l1, block_out);
+    hipLaunchKernelGGL(msm_planes_window, dim3(l1 + 1, Wr), dim3(128), 256 * sizeof(proj28_slot), st, block_out, l1, l2, window_sum);
+  } else {
+    hipLaunchKernelGGL(msm_reduce, dim3(blocks_per_window, Wr), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
+                       block_out);
+    hipLaunchKernelGGL(msm_window_finish, dim3(Wr), dim3(256), 256 * sizeof(proj28_slot), st, block_out, blocks_per_window, window_sum);
+  }
   BP_HIP(ctx, hipGetLastError());
-  BP_HIP(ctx, hipMemcpyAsync(h_windows, window_sum, (size_t)W * sizeof(proj28_slot), hipMemcpyDeviceToHost, st));
+  BP_HIP(ctx, hipMemcpyAsync(h_windows, window_sum, (size_t)n_planes * sizeof(proj28_slot), hipMemcpyDeviceToHost, st));
   BP_HIP(ctx, hipMemcpyAsync(h_status, long_count + 1, 4, hipMemcpyDeviceToHost, st));
   BP_HIP(ctx, hipEventRecord(ctx->ev[3], st));
   BP_HIP(ctx, hipStreamSynchronize(st));
@@ -178,16 +224,18 @@ int msm_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points2
   BP_HIP(ctx, hipEventElapsedTime(&ctx->msm_accumulate_ms, ctx->ev[1], ctx->ev[2]));
   BP_HIP(ctx, hipEventElapsedTime(&ctx->msm_total_ms, ctx->ev[0], ctx->ev[3]));
   ctx->msm_c = plan.c;
+  ctx->msm_tables = table_c != 0;
   ctx->msm_adds = max_entries;      // upper bound: zero digits are skipped (about n*W/2^c of them)
-  // host epilogue: W window sums back to the reference's Montgomery limbs, then Horner (msm.rs:107-115)
-  std::vector<g1_proj> windows(W);
-  for (uint32_t w = 0; w < W; w++) {
+  // host epilogue: window sums / planes back to the reference's Montgomery limbs, then Horner (msm.rs:107-115)
+  std::vector<g1_proj> windows(n_planes);
+  for (uint32_t w = 0; w < n_planes; w++) {
     g1_proj28 p;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&h_windows[w]);
     for (int j = 0; j < N28; j++) { p.x.l[j] = src[j]; p.y.l[j] = src[N28 + j]; p.z.l[j] = src[2 * N28 + j]; }
     windows[w] = g1_proj_from_28(p);
   }
-  host_horner(*host_out, windows.data(), W, plan.c);
+  if (table_c) host_plane_horner(*host_out, windows.data(), Wr, plan.c);
+  else host_horner(*host_out, windows.data(), Wr, plan.c);
   return BP_OK;
 }
 

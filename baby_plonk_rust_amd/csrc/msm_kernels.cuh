@@ -20,8 +20,11 @@
 //                       cover a whole bucket are stored as the bucket sum; runs cut by a chunk edge go
 //                       to a per-lane partial slot.
 //   6. msm_fixup        buckets that straddle chunks: add their partials.
-//   7. msm_reduce       sum_b b * S_b per window by segmented running sums + LDS tree.
-//   host epilogue       Horner over the W window sums (c doublings each) + one affine normalisation.
+//   7. msm_reduce       sum_b b * S_b per window by segmented running sums + LDS tree; with fixed-base tables
+//      msm_planes_*     (one bucket set for all windows) as bit planes T_j = sum of the buckets with bit j set:
+//                       a binary tree in LDS, two additions per bucket, dependent chain of log2(B) additions.
+//   host epilogue       Horner over the W window sums / the bit planes (c doublings per window, msm.rs:107-115)
+//                       + one affine normalisation.
 //
 // Group law: complete RCB formulas (g1.cuh) -- branch-free, so P+P / P+(-P) / identity need no
 // divergent special cases.
@@ -43,6 +46,13 @@ struct MsmPlan {
   uint32_t slices;     // workgroups per window in count/scatter
   uint32_t seg;        // buckets per lane in msm_reduce
   uint32_t bias[9];    // sum_{w < W-1} 2^(c-1) * 2^(c*w)   (the top window is unsigned)
+  // Two bucket layouts share every kernel.  Per-window buckets (any point set): window w owns buckets
+  // [w B, (w+1) B) and an entry is the point index i.  Fixed-base tables (bp_srs_precompute): the SRS carries
+  // T[w][i] = 2^(cw) P_i, every window feeds the SAME B buckets and an entry is the table index w * stride + i,
+  // so the reduction and the Horner epilogue run over one window instead of W.
+  uint32_t total;      // number of buckets: W * B, or B with tables
+  uint32_t wbuckets;   // bucket-index stride per window: B, or 0 with tables
+  uint32_t wpoints;    // point-index stride per window: 0, or the table row length with tables
 };
 
 // ---------------------------------------------------------------- 1. digits
@@ -105,7 +115,7 @@ __global__ void __launch_bounds__(1024) msm_count(const int16_t* __restrict__ di
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
     uint32_t v = msm_lds_hist[b];
-    if (v) atomicAdd(&counts[(size_t)w * B + b], v);
+    if (v) atomicAdd(&counts[(size_t)w * plan.wbuckets + b], v);
   }
 }
 
@@ -202,14 +212,14 @@ __global__ void __launch_bounds__(1024) msm_scatter(const int16_t* __restrict__ 
   // reserve this workgroup's range in every bucket it touches; LDS now holds the range start
   for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) {
     uint32_t v = msm_lds_hist[b];
-    if (v) msm_lds_hist[b] = atomicAdd(&cursors[(size_t)w * B + b], v);
+    if (v) msm_lds_hist[b] = atomicAdd(&cursors[(size_t)w * plan.wbuckets + b], v);
   }
   __syncthreads();
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     int32_t d = dw[i];
     if (d != 0) {
       uint32_t pos = atomicAdd(&msm_lds_hist[digit_bucket(d)], 1u);
-      sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+      sorted[pos] = (i + w * plan.wpoints) | (d < 0 ? 0x80000000u : 0u);
     }
   }
 }
@@ -275,6 +285,25 @@ __global__ void __launch_bounds__(256) srs_to28(const g1_affine* __restrict__ in
   for (int j = 0; j < 7; j++) q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
 
+// Fixed-base window tables: table[w * n + i] = 2^(c w) * P_i for w < W, affine, unsaturated limbs.  One lane per
+// point walks its doubling chain; built once per SRS (bp_srs_precompute), so clarity beats speed here.
+__global__ void __launch_bounds__(256) srs_window_tables(const g1_affine* __restrict__ in, size_t n, uint32_t c, uint32_t W,
+                                                         g1_affine28* __restrict__ table) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g1_proj p = g1_from_affine(load_affine(&in[i]));
+  for (uint32_t w = 1; w < W; w++) {
+    for (uint32_t j = 0; j < c; j++) g1_double(p, p);
+    g1_affine28 r = g1_affine_to_28(g1_to_affine(p));          // identity stays (0, 0)
+    uint4* q = reinterpret_cast<uint4*>(&table[(size_t)w * n + i]);
+    uint32_t wd[28];
+#pragma unroll
+    for (int j = 0; j < N28; j++) { wd[j] = r.x.l[j]; wd[N28 + j] = r.y.l[j]; }
+#pragma unroll
+    for (int j = 0; j < 7; j++) q[j] = make_uint4(wd[4 * j], wd[4 * j + 1], wd[4 * j + 2], wd[4 * j + 3]);
+  }
+}
+
 // largest g in [0, total) with offsets[g] <= p   (offsets is non-decreasing, offsets[0] = 0)
 __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offsets, uint32_t total, uint32_t p) {
   uint32_t lo = 0, hi = total;                 // invariant: offsets[lo] <= p < offsets[hi]
@@ -290,7 +319,7 @@ __global__ void __launch_bounds__(256, WAVES)
 msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restrict__ sorted,
                const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
                proj28_slot* __restrict__ partial) {
-  const uint32_t total = plan.W * plan.B;
+  const uint32_t total = plan.total;
   const uint32_t M = offsets[total];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t p0_64 = (uint64_t)t * plan.chunk;
@@ -341,7 +370,7 @@ __global__ void __launch_bounds__(256, 2)
 msm_fixup(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
           const proj28_slot* __restrict__ partial, uint32_t* __restrict__ long_count, uint32_t* __restrict__ long_list,
           uint32_t long_cap) {
-  const uint32_t total = plan.W * plan.B;
+  const uint32_t total = plan.total;
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   const uint32_t a = offsets[g], b = offsets[g + 1];
@@ -387,9 +416,7 @@ msm_fixup_long(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* 
   }
 }
 
-// ---------------------------------------------------------------- 7. reduce: T_w = sum_b (b+1) * S_{w,b}
-// grid (blocks_per_window, W), 256 lanes; lane handles `seg` consecutive buckets.
-// out[w * gridDim.x + blockIdx.x] = this block's share.
+// LDS tree sum of one value per lane (used by msm_fixup_long)
 __device__ __forceinline__ g1_proj28 block_tree_sum28(g1_proj28 v, uint32_t live) {
   proj28_slot* tree = reinterpret_cast<proj28_slot*>(msm_lds_tree);
   store_proj28(&tree[threadIdx.x], v);
@@ -407,6 +434,10 @@ __device__ __forceinline__ g1_proj28 block_tree_sum28(g1_proj28 v, uint32_t live
   return load_proj28(&tree[0]);
 }
 
+// ---------------------------------------------------------------- 7a. reduce, per-window buckets: T_w = sum_b (b+1) * S_{w,b}
+// Segmented running sums: grid (blocks_per_window, W), 256 lanes; a lane handles `seg` consecutive buckets, then
+// scales its share by its first bucket index and the block tree-sums in LDS.  With W * B buckets there is enough
+// parallel work to hide the ~50-operation chain per lane.  out[w * gridDim.x + blockIdx.x] = this block's share.
 __global__ void __launch_bounds__(256, 2)
 msm_reduce(const uint32_t* __restrict__ offsets, MsmPlan plan, const proj28_slot* __restrict__ bucket_sum,
            proj28_slot* __restrict__ block_out) {
@@ -444,6 +475,78 @@ __global__ void __launch_bounds__(256, 2) msm_window_finish(const proj28_slot* _
   }
   g1_proj28 tot = block_tree_sum28(v, blocks_per_window < blockDim.x ? blocks_per_window : blockDim.x);
   if (threadIdx.x == 0) store_proj28(&window_sum[w], tot);
+}
+
+// ---------------------------------------------------------------- 7b. reduce, fixed-base tables (one bucket set):  sum_b (b + 1) S_b  by bit planes
+//   sum_b (b + 1) S_b = A + sum_j 2^j T_j,    A = sum_b S_b,   T_j = sum of the buckets whose index b has bit j set.
+// A binary tree over the bucket index yields A and every T_j with two additions per bucket and a dependent chain
+// of only log2(B) additions (the running-sum method needs a chain of ~50 additions/doublings per lane, and at one
+// wave per SIMD that chain, not the work, was the cost).  A node covering 2^k buckets carries (A, T_0 .. T_{k-1});
+// merging the siblings (l, r):   A = A_l + A_r,   T_j = T_j,l + T_j,r  (j < k),   T_k = A_r.
+// msm_planes_block runs the first <= 8 levels per 256-bucket block in LDS, msm_planes_window the rest per window;
+// the c values (A, T_0 .. T_{c-2}) of each window go to the host, whose Horner pass over bit positions replaces
+// the scaling by 2^j (msm.rs:107-115 does the same doublings per window).
+//
+// LDS: two ping-pong arrays of 256 slots (a level never holds more: 2^(8-k) nodes x (k + 1) values <= 256).
+constexpr uint32_t PLANES_BLOCK_LOG = 8;
+
+// cur: 2^levels leaves (one slot each).  Returns the buffer holding the root: A at [0], T_j at [1 + j].
+// planes == false: plain tree sum, only slot [0] of the result is meaningful.
+__device__ __forceinline__ proj28_slot* planes_tree(proj28_slot* cur, proj28_slot* nxt, uint32_t levels, bool planes) {
+  for (uint32_t k = 0; k < levels; k++) {
+    const uint32_t merges = 1u << (levels - k - 1);
+    const uint32_t in_per = planes ? k + 1 : 1, out_per = planes ? k + 2 : 1;
+    for (uint32_t item = threadIdx.x; item < merges * out_per; item += blockDim.x) {
+      const uint32_t m = item / out_per, v = item - m * out_per;
+      const proj28_slot* L = cur + (size_t)(2 * m) * in_per;
+      const proj28_slot* R = L + in_per;
+      if (v == k + 1) {
+        nxt[(size_t)m * out_per + v] = R[0];                   // T_k = A_r
+      } else {
+        g1_proj28 a = load_proj28(&L[v]), b = load_proj28(&R[v]);
+        g1_add28(a, a, b);
+        store_proj28(&nxt[(size_t)m * out_per + v], a);
+      }
+    }
+    __syncthreads();
+    proj28_slot* t = cur; cur = nxt; nxt = t;
+  }
+  return cur;
+}
+
+// grid (B >> l1, windows), 2^l1 <= 256 lanes used.  out[(w * gridDim.x + block) * (l1 + 1) + v]
+__global__ void __launch_bounds__(256, 1)
+msm_planes_block(const uint32_t* __restrict__ offsets, MsmPlan plan, const proj28_slot* __restrict__ bucket_sum, uint32_t l1,
+                 proj28_slot* __restrict__ out) {
+  proj28_slot* buf = reinterpret_cast<proj28_slot*>(msm_lds_tree);
+  const uint32_t w = blockIdx.y, nb = 1u << l1;
+  if (threadIdx.x < nb) {
+    const size_t g = (size_t)w * plan.B + ((size_t)blockIdx.x << l1) + threadIdx.x;
+    g1_proj28 s = offsets[g + 1] != offsets[g] ? load_proj28(&bucket_sum[g]) : g1_identity28();   // empty bucket: slot never written
+    store_proj28(&buf[threadIdx.x], s);
+  }
+  __syncthreads();
+  const proj28_slot* root = planes_tree(buf, buf + 256, l1, true);
+  if (threadIdx.x <= l1) out[((size_t)w * gridDim.x + blockIdx.x) * (l1 + 1) + threadIdx.x] = root[threadIdx.x];
+}
+
+// grid (l1 + 1, windows), 128 lanes.  Workgroup v folds value v of the 2^l2 blocks of window w:
+//   v = 0: the block sums A -> window A and the planes l1 .. l1 + l2 - 1 (the block index supplies the high bits);
+//   v > 0: plane v - 1, a plain sum over the blocks.
+// out[w * (l1 + l2 + 1) + {0: A, 1 + j: T_j}]
+__global__ void __launch_bounds__(128, 1)
+msm_planes_window(const proj28_slot* __restrict__ in, uint32_t l1, uint32_t l2, proj28_slot* __restrict__ out) {
+  proj28_slot* buf = reinterpret_cast<proj28_slot*>(msm_lds_tree);
+  const uint32_t v = blockIdx.x, w = blockIdx.y, nblk = 1u << l2, c = l1 + l2 + 1;
+  if (threadIdx.x < nblk) buf[threadIdx.x] = in[((size_t)w * nblk + threadIdx.x) * (l1 + 1) + v];
+  __syncthreads();
+  const proj28_slot* root = planes_tree(buf, buf + 128, l2, v == 0);
+  if (v == 0) {
+    if (threadIdx.x == 0) out[(size_t)w * c] = root[0];
+    else if (threadIdx.x <= l2) out[(size_t)w * c + l1 + threadIdx.x] = root[threadIdx.x];     // T'_{j} -> plane l1 + j
+  } else if (threadIdx.x == 0) {
+    out[(size_t)w * c + v] = root[0];
+  }
 }
 
 }  // namespace bp

@@ -37,14 +37,14 @@ int ntt_init_tables(bp_ctx* ctx) {
 
 // one butterfly per lane per stage: 2^(l-1) * 8 columns lanes, capped at 1024 (a 2^8 x 8 tile owns most of the CU's LDS)
 static unsigned pass_threads(uint32_t l) {
-  unsigned t = (1u << (l - 1)) << NTT_TILE_COLS_LOG;
+  unsigned t = (1u << (l - 1)) << ntt_tile_cols_log(l);
   return t > 1024 ? 1024 : (t < 64 ? 64 : t);
 }
 
 static void make_ntt_plan(NttPlan& plan, uint32_t k) {
   memset(&plan, 0, sizeof plan);
   plan.k = k;
-  plan.P = k <= NTT_SMALL_MAX_LOG ? 1 : (k + NTT_MAX_PASS_LOG - 1) / NTT_MAX_PASS_LOG;
+  plan.P = k <= NTT_SMALL_MAX_LOG ? 1 : (k <= 2 * NTT_MAX_PASS_LOG ? 2 : 3);
   uint32_t rem = k;
   for (uint32_t i = 0; i < plan.P; i++) {          // balanced widths, larger ones first
     uint32_t left = plan.P - i;
@@ -109,20 +109,23 @@ int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, si
     // ping-pong: pass 1 data -> tmp, middle passes in tmp, last pass tmp -> data
     fr_t* tmp;
     BP_TRY(ws_get(ctx, "ntt.tmp", batch * N * sizeof(fr_t), (void**)&tmp));
-    constexpr uint32_t C = 1u << NTT_TILE_COLS_LOG;
+    auto tile_lds = [](uint32_t l) {
+      const uint32_t C = 1u << ntt_tile_cols_log(l), tstride = ((1u << l) * (C + 1) + 1) & ~1u;
+      return ((size_t)tstride + (1u << l)) * N29 * 4 + 16;
+    };
     uint32_t s = k;
     for (uint32_t i = 0; i + 1 < plan.P; i++) {
       const uint32_t l = plan.l[i];
       s -= l;
-      const size_t lds = ((size_t)(1u << l) * (C + 1) + (1u << l)) * N29 * 4 + 16;
+      const size_t lds = tile_lds(l);
       const tw29_t* hi = (inverse && i == 0) ? tab->hi_scaled : tab->hi;   // N^-1 rides on the first twiddle
-      hipLaunchKernelGGL(ntt_pass_strided, dim3((unsigned)(N >> (l + NTT_TILE_COLS_LOG)), (unsigned)batch), dim3(pass_threads(l)), lds, st,
+      hipLaunchKernelGGL(ntt_pass_strided, dim3((unsigned)(N >> (l + ntt_tile_cols_log(l))), (unsigned)batch), dim3(pass_threads(l)), lds, st,
                          i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp, tmp, i == 0 ? stride : N, N, k, l, s, small, tab->lo, hi,
                          tab->h);
     }
     const uint32_t l = plan.l[plan.P - 1];
-    const size_t lds = ((size_t)(1u << l) * (C + 1) + (1u << l)) * N29 * 4 + 16;
-    hipLaunchKernelGGL(ntt_pass_last, dim3((unsigned)(N >> (l + NTT_TILE_COLS_LOG)), (unsigned)batch), dim3(pass_threads(l)), lds, st,
+    const size_t lds = tile_lds(l);
+    hipLaunchKernelGGL(ntt_pass_last, dim3((unsigned)(N >> (l + ntt_tile_cols_log(l))), (unsigned)batch), dim3(pass_threads(l)), lds, st,
                        (const fr_t*)tmp, d_data, N, stride, plan, small);
   }
   BP_HIP(ctx, hipGetLastError());

@@ -5,7 +5,7 @@
 // unique reduced residue, so an O(N log N) factorisation produces bit-identical output.
 //
 // Factorisation (decimation by index digits, "four-step" applied recursively):
-//   N = 2^k, k = l_1 + ... + l_P, each l_i <= 8.  Input index n = (d_1, ..., d_P), d_1 most significant.
+//   N = 2^k, k = l_1 + ... + l_P, each l_i <= 10 (two passes up to 2^20, three up to 2^28).  Input index n = (d_1, ..., d_P), d_1 most significant.
 //   pass i < P : length-2^(l_i) transforms over digit d_i (stride 2^(s_i), s_i = bits below d_i), all
 //                butterflies in LDS, then one multiply by w_{M}^(e_i * r) (M = 2^(l_i+s_i), r = low part)
 //                from a two-level precomputed table; written back in place of d_i.
@@ -13,16 +13,18 @@
 //                position e_1 + 2^(l_1) e_2 + ..., i.e. natural order, written in coalesced runs.
 //   A tile is 2^l x C elements (C = 8 adjacent columns = 256-B global runs) staged in LDS limb-major
 //   (9 x 29-bit limbs per element, fr29.cuh: one v_mad_u64_u32 per partial product, lazy butterflies).
-//   HBM traffic: P reads + P writes of the vector (P = 1 up to 2^10, 2 up to 2^16, 3 up to 2^24).
+//   HBM traffic: P reads + P writes of the vector (P = 1 up to 2^10, 2 up to 2^20, 3 beyond).
 #pragma once
 #include "fr_io.cuh"
 #include "fr29.cuh"
 
 namespace bp {
 
-constexpr int NTT_MAX_PASS_LOG = 8;     // per-pass transform length 2^8
+constexpr int NTT_MAX_PASS_LOG = 10;    // per-pass transform length up to 2^10
 constexpr int NTT_SMALL_MAX_LOG = 10;   // single-workgroup transform up to 2^10
-constexpr int NTT_TILE_COLS_LOG = 3;    // C = 8
+// tile columns C = 2^cl shrink as the per-pass length grows so that a tile (2^l x (C+1) x 36 B) plus its stage twiddles
+// stays inside the 160 KiB of LDS: l <= 8 -> C = 8 (256-B global runs), l = 9 -> C = 4, l = 10 -> C = 2 (64-B runs)
+__host__ __device__ constexpr uint32_t ntt_tile_cols_log(uint32_t l) { return l <= 8 ? 3u : (l == 9 ? 2u : 1u); }
 
 struct NttPlan {
   uint32_t k;            // log2 N
@@ -175,24 +177,24 @@ __global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* 
                                                          uint32_t k, uint32_t l, uint32_t s,
                                                          const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo,
                                                          const tw29_t* __restrict__ tw_hi, uint32_t h) {
-  constexpr uint32_t C = 1u << NTT_TILE_COLS_LOG, CP = C + 1;
-  const uint32_t L = 1u << l, mlog = l + s, tstride = L * CP;
+  const uint32_t cl = ntt_tile_cols_log(l), C = 1u << cl, CP = C + 1;
+  const uint32_t L = 1u << l, mlog = l + s, tstride = (L * CP + 1) & ~1u;      // even: the limb-pair arrays stay 8-byte aligned
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
   const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
-  const uint32_t tiles_per_hi = 1u << (s - NTT_TILE_COLS_LOG);
-  const uint32_t hi = blockIdx.x / tiles_per_hi, r0 = (blockIdx.x % tiles_per_hi) << NTT_TILE_COLS_LOG;
+  const uint32_t tiles_per_hi = 1u << (s - cl);
+  const uint32_t hi = blockIdx.x / tiles_per_hi, r0 = (blockIdx.x % tiles_per_hi) << cl;
   const size_t base = ((size_t)hi << mlog) + r0;
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
-    const uint32_t c = x % C, d = x / C;
+    const uint32_t c = x & (C - 1), d = x >> cl;
     lds_st29(tile, tstride, d * CP + c, fr29_from_sat(load_fr(&src[soff + base + ((size_t)d << s) + c])));
   }
   lds_fill_stage_twiddles(tw, l, small_tw);
   __syncthreads();
-  lds_ntt_dif(tile, tstride, tw, l, NTT_TILE_COLS_LOG, CP);
+  lds_ntt_dif(tile, tstride, tw, l, cl, CP);
   const uint32_t tshift = k - mlog;                 // w_M^x = w_N^(x << tshift)
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
-    const uint32_t c = x % C, e = x / C;
+    const uint32_t c = x & (C - 1), e = x >> cl;
     fr29 v = lds_ld29(tile, tstride, bitrev(e, l) * CP + c);
     const uint64_t E = ((uint64_t)e * (r0 + c)) << tshift;
     v = fr29_mul(v, twiddle_lookup(tw_lo, tw_hi, h, E));     // tw_hi may carry the folded N^-1 (first pass of an inverse)
@@ -206,14 +208,14 @@ __global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* 
 // digit by digit (least significant output digit first).
 __global__ void __launch_bounds__(1024) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
                                                       size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
-  constexpr uint32_t C = 1u << NTT_TILE_COLS_LOG, CP = C + 1;
-  const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l, tstride = L * CP;
+  const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l;
+  const uint32_t cl = ntt_tile_cols_log(l), C = 1u << cl, CP = C + 1, tstride = (L * CP + 1) & ~1u;
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
   const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
   const uint32_t midbits = k - l1 - l;              // bits of (e_2 .. e_{P-1})
   // blockIdx.x enumerates (e1_tile, mid): e_1 = e1_tile * C + c
-  const uint32_t mid = blockIdx.x & ((1u << midbits) - 1u), e1_0 = (blockIdx.x >> midbits) << NTT_TILE_COLS_LOG;
+  const uint32_t mid = blockIdx.x & ((1u << midbits) - 1u), e1_0 = (blockIdx.x >> midbits) << cl;
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t d = x % L, c = x / L;
     const size_t row = ((size_t)(e1_0 + c) << midbits) + mid;
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_last(const fr_t* __restrict__ s
   }
   lds_fill_stage_twiddles(tw, l, small_tw);
   __syncthreads();
-  lds_ntt_dif(tile, tstride, tw, l, NTT_TILE_COLS_LOG, CP);
+  lds_ntt_dif(tile, tstride, tw, l, cl, CP);
   // digit-reverse mid: mid = e_2 * 2^(l_3+..+l_{P-1}) + ... + e_{P-1}; output wants e_2 lowest.
   uint32_t mid_out = 0, shift_out = 0, rem = midbits;
   for (uint32_t i = 1; i + 1 < P; i++) {
@@ -232,7 +234,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_last(const fr_t* __restrict__ s
   }
   const size_t obase = ((size_t)mid_out << l1) + e1_0;
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
-    const uint32_t c = x % C, e = x / C;
+    const uint32_t c = x & (C - 1), e = x >> cl;
     fr29 v = lds_ld29(tile, tstride, bitrev(e, l) * CP + c);
     store_fr(&dst[doff + obase + ((size_t)e << (k - l)) + c], fr29_to_sat_canonical(v));
   }

@@ -180,9 +180,13 @@ struct BucketMSM {
 // src/setup.rs:7-37 (G1 part)
 class Setup {
  public:
-  static Setup generate_srs(size_t powers, const std::array<uint8_t, 32>& tau_le, Context& c = Context::global()) {   // setup.rs:12-31
+  // A Setup serves every commitment of a prover: unless tables == false it also builds the SRS's fixed-base
+  // window tables (bp_srs_precompute), which every later commit() then uses.
+  static Setup generate_srs(size_t powers, const std::array<uint8_t, 32>& tau_le, Context& c = Context::global(),
+                            bool tables = true) {                                                                     // setup.rs:12-31
     uint64_t h = 0;
     c.check(bp_srs_generate(c.raw(), powers, tau_le.data(), &h), "generate_srs");
+    if (tables) c.check(bp_srs_precompute(c.raw(), h, 0), "generate_srs: tables");
     return Setup(h, c);
   }
   std::vector<G1> powers_of_x() const {

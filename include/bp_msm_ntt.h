@@ -71,6 +71,17 @@ int  bp_srs_len(bp_ctx* ctx, uint64_t srs_handle, size_t* n);
 /* Read points [first, first+n) back in the 96-byte encoding (G1Affine::to_uncompressed). */
 int  bp_srs_export(bp_ctx* ctx, uint64_t srs_handle, size_t first, size_t n, uint8_t* points96);
 int  bp_srs_free(bp_ctx* ctx, uint64_t srs_handle);
+/* Fixed-base window tables for an SRS that serves many commitments (Setup lives as long as the prover,
+ * src/setup.rs:7-10): T[w][i] = 2^(window_bits * w) * P_i for every window w, affine, resident in HBM
+ * (windows x srs_len x 112 bytes: 1.9 GB at 2^20 points, 30 GB at 2^24).  With tables every window of an
+ * MSM feeds one shared bucket set, so the bucket reduction and the Horner epilogue shrink from `windows`
+ * passes to one; results are the same group element.  window_bits: 0 = chosen from srs_len,
+ * BP_SRS_TABLES_OFF = drop the tables, else 4..16.  MSMs shorter than 2^window_bits / 8 scalars keep
+ * using the table-free path.  The reference has no counterpart (its MSM recomputes from the raw points). */
+#define BP_SRS_TABLES_OFF 1u
+int  bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits);
+/* window_bits / windows / bytes of the tables of an SRS (all 0 without tables). */
+int  bp_srs_table_info(bp_ctx* ctx, uint64_t srs_handle, uint32_t* window_bits, uint32_t* windows, uint64_t* bytes);
 
 /* ---- MSM: BucketMSM::bucket_msm(points, scalars, b, c) (src/msm.rs:76-118) ----------------------- */
 /* sum_{i < min(n_scalars, srs_len - first)} s_i * P_{first+i}   (zip truncation of msm.rs:29).
@@ -91,6 +102,8 @@ int  bp_g1_bytes96_to_partial(const uint8_t in96[96], uint8_t out144[144]);
 /* HIP-event duration of the bucket-accumulation kernel of the last MSM on this ctx, and its adds. */
 int  bp_msm_last_stats(bp_ctx* ctx, float* accumulate_ms, float* total_device_ms, uint64_t* mixed_adds,
                        uint32_t* window_bits);
+/* 1 when the last MSM on this ctx went through fixed-base tables, 0 when not, negative on error. */
+int  bp_msm_last_used_tables(bp_ctx* ctx);
 
 /* ---- DFT: ntt_381 / i_ntt_381 (src/utils.rs:63-81, 106-129) --------------------------------------- */
 /* In-place natural-order transform of length 2^log_n on `batch` vectors, vector b at data + b*stride

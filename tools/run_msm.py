@@ -14,18 +14,23 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--log-n", type=int, default=20)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--ntt-log-n", type=int, default=0)
+ap.add_argument("--tables", type=int, default=-1, help="fixed-base table window bits (0 = auto, -1 = no tables)")
 args = ap.parse_args()
 ctx = bp.Context(0)
 n = 1 << args.log_n
 srs = ctx.srs_generate_progression(n, 12345, 67891)
+if args.tables >= 0:
+    t0 = time.perf_counter()
+    info = ctx.srs_precompute(srs, args.tables)
+    print("tables: %.1f ms, %s" % (1e3 * (time.perf_counter() - t0), info), flush=True)
 sc = torch.empty(n * 4, dtype=torch.int64, device="cuda")
 ctx.synthetic_scalars_device(sc.data_ptr(), n, 0x5EED)
 for i in range(args.reps):
     t0 = time.perf_counter()
     ctx.msm_partial(srs, None, device_ptr=sc.data_ptr(), n=n)
     st = ctx.msm_stats()
-    print("msm 2^%d: wall %.3f ms, device %.3f ms, accumulate %.3f ms, c=%d" % (
-        args.log_n, 1e3 * (time.perf_counter() - t0), st["device_ms"], st["accumulate_ms"], st["window_bits"]), flush=True)
+    print("msm 2^%d: wall %.3f ms, device %.3f ms, accumulate %.3f ms, c=%d tables=%s" % (
+        args.log_n, 1e3 * (time.perf_counter() - t0), st["device_ms"], st["accumulate_ms"], st["window_bits"], st["tables"]), flush=True)
 if args.ntt_log_n:
     nn = 1 << args.ntt_log_n
     v = torch.empty(nn * 4, dtype=torch.int64, device="cuda")
