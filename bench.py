@@ -11,6 +11,10 @@ The Fr NTT (independent columns, one 2^ntt_log_n vector per rank, no collective)
 second region and reported in the "ntt" object of the same JSON line.
 
 Workload at N = 1: BASELINE.json configs[2], the 2^20-point MSM the metric is quoted on (+ a 2^20 NTT).
+The SRS is what Setup holds for the life of a prover (src/setup.rs:7-10): resident in HBM together with its
+fixed-base window tables, built once by bp_srs_precompute before the timed region (build time and size are
+reported).  The same MSM without tables (raw points only, the uncached bucket_msm seam) is timed beside it
+in "msm_without_tables"; --no-tables makes that the headline instead.
 Inputs: points P_i = (a + i d) G generated on the GPU, scalars = SplitMix64 ->
 from_bytes_wide generated on the GPU; nothing is read from disk.  The CPU oracle is used for the
 `cpu_baseline` leg only (rank 0, N = 1, bounded sample).
@@ -89,6 +93,7 @@ def main():
     ap.add_argument("--ntt-log-n", type=int, default=20, help="NTT length per GPU = 2^ntt_log_n")
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--no-tables", action="store_true", help="headline = MSM on the raw SRS, no fixed-base window tables")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the N > 1 control flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -127,19 +132,36 @@ def main():
         # and the N-1 complete additions on every rank (baby_plonk_rust_amd/dist.py)
         return bpd.msm_sharded(ctx, srs, None, device_ptr=scal.data_ptr(), n=n)
 
-    for _ in range(args.warmup):
-        result = msm_step()
-    barrier()
-    acc_ms, dev_ms = [], []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = msm_step()
-        st = ctx.msm_stats()
-        acc_ms.append(st["accumulate_ms"])
-        dev_ms.append(st["device_ms"])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    stats = ctx.msm_stats()
+    def timed_msm():
+        for _ in range(args.warmup):
+            res = msm_step()
+        barrier()
+        acc, devt = [], []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = msm_step()
+            st = ctx.msm_stats()
+            acc.append(st["accumulate_ms"])
+            devt.append(st["device_ms"])
+        barrier()
+        return res, time.perf_counter() - t0, acc, devt, ctx.msm_stats()
+
+    # secondary leg first: the other table setting, same inputs
+    table_info, table_build_s = {"window_bits": 0, "windows": 0, "bytes": 0}, 0.0
+    if args.no_tables:
+        t0 = time.perf_counter()
+        table_info = ctx.srs_precompute(srs, 0)
+        table_build_s = time.perf_counter() - t0
+        other = timed_msm()
+        ctx.srs_precompute(srs, bp.SRS_TABLES_OFF)
+    else:
+        other = timed_msm()
+        t0 = time.perf_counter()
+        table_info = ctx.srs_precompute(srs, 0)
+        table_build_s = time.perf_counter() - t0
+    result, elapsed, acc_ms, dev_ms, stats = timed_msm()
+    assert other[0] == result, "MSM with and without fixed-base tables disagree"
+    assert stats["tables"] == (not args.no_tables)
 
     # ---- NTT leg (independent columns, no collective) ----
     nn = 1 << args.ntt_log_n
@@ -157,10 +179,11 @@ def main():
     ntt_elapsed = time.perf_counter() - t1
     ntt_passes = ctx.ntt_stats()["passes"]
 
+    other_elapsed = other[1]
     if world > 1:
-        t = torch.tensor([elapsed, ntt_elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed, ntt_elapsed, other_elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, ntt_elapsed = float(t[0]), float(t[1])
+        elapsed, ntt_elapsed, other_elapsed = float(t[0]), float(t[1]), float(t[2])
 
     if rank == 0:
         units = world * n * args.steps
@@ -176,16 +199,24 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 limbs (381-bit Fp Montgomery, 255-bit Fr)", "data": "synthetic",
             "config": {"workload": "2^%d-point BLS12-381 G1 MSM per GPU (global 2^%d x %d points, point-range shards, "
-                                   "RCCL all-gather of 144-B partials) + 2^%d Fr NTT per GPU; BASELINE configs[2] at N=1"
-                                   % (args.log_n, args.log_n, world, args.ntt_log_n),
+                                   "RCCL all-gather of 144-B partials), SRS %s; + 2^%d Fr NTT per GPU; BASELINE configs[2] at N=1"
+                                   % (args.log_n, args.log_n, world,
+                                      "raw points only" if args.no_tables else "resident with its fixed-base window tables (Setup)",
+                                      args.ntt_log_n),
                        "msm_points_per_gpu": n, "window_bits": stats["window_bits"], "ntt_len_per_gpu": nn,
+                       "srs_tables": {"used": stats["tables"], "window_bits": table_info["window_bits"], "windows": table_info["windows"],
+                                      "bytes_per_gpu": table_info["bytes"], "build_s": table_build_s},
                        "parallelism": "point-range x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("msm_accumulate_2p20_c16") if (args.log_n == 20 and stats["window_bits"] == 16) else None,
+                         "traffic": measured_traffic("msm_accumulate_2p20_c16" + ("" if args.no_tables else "_tables"))
+                         if (args.log_n == 20 and stats["window_bits"] == 16) else None,
                          "kernel_ms": acc * 1e3, "algorithmic_bytes_per_launch": MSM_BYTES_PER_UNIT * n,
                          "note": "integer-ALU bound by design (11 Fp mul per bucket add); see DESIGN.md"},
             "msm_device_ms": float(np.mean(dev_ms)),
+            ("msm_with_tables" if args.no_tables else "msm_without_tables"): {
+                "value": units / other_elapsed, "unit": "scalar-muls/s", "ms_per_step": 1e3 * other_elapsed / args.steps,
+                "device_ms": float(np.mean(other[3])), "accumulate_ms": float(np.mean(other[2])), "window_bits": other[4]["window_bits"]},
             "ntt": {"metric": "fr_ntt_elements_per_s", "value": world * nn * args.steps / ntt_elapsed, "unit": "elements/s",
                     "ms_per_step": 1e3 * ntt_elapsed / args.steps, "passes": ntt_passes,
                     "roofline": {"bound": "hbm", "kernel": "ntt_pass_* (all passes of one transform)", "achieved": ntt_achieved,
