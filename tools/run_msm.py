@@ -31,6 +31,13 @@ for i in range(args.reps):
     st = ctx.msm_stats()
     print("msm 2^%d: wall %.3f ms, device %.3f ms, accumulate %.3f ms, c=%d tables=%s" % (
         args.log_n, 1e3 * (time.perf_counter() - t0), st["device_ms"], st["accumulate_ms"], st["window_bits"], st["tables"]), flush=True)
+# PCIe-inclusive: the caller hands pageable host scalars (bp_msm_g1 through the reference-shaped seam)
+host = sc.cpu().numpy().view("uint64").reshape(n, 4)
+for i in range(args.reps):
+    t0 = time.perf_counter()
+    ctx.msm_partial(srs, host)
+    print("msm 2^%d from host scalars: wall %.3f ms (device part %.3f ms)" % (
+        args.log_n, 1e3 * (time.perf_counter() - t0), ctx.msm_stats()["device_ms"]), flush=True)
 if args.ntt_log_n:
     nn = 1 << args.ntt_log_n
     v = torch.empty(nn * 4, dtype=torch.int64, device="cuda")
