@@ -42,6 +42,11 @@ SIGNATURES = {
     "bp_srs_precompute": (_int, [_vp, _u64, _u32]),
     "bp_srs_table_info": (_int, [_vp, _u64, _pp(_u32), _pp(_u32), _pp(_u64)]),
     "bp_msm_last_used_tables": (_int, [_vp]),
+    "bp_circuit_load": (_int, [_vp, _u32, _vp, _int, _int, _pp(_u64)]),
+    "bp_circuit_free": (_int, [_vp, _u64]),
+    "bp_prove": (_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp]),
+    "bp_prove_last_stats": (_int, [_vp, _vp, _pp(C.c_float)]),
+    "bp_transcript_test_vector": (_int, [_vp]),
     "bp_msm_g1": (_int, [_vp, _u64, _vp, _sz, _int, _vp]),
     "bp_msm_g1_partial": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),
     "bp_g1_sum_partials": (_int, [_vp, _sz, _vp]),

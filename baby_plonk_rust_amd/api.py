@@ -520,3 +520,75 @@ class Setup:
         c.check(c._lib.bp_commit(c._h, self.handle, polynomial.values.ctypes.data, len(polynomial), polynomial.basis, FR_MONT,
                                  out.ctypes.data), "Setup.commit")
         return bytes(out)
+
+
+CIRCUIT_COLUMNS = ("ql", "qr", "qm", "qo", "qc", "s1", "s2", "s3")
+
+
+class Circuit:
+    """CommonPreprocessedInput (src/program.rs:34-50) resident in HBM: the eight Lagrange columns QL QR QM QO QC S1 S2 S3
+    of a 2^log_n-row circuit, uploaded once (bp_circuit_load)"""
+
+    def __init__(self, columns, ctx=None):
+        self.ctx = ctx or default_context()
+        cols = [_fr_array(columns[k]) for k in CIRCUIT_COLUMNS] if isinstance(columns, dict) else [_fr_array(c) for c in columns]
+        n = len(cols[0])
+        if len(cols) != 8 or any(len(c) != n for c in cols) or n < 8 or n & (n - 1):
+            raise BpError(-2, "Circuit", "eight columns of equal power-of-two length >= 8 expected")
+        self.group_order = n
+        ptrs = (C.c_void_p * 8)(*[c.ctypes.data for c in cols])
+        h = C.c_uint64()
+        self.ctx.check(self.ctx._lib.bp_circuit_load(self.ctx._h, n.bit_length() - 1, ptrs, FR_MONT, 0, C.byref(h)), "bp_circuit_load")
+        self.handle = h.value
+
+    def free(self):
+        self.ctx.check(self.ctx._lib.bp_circuit_free(self.ctx._h, self.handle), "bp_circuit_free")
+
+
+class Prover:
+    """src/prover.rs:50-175 behind bp_prove: rounds 1-5 on the GPU, Fiat-Shamir transcript on the host"""
+
+    def __init__(self, setup, circuit):
+        assert setup.ctx is circuit.ctx
+        self.setup, self.circuit, self.ctx = setup, circuit, setup.ctx
+
+    def prove_with_blinding(self, a, b, c, public_input, blinders):
+        """a, b, c: the three Lagrange wire columns (prover.rs:186-227); public_input: the Lagrange column of prover.rs:114-127
+        or None; blinders: 11 ints b1..b11 (the reference draws them from thread_rng, prover.rs:108-110).  Returns the 624-byte
+        proof: 9 compressed G1 points in Proof field order (verifier.rs:23-40) then the 6 evaluations, 32 bytes LE each."""
+        n = self.circuit.group_order
+        cols = [_fr_array(v) for v in (a, b, c)]
+        pi = None if public_input is None else _fr_array(public_input)
+        if any(len(v) != n for v in cols) or (pi is not None and len(pi) != n):
+            raise BpError(-6, "prove", "witness columns must have group_order entries")
+        bl = np.frombuffer(b"".join((int(v) % Q).to_bytes(32, "little") for v in blinders), dtype=np.uint8).copy()
+        if len(bl) != 352:
+            raise BpError(-2, "prove", "11 blinders expected")
+        out = np.zeros(624, dtype=np.uint8)
+        c_ = self.ctx
+        c_.check(c_._lib.bp_prove(c_._h, self.setup.handle, self.circuit.handle, cols[0].ctypes.data, cols[1].ctypes.data, cols[2].ctypes.data,
+                                  None if pi is None else pi.ctypes.data, FR_MONT, 0, bl.ctypes.data, out.ctypes.data), "bp_prove")
+        return bytes(out)
+
+    def prove_device(self, a_ptr, b_ptr, c_ptr, pi_ptr, blinders):
+        """same with the witness columns already in HBM (Montgomery limbs)"""
+        bl = np.frombuffer(b"".join((int(v) % Q).to_bytes(32, "little") for v in blinders), dtype=np.uint8).copy()
+        out = np.zeros(624, dtype=np.uint8)
+        c_ = self.ctx
+        c_.check(c_._lib.bp_prove(c_._h, self.setup.handle, self.circuit.handle, a_ptr, b_ptr, c_ptr, pi_ptr, FR_MONT, 1, bl.ctypes.data,
+                                  out.ctypes.data), "bp_prove")
+        return bytes(out)
+
+    def last_stats(self):
+        r, t = (C.c_float * 5)(), C.c_float()
+        self.ctx.check(self.ctx._lib.bp_prove_last_stats(self.ctx._h, r, C.byref(t)), "bp_prove_last_stats")
+        return {"round_ms": list(r), "total_ms": t.value}
+
+
+def transcript_test_vector():
+    """merlin's conformance vector through the library's host transcript (no GPU needed)"""
+    out = np.zeros(32, dtype=np.uint8)
+    rc = _lib.load().bp_transcript_test_vector(out.ctypes.data)
+    if rc:
+        raise BpError(rc, "bp_transcript_test_vector", "")
+    return bytes(out)

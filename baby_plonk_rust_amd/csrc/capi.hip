@@ -830,3 +830,80 @@ int bp_commit(bp_ctx* ctx, uint64_t srs_handle, const void* coeffs, size_t n, in
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- prover
+int bp_circuit_load(bp_ctx* ctx, uint32_t log_n, const void* const columns[8], int scalar_fmt, int columns_on_device, uint64_t* handle) {
+  if (!ctx || !columns || !handle || !fmt_ok(scalar_fmt)) return BP_ERR_INVALID_ARG;
+  if (log_n < 3 || log_n > 24) return fail(ctx, BP_ERR_INVALID_ARG, "circuit: log_n must be in 3..24", hipSuccess, __FILE__, __LINE__);
+  if (columns_on_device && scalar_fmt != BP_FR_MONT) return fail(ctx, BP_ERR_INVALID_ARG, "device columns must be Montgomery", hipSuccess, __FILE__, __LINE__);
+  for (int k = 0; k < 8; k++)
+    if (!columns[k]) return BP_ERR_INVALID_ARG;
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)1 << log_n;
+  fr_t* lag = nullptr;
+  BP_HIP(ctx, hipMalloc((void**)&lag, 8 * n * sizeof(fr_t)));
+  for (int k = 0; k < 8; k++) {
+    hipError_t e = hipMemcpyAsync(lag + (size_t)k * n, columns[k], n * sizeof(fr_t), columns_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                  ctx->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(lag);
+      return fail(ctx, BP_ERR_HIP, "circuit upload", e, __FILE__, __LINE__);
+    }
+  }
+  int rc = BP_OK;
+  if (scalar_fmt == BP_FR_BYTES_LE) rc = fr_convert_run(ctx, lag, 8 * n, 0);
+  CircuitEntry e;
+  if (rc == BP_OK) rc = circuit_build(ctx, log_n, lag, &e);
+  if (rc != BP_OK) {
+    (void)hipFree(lag);
+    return rc;
+  }
+  *handle = ctx->next_handle++;
+  ctx->circuits[*handle] = e;
+  return BP_OK;
+}
+int bp_circuit_free(bp_ctx* ctx, uint64_t handle) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  auto it = ctx->circuits.find(handle);
+  if (it == ctx->circuits.end()) return fail(ctx, BP_ERR_INVALID_ARG, "unknown circuit handle", hipSuccess, __FILE__, __LINE__);
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  circuit_release(it->second);
+  ctx->circuits.erase(it);
+  return BP_OK;
+}
+int bp_prove(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_handle, const void* a, const void* b, const void* c, const void* public_input,
+             int scalar_fmt, int witness_on_device, const uint8_t blinders[352], uint8_t proof[624]) {
+  if (!ctx || !a || !b || !c || !blinders || !proof || !fmt_ok(scalar_fmt)) return BP_ERR_INVALID_ARG;
+  if (witness_on_device && scalar_fmt != BP_FR_MONT) return fail(ctx, BP_ERR_INVALID_ARG, "device witness must be Montgomery", hipSuccess, __FILE__, __LINE__);
+  auto it = ctx->circuits.find(circuit_handle);
+  if (it == ctx->circuits.end()) return fail(ctx, BP_ERR_INVALID_ARG, "unknown circuit handle", hipSuccess, __FILE__, __LINE__);
+  SrsEntry* srs;
+  BP_TRY(srs_find(ctx, srs_handle, &srs));
+  const size_t n = (size_t)1 << it->second.log_n;
+  if (srs->n < n + 6) return fail(ctx, BP_ERR_LENGTH, "SRS shorter than group_order + 6 powers", hipSuccess, __FILE__, __LINE__);
+  fr_t blind[11];
+  for (int j = 0; j < 11; j++)
+    if (!fr_bytes_to_mont(blind[j], blinders + 32 * j, BP_FR_BYTES_LE)) return fail(ctx, BP_ERR_BAD_SCALAR, "blinder >= q", hipSuccess, __FILE__, __LINE__);
+  BP_HIP(ctx, hipSetDevice(ctx->device));
+  fr_t* wit;
+  BP_TRY(ws_get(ctx, "prove.witness", 4 * n * sizeof(fr_t), (void**)&wit));
+  const void* cols[4] = {a, b, c, public_input};
+  const hipMemcpyKind kind = witness_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  for (int k = 0; k < 4; k++) {
+    if (cols[k]) BP_HIP(ctx, hipMemcpyAsync(wit + (size_t)k * n, cols[k], n * sizeof(fr_t), kind, ctx->stream));
+    else BP_HIP(ctx, hipMemsetAsync(wit + (size_t)k * n, 0, n * sizeof(fr_t), ctx->stream));
+  }
+  if (scalar_fmt == BP_FR_BYTES_LE) BP_TRY(fr_convert_run(ctx, wit, 4 * n, 0));
+  return prove_run(ctx, srs_handle, it->second, wit, blind, proof);
+}
+int bp_prove_last_stats(bp_ctx* ctx, float round_ms[5], float* total_ms) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  if (round_ms) memcpy(round_ms, ctx->prove_ms, 5 * sizeof(float));
+  if (total_ms) *total_ms = ctx->prove_ms[5];
+  return BP_OK;
+}
+int bp_transcript_test_vector(uint8_t out32[32]) {
+  if (!out32) return BP_ERR_INVALID_ARG;
+  transcript_test_vector(out32);
+  return BP_OK;
+}

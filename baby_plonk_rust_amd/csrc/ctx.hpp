@@ -26,6 +26,19 @@ struct SrsEntry {
   size_t n = 0;
 };
 
+// preprocessed circuit of the native prover (prover.hip): CommonPreprocessedInput (program.rs:34-50) resident in HBM,
+// with the derived forms the reference recomputes in every proof.  Column order: ql qr qm qo qc s1 s2 s3.
+struct CircuitEntry {
+  uint32_t log_n = 0;
+  fr_t* lag = nullptr;        // 8 x n Lagrange columns as loaded
+  fr_t* coef = nullptr;       // 8 x n coefficient forms (i_ntt, prover.rs:379-386)
+  fr_t* coset = nullptr;      // 9 x 4n evaluations on the quotient coset g <w_4n> (the eight columns + L1)
+  fr_t* coset_x = nullptr;    // 4n coset points g w_4n^i
+  fr_t* g_pow = nullptr;      // g^i, i < n + 8
+  fr_t* ginv_pow = nullptr;   // g^-i, i < 4n
+  fr_t zh_inv[4];             // 1 / (X^n - 1) on the coset (period 4)
+};
+
 struct tw29_t;
 struct NttTables {       // per (log_n, inverse); entries are 48-byte 29-bit-limb twiddle records (fr29.cuh)
   tw29_t* lo = nullptr;        // w_N^j, j < 2^h
@@ -45,6 +58,7 @@ struct bp_ctx {
   std::string last_error;
   std::map<std::string, bp::DevBuf> ws;            // grow-only named device workspaces
   std::map<uint64_t, bp::SrsEntry> srs;
+  std::map<uint64_t, bp::CircuitEntry> circuits;
   uint64_t next_handle = 1;
   bp::tw29_t* small_tw[2] = {nullptr, nullptr};    // w_1024^j, j < 512: forward / inverse
   std::map<uint32_t, bp::NttTables> ntt_tables;    // key = log_n * 2 + inverse
@@ -54,6 +68,7 @@ struct bp_ctx {
   uint64_t msm_adds = 0;
   uint32_t msm_c = 0;
   bool msm_tables = false;
+  float prove_ms[6] = {0, 0, 0, 0, 0, 0};            // host wall clock of rounds 1..5 and of the whole bp_prove
   float ntt_ms = 0;
   uint32_t ntt_passes = 0;
   void* pinned = nullptr;                          // small pinned staging buffer (window sums etc.)
@@ -103,6 +118,11 @@ int roots_run(bp_ctx* ctx, const fr_t& w, size_t n, fr_t* d_out);
 int srs_decode_run(bp_ctx* ctx, const uint8_t* d_bytes, size_t n, g1_affine* d_out);
 int srs_encode_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, uint8_t* d_bytes);
 int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t n, g1_affine* d_out);
+
+int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out);
+void circuit_release(CircuitEntry& e);
+int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_wit, const fr_t blind[11], uint8_t proof[624]);
+void transcript_test_vector(uint8_t out32[32]);
 
 // ---- host-side helpers (host.cpp part of capi.hip) ---------------------------------------------------
 void host_horner(g1_proj& out, const g1_proj* window_sums, uint32_t W, uint32_t c);

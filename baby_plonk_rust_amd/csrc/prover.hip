@@ -1,0 +1,388 @@
+// prover.hip -- Prover::prove (src/prover.rs:64-175; rounds 1-5 :177-647) on the GPU behind the C ABI, with the eleven
+// blinding scalars as an input (the reference draws them from thread_rng, :108-110, so its proofs are not reproducible)
+// and the Fiat-Shamir challenges from the host transcript (transcript.hpp, src/transcript.rs:4-86).
+//
+// The reference builds every round out of value-semantics `Polynomial` operators (each product = three O(n^2) DFTs,
+// each division a long division).  Every committed or evaluated polynomial is uniquely determined by the witness, the
+// circuit, the blinders and the challenges, so this file computes the same polynomials by the cheapest exact route:
+//   round 1/2  b(x) (x^n - 1) + iNTT(values) written directly (fr_blind); grand product by scans (poly_kernels.cuh);
+//   round 3    the quotient t = (gate + alpha perm + alpha^2 first_row) / (x^n - 1) point-wise on the coset g <w_4n>
+//              (5 coset NTTs of the witness polynomials + 1 inverse; the circuit's 9 coset columns are cached);
+//   round 5    the opening numerator as one fused linear combination, division by x - zeta as a scan (poly.hip).
+// The reference's Div squeezes zero quotient coefficients out (polynomial.rs:371-376); the same compaction is applied
+// wherever a quotient has one (probability ~ deg / q with random blinders).
+// Parity: tests/test_native_prover.py -- proof bytes equal the reference-shaped restatement (tests/prover_rounds.py) run
+// on the CPU oracle, and the committed golden proof of the toy circuit (tests/verify_proof_test.rs).
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <vector>
+
+#include "ctx.hpp"
+#include "prover_kernels.cuh"
+#include "transcript.hpp"
+
+namespace bp {
+namespace {
+
+// ------------------------------------------------------------------------------------------------ host field helpers
+fr_t fmul(const fr_t& a, const fr_t& b) { fr_t r; Fr::mul(r, a, b); return r; }
+fr_t fadd(const fr_t& a, const fr_t& b) { fr_t r; Fr::add(r, a, b); return r; }
+fr_t fsub(const fr_t& a, const fr_t& b) { fr_t r; Fr::sub(r, a, b); return r; }
+fr_t fneg(const fr_t& a) { fr_t r; Fr::neg(r, a); return r; }
+fr_t finv(const fr_t& a) { fr_t r; fr_invert(r, a); return r; }
+fr_t fpow(const fr_t& a, uint64_t e) {
+  uint32_t e32[2] = {(uint32_t)e, (uint32_t)(e >> 32)};
+  fr_t r;
+  Fr::pow(r, a, e32, 2);
+  return r;
+}
+fr_t from_u64(uint64_t v) {
+  fr_t c = Fr::zero(), r;
+  c.l[0] = (uint32_t)v;
+  c.l[1] = (uint32_t)(v >> 32);
+  Fr::to_mont(r, c);
+  return r;
+}
+bool from_le32(fr_t& out, const uint8_t* b32) {             // Scalar::from_bytes (scalar.rs:264-288)
+  fr_t v, t;
+  memcpy(&v, b32, 32);
+  if (!big_sub(t, v, Fr::modulus())) return false;
+  Fr::to_mont(out, v);
+  return true;
+}
+void to_le32(uint8_t* b32, const fr_t& v) {                  // Scalar::to_bytes (scalar.rs:292-304)
+  fr_t t;
+  Fr::from_mont(t, v);
+  memcpy(b32, &t, 32);
+}
+fr_t root_of_unity(uint64_t order) {                         // utils.rs:39-43
+  return fpow(fr_root_of_unity(false), ((uint64_t)1 << 32) / order);
+}
+
+// G1Affine::to_compressed (g1.rs:221-244): big-endian x, bit 7 compressed, bit 6 infinity, bit 5 y lexicographically largest
+void compress48(uint8_t out[48], const g1_proj& p) {
+  memset(out, 0, 48);
+  if (g1_is_identity(p)) {
+    out[0] = 0xc0;
+    return;
+  }
+  g1_affine a = g1_to_affine(p);
+  fp_t x, y, ny;
+  Fp::from_mont(x, a.x);
+  Fp::from_mont(y, a.y);
+  Fp::neg(ny, a.y);
+  Fp::from_mont(ny, ny);
+  for (int i = 0; i < 12; i++) {
+    uint8_t* q = out + 4 * (11 - i);
+    q[0] = (uint8_t)(x.l[i] >> 24); q[1] = (uint8_t)(x.l[i] >> 16); q[2] = (uint8_t)(x.l[i] >> 8); q[3] = (uint8_t)x.l[i];
+  }
+  bool larger = false;                                       // y > -y  (fp.rs:273-298)
+  for (int i = 11; i >= 0; i--) {
+    if (y.l[i] != ny.l[i]) {
+      larger = y.l[i] > ny.l[i];
+      break;
+    }
+  }
+  out[0] |= 0x80 | (larger ? 0x20 : 0);
+}
+
+// src/transcript.rs:4-86 (alpha is drawn under the label "z_1", :24; challenges are rejection-sampled until canonical
+// and non-zero and then re-absorbed, :70-82)
+struct PlonkTranscript {
+  MerlinTranscript t{"plonk"};                               // prover.rs:112
+  void point(const char* label, const g1_proj& p) {
+    uint8_t c[48];
+    compress48(c, p);
+    t.append_message(label, c, 48);
+  }
+  void scalar(const char* label, const fr_t& v) {
+    uint8_t b[32];
+    to_le32(b, v);
+    t.append_message(label, b, 32);
+  }
+  fr_t challenge(const char* label) {
+    for (;;) {
+      uint8_t b[32];
+      t.challenge_bytes(label, b, 32);
+      fr_t v;
+      if (from_le32(v, b) && !big_is_zero(v)) {
+        t.append_message(label, b, 32);
+        return v;
+      }
+    }
+  }
+};
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int commit(bp_ctx* ctx, uint64_t srs, const fr_t* d_coeffs, size_t n, g1_proj* out) {       // setup.rs:32-37
+  uint8_t part[144];
+  BP_TRY(bp_msm_g1_partial(ctx, srs, 0, d_coeffs, n, BP_FR_MONT, 1, part));
+  memcpy(out, part, 144);
+  return BP_OK;
+}
+
+// the reference's Div drops zero quotient coefficients (polynomial.rs:371-376): compact d_q[0..n) in place
+int squeeze_zeros(bp_ctx* ctx, fr_t* d_q, size_t* n) {
+  size_t eff, nonzero;
+  BP_TRY(fr_nonzero_stats_run(ctx, d_q, *n, 0, *n, &eff, &nonzero));
+  if (nonzero == *n) return BP_OK;
+  std::vector<fr_t> h(*n);
+  BP_HIP(ctx, hipMemcpyAsync(h.data(), d_q, *n * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  size_t m = 0;
+  for (size_t i = 0; i < *n; i++)
+    if (!big_is_zero(h[i])) h[m++] = h[i];
+  if (m) BP_HIP(ctx, hipMemcpy(d_q, h.data(), m * sizeof(fr_t), hipMemcpyHostToDevice));
+  *n = m;
+  return BP_OK;
+}
+
+// (numerator of na coefficients) / (x - point) -> d_q, *nq coefficients, by the reference's Div semantics
+int divide_by_linear(bp_ctx* ctx, fr_t* d_num, size_t na, const fr_t& point, fr_t* d_q, size_t* nq) {
+  size_t na_eff, dummy;
+  BP_TRY(fr_nonzero_stats_run(ctx, d_num, na, 0, 0, &na_eff, &dummy));               // trailing zeros trimmed (polynomial.rs:325-339)
+  *nq = 0;
+  if (na_eff < 2) return BP_OK;
+  fr_t* d_b;
+  BP_TRY(ws_get(ctx, "prove.divisor", 2 * sizeof(fr_t), (void**)&d_b));
+  const fr_t hb[2] = {fneg(point), Fr::one()};
+  BP_HIP(ctx, hipMemcpyAsync(d_b, hb, sizeof hb, hipMemcpyHostToDevice, ctx->stream));
+  *nq = na_eff - 1;
+  BP_TRY(poly_div_run(ctx, d_num, na_eff, d_b, 2, hb[0], hb[1], true, d_q, *nq));
+  return squeeze_zeros(ctx, d_q, nq);
+}
+
+constexpr uint64_t COSET_GEN = 7;        // generator of Fr^* (scalar.rs GENERATOR): g^n w^j != 1 for every n-th-root coset used here
+constexpr int N_PRE = 9;                 // ql qr qm qo qc s1 s2 s3 (+ L1 on the coset)
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ circuit
+int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out) {
+  const size_t n = (size_t)1 << log_n, N = 4 * n;
+  CircuitEntry e;
+  e.log_n = log_n;
+  e.lag = d_lag;
+  BP_HIP(ctx, hipMalloc((void**)&e.coef, 8 * n * sizeof(fr_t)));
+  BP_HIP(ctx, hipMalloc((void**)&e.coset, (size_t)N_PRE * N * sizeof(fr_t)));
+  BP_HIP(ctx, hipMalloc((void**)&e.coset_x, N * sizeof(fr_t)));
+  BP_HIP(ctx, hipMalloc((void**)&e.g_pow, (n + 8) * sizeof(fr_t)));
+  BP_HIP(ctx, hipMalloc((void**)&e.ginv_pow, N * sizeof(fr_t)));
+  const fr_t g = from_u64(COSET_GEN), w4n = root_of_unity(N);
+  BP_TRY(roots_run(ctx, g, n + 8, e.g_pow));
+  BP_TRY(roots_run(ctx, finv(g), N, e.ginv_pow));
+  BP_TRY(roots_run(ctx, w4n, N, e.coset_x));                                             // w_4n^i ...
+  BP_TRY(fr_scalar_run(ctx, e.coset_x, g, e.coset_x, N, 2));                            // ... times g
+  // coefficient forms (prover.rs:379-386 recomputes these i_ntt's in every proof)
+  BP_HIP(ctx, hipMemcpyAsync(e.coef, e.lag, 8 * n * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
+  BP_TRY(ntt_run(ctx, e.coef, log_n, 1, 8, n));
+  // their evaluations on the quotient coset, and L1's (l1_coeff = i_ntt(e_0) = [1/n; n], prover.rs:430)
+  const unsigned blocks = (unsigned)((N + 255) / 256);
+  for (int k = 0; k < 8; k++)
+    hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks), dim3(256), 0, ctx->stream, e.coef + (size_t)k * n, n, e.g_pow, e.coset + (size_t)k * N, N);
+  fr_t* l1;
+  BP_TRY(ws_get(ctx, "prove.l1", n * sizeof(fr_t), (void**)&l1));
+  BP_HIP(ctx, hipMemsetAsync(l1, 0, n * sizeof(fr_t), ctx->stream));
+  BP_TRY(fr_scalar_run(ctx, l1, finv(from_u64(n)), l1, n, 0));                          // 0 + 1/n
+  hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks), dim3(256), 0, ctx->stream, l1, n, e.g_pow, e.coset + (size_t)8 * N, N);
+  BP_HIP(ctx, hipGetLastError());
+  BP_TRY(ntt_run(ctx, e.coset, log_n + 2, 0, N_PRE, N));
+  // 1 / (X^n - 1) on the coset: X^n = g^n i^j for X = g w_4n^j, i = w_4n^n the 4th root of unity
+  const fr_t gn = fpow(g, n), i4 = fpow(w4n, n);
+  fr_t p = Fr::one();
+  for (int j = 0; j < 4; j++) {
+    e.zh_inv[j] = finv(fsub(fmul(gn, p), Fr::one()));
+    p = fmul(p, i4);
+  }
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = e;
+  return BP_OK;
+}
+void circuit_release(CircuitEntry& e) {
+  (void)hipFree(e.lag); (void)hipFree(e.coef); (void)hipFree(e.coset); (void)hipFree(e.coset_x); (void)hipFree(e.g_pow); (void)hipFree(e.ginv_pow);
+}
+
+// ------------------------------------------------------------------------------------------------ prove
+// d_wit: a | b | c | PI Lagrange columns (4 x n, Montgomery, device).  blinders: b1..b11 (prover.rs:110).
+int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_wit, const fr_t blind[11], uint8_t proof[624]) {
+  const uint32_t k = cir.log_n;
+  const size_t n = (size_t)1 << k, N = 4 * n;
+  const fr_t omega = root_of_unity(n), k1 = from_u64(2), k2 = from_u64(3), one = Fr::one();      // prover.rs:99-100
+  hipStream_t st = ctx->stream;
+  const double t_start = now_ms();
+  PlonkTranscript tr;
+  g1_proj cm[9];
+
+  // ---- round 1 (prover.rs:177-277): a, b, c (and PI) to coefficient form, blinded by (b2 + b1 x)(x^n - 1) etc.
+  fr_t *coefs, *abc, *zc;
+  BP_TRY(ws_get(ctx, "prove.coefs", 4 * n * sizeof(fr_t), (void**)&coefs));          // iNTT of a | b | c | PI
+  BP_TRY(ws_get(ctx, "prove.abc", 3 * (n + 8) * sizeof(fr_t), (void**)&abc));        // a_coeff | b_coeff | c_coeff, n + 2 each
+  BP_TRY(ws_get(ctx, "prove.z", 2 * (n + 8) * sizeof(fr_t), (void**)&zc));           // z (Lagrange -> coefficients) | z_coeff, n + 3
+  BP_HIP(ctx, hipMemcpyAsync(coefs, d_wit, 4 * n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+  BP_TRY(ntt_run(ctx, coefs, k, 1, 4, n));
+  fr_t* poly_abc[3] = {abc, abc + (n + 8), abc + 2 * (n + 8)};
+  const unsigned blocks_n = (unsigned)((n + 8 + 255) / 256);
+  for (int j = 0; j < 3; j++)
+    hipLaunchKernelGGL(fr_blind, dim3(blocks_n), dim3(256), 0, st, coefs + (size_t)j * n, n, blind[2 * j + 1], blind[2 * j], Fr::zero(), 2u,
+                       poly_abc[j]);
+  BP_HIP(ctx, hipGetLastError());
+  for (int j = 0; j < 3; j++) BP_TRY(commit(ctx, srs, poly_abc[j], n + 2, &cm[j]));
+  tr.point("a_1", cm[0]); tr.point("b_1", cm[1]); tr.point("c_1", cm[2]);
+  const fr_t beta = tr.challenge("beta"), gamma = tr.challenge("gamma");
+  const double t_r1 = now_ms();
+
+  // ---- round 2 (prover.rs:279-368): permutation grand product, blinded by (b9 + b8 x + b7 x^2)(x^n - 1)
+  fr_t *z_lag = zc, *z_coeff = zc + (n + 8);
+  BP_TRY(grand_product_run(ctx, d_wit, d_wit + n, d_wit + 2 * n, cir.lag + 5 * n, cir.lag + 6 * n, cir.lag + 7 * n, n, beta, gamma, k1, k2,
+                           omega, z_lag));
+  BP_TRY(ntt_run(ctx, z_lag, k, 1, 1, n));
+  hipLaunchKernelGGL(fr_blind, dim3(blocks_n), dim3(256), 0, st, z_lag, n, blind[8], blind[7], blind[6], 3u, z_coeff);
+  BP_HIP(ctx, hipGetLastError());
+  BP_TRY(commit(ctx, srs, z_coeff, n + 3, &cm[3]));
+  tr.point("z_1", cm[3]);
+  const fr_t alpha = tr.challenge("z_1");                                           // transcript.rs:24
+  const double t_r2 = now_ms();
+
+  // ---- round 3 (prover.rs:370-500): quotient on the coset g <w_4n>
+  fr_t *ev, *t;
+  BP_TRY(ws_get(ctx, "prove.coset_wit", 5 * N * sizeof(fr_t), (void**)&ev));         // a | b | c | z | PI evaluations
+  BP_TRY(ws_get(ctx, "prove.t", (N + 16) * sizeof(fr_t), (void**)&t));
+  const unsigned blocks_N = (unsigned)((N + 255) / 256);
+  for (int j = 0; j < 3; j++) hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, poly_abc[j], n + 2, cir.g_pow, ev + (size_t)j * N, N);
+  hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, z_coeff, n + 3, cir.g_pow, ev + 3 * N, N);
+  hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, coefs + 3 * n, n, cir.g_pow, ev + 4 * N, N);
+  BP_HIP(ctx, hipGetLastError());
+  BP_TRY(ntt_run(ctx, ev, k + 2, 0, 5, N));
+  QuotientArgs qa;
+  qa.alpha = alpha; qa.alpha2 = fmul(alpha, alpha); qa.beta = beta; qa.gamma = gamma;
+  qa.beta_k1 = fmul(beta, k1); qa.beta_k2 = fmul(beta, k2); qa.one = one;
+  for (int j = 0; j < 4; j++) qa.zh_inv[j] = cir.zh_inv[j];
+  hipLaunchKernelGGL(quotient_coset, dim3(blocks_N), dim3(256), 0, st, ev, cir.coset, cir.coset_x, N, qa, t);
+  BP_HIP(ctx, hipGetLastError());
+  BP_TRY(ntt_run(ctx, t, k + 2, 1, 1, N));
+  BP_TRY(fr_binary_run(ctx, t, N, cir.ginv_pow, N, t, N, 2));
+  size_t t_len, dummy;
+  BP_TRY(fr_nonzero_stats_run(ctx, t, N, 0, 0, &t_len, &dummy));
+  // deg(numerator) <= 4n + 5, so an exact quotient has at most 3n + 6 coefficients; anything longer means the division by
+  // x^n - 1 left a remainder, i.e. the witness does not satisfy the circuit (the reference would panic at prover.rs:615)
+  if (t_len > 3 * n + 6) return fail(ctx, BP_ERR_ASSERT, "round 3: constraints not divisible by x^n - 1 (witness does not satisfy the circuit)", hipSuccess, __FILE__, __LINE__);
+  BP_TRY(squeeze_zeros(ctx, t, &t_len));
+  if (t_len <= 2 * n) return fail(ctx, BP_ERR_ASSERT, "round 3: quotient shorter than 2n + 1 (t_hi would be empty; values[0] panics)", hipSuccess, __FILE__, __LINE__);
+  // split_t_to_3pieces (:649-659) and the blinding of :475-481
+  fr_t *t_lo, *t_mid, *t_hi;
+  BP_TRY(ws_get(ctx, "prove.t_parts", 3 * (n + 8) * sizeof(fr_t), (void**)&t_lo));
+  t_mid = t_lo + (n + 8);
+  t_hi = t_mid + (n + 8);
+  const size_t hi_len = t_len - 2 * n;
+  BP_HIP(ctx, hipMemcpyAsync(t_lo, t, n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+  BP_HIP(ctx, hipMemcpyAsync(t_mid, t + n, n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+  BP_HIP(ctx, hipMemcpyAsync(t_hi, t + 2 * n, hi_len * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+  BP_HIP(ctx, hipMemcpyAsync(t_lo + n, &blind[9], sizeof(fr_t), hipMemcpyHostToDevice, st));        // + b10 x^n
+  BP_HIP(ctx, hipMemcpyAsync(t_mid + n, &blind[10], sizeof(fr_t), hipMemcpyHostToDevice, st));      // + b11 x^n ...
+  hipLaunchKernelGGL(fr_poke_add, dim3(1), dim3(1), 0, st, t_mid, fneg(blind[9]));                  // ... - b10
+  hipLaunchKernelGGL(fr_poke_add, dim3(1), dim3(1), 0, st, t_hi, fneg(blind[10]));                  // - b11
+  BP_HIP(ctx, hipGetLastError());
+  BP_TRY(commit(ctx, srs, t_lo, n + 1, &cm[4]));
+  BP_TRY(commit(ctx, srs, t_mid, n + 1, &cm[5]));
+  BP_TRY(commit(ctx, srs, t_hi, hi_len, &cm[6]));
+  tr.point("t_lo_1", cm[4]); tr.point("t_mid_1", cm[5]); tr.point("t_hi_1", cm[6]);
+  const fr_t zeta = tr.challenge("zeta");
+  const double t_r3 = now_ms();
+
+  // ---- round 4 (prover.rs:502-541): evaluations at zeta (z at zeta w)
+  const fr_t *s1c = cir.coef + 5 * n, *s2c = cir.coef + 6 * n, *s3c = cir.coef + 7 * n;
+  fr_t a_bar, b_bar, c_bar, s1_bar, s2_bar, zw_bar, pi_zeta;
+  BP_TRY(poly_eval_run(ctx, poly_abc[0], n + 2, zeta, &a_bar));
+  BP_TRY(poly_eval_run(ctx, poly_abc[1], n + 2, zeta, &b_bar));
+  BP_TRY(poly_eval_run(ctx, poly_abc[2], n + 2, zeta, &c_bar));
+  BP_TRY(poly_eval_run(ctx, s1c, n, zeta, &s1_bar));
+  BP_TRY(poly_eval_run(ctx, s2c, n, zeta, &s2_bar));
+  BP_TRY(poly_eval_run(ctx, z_coeff, n + 3, fmul(zeta, omega), &zw_bar));           // z_omega(zeta) = z(zeta w), :661-674
+  tr.scalar("a_eval", a_bar); tr.scalar("b_eval", b_bar); tr.scalar("c_eval", c_bar);
+  tr.scalar("s1_eval", s1_bar); tr.scalar("s2_eval", s2_bar); tr.scalar("z_shifted_eval", zw_bar);
+  const fr_t nu = tr.challenge("nu");
+  const double t_r4 = now_ms();
+
+  // ---- round 5 (prover.rs:543-647): linearisation r and the two opening quotients
+  BP_TRY(poly_eval_run(ctx, coefs + 3 * n, n, zeta, &pi_zeta));
+  const fr_t zeta_n = fpow(zeta, n), zh_zeta = fsub(zeta_n, one);
+  // L1(zeta) = (1/n) sum_i zeta^i  (l1_coeff.coeffs_evaluate, :590)
+  const fr_t l1_zeta = big_eq(zeta, one) ? one : fmul(zh_zeta, finv(fmul(from_u64(n), fsub(zeta, one))));
+  const fr_t bz = fmul(beta, zeta);
+  const fr_t f_a = fadd(fadd(a_bar, bz), gamma), f_b = fadd(fadd(b_bar, fmul(bz, k1)), gamma), f_c = fadd(fadd(c_bar, fmul(bz, k2)), gamma);
+  const fr_t g_a = fadd(fadd(a_bar, fmul(s1_bar, beta)), gamma), g_b = fadd(fadd(b_bar, fmul(s2_bar, beta)), gamma);
+  const fr_t alpha2 = fmul(alpha, alpha);
+  const fr_t perm_z = fmul(alpha, fmul(fmul(f_a, f_b), f_c));                        // coefficient of z in alpha r2
+  const fr_t perm_s = fmul(alpha, fmul(fmul(g_a, g_b), zw_bar));                     // alpha (..)(..) z_omega_bar
+  fr_t nup[6];
+  nup[0] = one;
+  for (int j = 1; j < 6; j++) nup[j] = fmul(nup[j - 1], nu);
+  LinComb lc;
+  memset(&lc, 0, sizeof lc);
+  int m = 0;
+  auto term = [&](const fr_t* p, size_t len, const fr_t& c) { lc.p[m] = p; lc.len[m] = len; lc.c[m] = c; m++; };
+  term(cir.coef + 2 * n, n, fmul(a_bar, b_bar));                                     // r1: qm a b + ql a + qr b + qo c + PI(zeta) + qc
+  term(cir.coef + 0 * n, n, a_bar);
+  term(cir.coef + 1 * n, n, b_bar);
+  term(cir.coef + 3 * n, n, c_bar);
+  term(cir.coef + 4 * n, n, one);
+  term(z_coeff, n + 3, fadd(perm_z, fmul(alpha2, l1_zeta)));                         // alpha r2 (z part) + alpha^2 r3 (z part)
+  term(s3c, n, fneg(fmul(perm_s, beta)));                                            // alpha r2: -(s3 beta + c + gamma) (..)(..) z_w
+  term(t_lo, n + 1, fneg(zh_zeta));                                                  // -r4
+  term(t_mid, n + 1, fneg(fmul(zeta_n, zh_zeta)));
+  term(t_hi, hi_len, fneg(fmul(fmul(zeta_n, zeta_n), zh_zeta)));
+  fr_t r_const = fsub(fsub(pi_zeta, fmul(perm_s, fadd(c_bar, gamma))), fmul(alpha2, l1_zeta));
+  const int r_terms = m;
+  term(poly_abc[0], n + 2, nup[1]);                                                  // + nu (a - a_bar) + ... (:623-634)
+  term(poly_abc[1], n + 2, nup[2]);
+  term(poly_abc[2], n + 2, nup[3]);
+  term(s1c, n, nup[4]);
+  term(s2c, n, nup[5]);
+  fr_t open_const = fadd(fadd(fmul(nup[1], a_bar), fmul(nup[2], b_bar)), fadd(fmul(nup[3], c_bar), fadd(fmul(nup[4], s1_bar), fmul(nup[5], s2_bar))));
+  lc.terms = m;
+  lc.constant = fsub(r_const, open_const);
+  size_t num_len = std::max({n + 3, n + 2, hi_len, n + 1});
+  fr_t *num, *w_zeta, *w_zeta_omega;
+  BP_TRY(ws_get(ctx, "prove.num", (n + 16) * sizeof(fr_t), (void**)&num));
+  BP_TRY(ws_get(ctx, "prove.w", 2 * (n + 16) * sizeof(fr_t), (void**)&w_zeta));
+  w_zeta_omega = w_zeta + (n + 16);
+  if (num_len > n + 16) return fail(ctx, BP_ERR_ASSERT, "round 5: quotient piece longer than n + 16", hipSuccess, __FILE__, __LINE__);
+  hipLaunchKernelGGL(fr_lincomb, dim3((unsigned)((num_len + 255) / 256)), dim3(256), 0, st, lc, num, num_len);
+  BP_HIP(ctx, hipGetLastError());
+  // r(zeta) == 0 (prover.rs:615): the opening terms vanish at zeta, so the numerator's value there is r's
+  fr_t check;
+  BP_TRY(poly_eval_run(ctx, num, num_len, zeta, &check));
+  (void)r_terms;
+  if (!big_is_zero(check)) return fail(ctx, BP_ERR_ASSERT, "round 5: r(zeta) != 0 (prover.rs:615)", hipSuccess, __FILE__, __LINE__);
+  size_t wz_len, wzo_len;
+  BP_TRY(divide_by_linear(ctx, num, num_len, zeta, w_zeta, &wz_len));
+  // W_zeta_omega = (z - z_omega_bar) / (x - zeta w)  (:636-638)
+  BP_HIP(ctx, hipMemcpyAsync(num, z_coeff, (n + 3) * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(fr_poke_add, dim3(1), dim3(1), 0, st, num, fneg(zw_bar));
+  BP_HIP(ctx, hipGetLastError());
+  BP_TRY(divide_by_linear(ctx, num, n + 3, fmul(zeta, omega), w_zeta_omega, &wzo_len));
+  BP_TRY(commit(ctx, srs, w_zeta, wz_len, &cm[7]));
+  BP_TRY(commit(ctx, srs, w_zeta_omega, wzo_len, &cm[8]));
+  const double t_r5 = now_ms();
+
+  // ---- Proof (verifier.rs:23-40 field order): 9 compressed points, then the 6 evaluations as 32-byte little-endian
+  for (int j = 0; j < 9; j++) compress48(proof + 48 * j, cm[j]);
+  const fr_t evals[6] = {a_bar, b_bar, c_bar, s1_bar, s2_bar, zw_bar};
+  for (int j = 0; j < 6; j++) to_le32(proof + 432 + 32 * j, evals[j]);
+  ctx->prove_ms[0] = (float)(t_r1 - t_start); ctx->prove_ms[1] = (float)(t_r2 - t_r1); ctx->prove_ms[2] = (float)(t_r3 - t_r2);
+  ctx->prove_ms[3] = (float)(t_r4 - t_r3); ctx->prove_ms[4] = (float)(t_r5 - t_r4); ctx->prove_ms[5] = (float)(now_ms() - t_start);
+  return BP_OK;
+}
+
+void transcript_test_vector(uint8_t out32[32]) {
+  MerlinTranscript t("test protocol");
+  t.append_message("some label", (const uint8_t*)"some data", 9);
+  t.challenge_bytes("challenge", out32, 32);
+}
+
+}  // namespace bp

@@ -175,6 +175,33 @@ int  bp_commit_device(bp_ctx* ctx, uint64_t srs_handle, const void* d_coeffs, si
 int  bp_commit(bp_ctx* ctx, uint64_t srs_handle, const void* coeffs, size_t n, int basis, int scalar_fmt,
                uint8_t out96[96]);
 
+/* ---- Prover::prove (src/prover.rs:64-175; rounds :177-647) -- SURVEY.md 8f "next" rows 1-3 ------------------ */
+/* Preprocessed circuit = CommonPreprocessedInput (src/program.rs:34-50): the eight Lagrange columns
+ * QL QR QM QO QC S1 S2 S3 (in this order) of a 2^log_n-row circuit, log_n >= 3.  Uploaded once and kept in HBM
+ * with the forms the reference re-derives inside every proof (coefficient forms, prover.rs:379-386).
+ * columns_on_device != 0: the eight pointers are HBM addresses of Montgomery data. */
+int  bp_circuit_load(bp_ctx* ctx, uint32_t log_n, const void* const columns[8], int scalar_fmt, int columns_on_device,
+                     uint64_t* circuit_handle);
+int  bp_circuit_free(bp_ctx* ctx, uint64_t circuit_handle);
+/* One proof.  a, b, c: the witness as the three Lagrange wire columns the reference builds at prover.rs:186-227;
+ * public_input: the Lagrange column of prover.rs:114-127 (-x_i in the first rows, zero elsewhere), NULL = all zero;
+ * 2^log_n scalars each.  blinders: b1..b11 of prover.rs:110 as 11 x 32 canonical little-endian bytes -- an input here
+ * (prove_with_blinding), because the reference draws them from thread_rng and is therefore not reproducible.
+ * The SRS needs 2^log_n + 6 points (verify_proof_test.rs:16).  Challenges come from the reference's transcript
+ * (src/transcript.rs:4-86; merlin 3.0.0 restated on the host).
+ * proof: 9 x 48-byte compressed G1 points in Proof field order (verifier.rs:23-40: a_1 b_1 c_1 z_1 t_lo_1 t_mid_1
+ * t_hi_1 w_zeta_1 w_zeta_omega_1), then a_bar b_bar c_bar s1_bar s2_bar z_omega_bar as 32-byte little-endian.
+ * Errors mirror the reference's panics: BP_ERR_ASSERT for z_n != 1 (prover.rs:319) and r(zeta) != 0 (:615), i.e. a
+ * witness that does not satisfy the circuit; BP_ERR_DIV_ZERO for a zero permutation denominator. */
+int  bp_prove(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_handle, const void* a, const void* b, const void* c,
+              const void* public_input, int scalar_fmt, int witness_on_device, const uint8_t blinders[352],
+              uint8_t proof[624]);
+/* Host wall-clock milliseconds of rounds 1..5 and of the whole last bp_prove on this ctx. */
+int  bp_prove_last_stats(bp_ctx* ctx, float round_ms[5], float* total_ms);
+/* merlin conformance vector: Transcript::new("test protocol"), append_message("some label", "some data"),
+ * challenge_bytes("challenge", 32) -- lets a binding check the host transcript without a GPU. */
+int  bp_transcript_test_vector(uint8_t out32[32]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,18 @@ def enc48(pt):
     return bytes(b)
 
 
+def dec48(b):
+    """G1Affine::from_compressed (g1.rs:324-388): y = sqrt(x^3 + 4) with the sign bit choosing the larger root"""
+    if b[0] & 0x40:
+        return None
+    x = int.from_bytes(bytes([b[0] & 0x1F]) + bytes(b[1:48]), "big")
+    y = pow((x * x * x + 4) % P, (P + 1) // 4, P)            # p = 3 mod 4
+    assert y * y % P == (x * x * x + 4) % P
+    if (y > (P - 1) // 2) != bool(b[0] & 0x20):
+        y = P - y
+    return (x, y)
+
+
 def omega(n):
     return pow(ROOT_OF_UNITY, (1 << 32) // n, Q)
 

@@ -1,0 +1,142 @@
+"""bp_prove -- the native prover (csrc/prover.hip: rounds 1-5 on the GPU, Fiat-Shamir transcript on the host) against
+the reference-shaped restatement of src/prover.rs in tests/prover_rounds.py run on the CPU oracle, the committed golden
+proof of the toy circuit of tests/verify_proof_test.rs, and the verifier's final equation (checked in G1 with the known tau).
+The native path computes the same polynomials by a different route (coset quotient, fused linear combinations), so equal
+proof BYTES are the parity statement."""
+import hashlib
+import os
+import random
+
+import numpy as np
+import pytest
+
+import baby_plonk_rust_amd as bp
+from tests import bigint_model as M
+from tests import prover_rounds as PR
+
+Q = M.Q
+HERE = os.path.dirname(__file__)
+MERLIN_VECTOR = "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+
+
+def test_host_transcript_conformance_vector():
+    """merlin's published test vector through the library's C++ transcript (no GPU): pins transcript.hpp like
+    tests/test_merlin_transcript.py pins its Python twin"""
+    assert bp.transcript_test_vector().hex() == MERLIN_VECTOR
+
+
+def _split(blob):
+    names = ("a_1", "b_1", "c_1", "z_1", "t_lo_1", "t_mid_1", "t_hi_1", "w_zeta_1", "w_zeta_omega_1")
+    pts = {k: M.dec48(blob[48 * i: 48 * i + 48]) for i, k in enumerate(names)}
+    ev = {k: int.from_bytes(blob[432 + 32 * i: 464 + 32 * i], "little")
+          for i, k in enumerate(("a_bar", "b_bar", "c_bar", "s1_bar", "s2_bar", "z_omega_bar"))}
+    return pts, ev
+
+
+def _challenges(blob):
+    from tests.merlin_transcript import PlonkTranscript
+    tr = PlonkTranscript()
+    pt = lambda i: blob[48 * i: 48 * i + 48]
+    ev = [int.from_bytes(blob[432 + 32 * i: 464 + 32 * i], "little") for i in range(6)]
+    beta, gamma = tr.round_1(pt(0), pt(1), pt(2))
+    alpha = tr.round_2(pt(3))
+    zeta = tr.round_3(pt(4), pt(5), pt(6))
+    nu = tr.round_4(*ev)
+    mu = tr.round_5(pt(7), pt(8))
+    return dict(beta=beta, gamma=gamma, alpha=alpha, zeta=zeta, nu=nu, mu=mu)
+
+
+@pytest.mark.gpu
+def test_toy_circuit_native_proof_is_the_golden_proof():
+    from oracle import oracle as O
+    from tests.test_gpu_prover_rounds import g1_only_verify, prove_with_blinding, toy_circuit, decode
+    n, tau = 8, 101
+    cols, pk, public = toy_circuit(n)
+    blinders = [random.Random(99).randrange(1, Q) for _ in range(11)]
+    setup = bp.Setup.generate_srs(n + 6, tau)                          # verify_proof_test.rs:16
+    circuit = bp.Circuit({k: PR.SV(v) for k, v in pk.items()})
+    prover = bp.Prover(setup, circuit)
+    blob = prover.prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), PR.SV(public), blinders)
+    golden = open(os.path.join(HERE, "golden", "toy_proof_blinders_seed99.sha256")).read().strip()
+    assert len(blob) == 624 and hashlib.sha256(blob).hexdigest() == golden      # fixture made by the oracle path on the CPU
+    # the restatement of the reference's call sequence on the CPU oracle gives the same bytes
+    cpu = PR.OracleBackend(O.proj_from_bytes96(setup.powers_of_x()))
+    _, _, blob_c = prove_with_blinding(cpu, n, cols, pk, public, blinders)
+    assert blob == blob_c
+    # verifier (src/verifier.rs:80-209), challenges recomputed from the proof bytes
+    gpu = PR.GpuBackend(setup)
+    vk = {k: decode(gpu.commit(gpu.Polynomial(gpu.i_ntt_381(PR.SV(pk[k])), gpu.MONO))) for k in pk}
+    pts, ev = _split(blob)
+    assert g1_only_verify(n, tau, pts, ev, _challenges(blob), vk, [80])
+    assert not g1_only_verify(n, tau, pts, ev, _challenges(blob), vk, [81])
+    # canonical-bytes input format and a different blinding
+    st = prover.last_stats()
+    assert len(st["round_ms"]) == 5 and st["total_ms"] > 0
+    other = prover.prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), PR.SV(public), [b + 1 for b in blinders])
+    assert other != blob and g1_only_verify(n, tau, *_split(other), _challenges(other), vk, [80])
+    circuit.free()
+
+
+@pytest.mark.gpu
+def test_witness_that_does_not_satisfy_the_circuit_is_rejected():
+    """the reference panics: assert z[n] == 1 (prover.rs:319) for a broken copy constraint, r(zeta) != 0 (:615) for a broken gate"""
+    from tests.test_gpu_prover_rounds import toy_circuit
+    n = 8
+    cols, pk, public = toy_circuit(n)
+    blinders = list(range(1, 12))
+    setup = bp.Setup.generate_srs(n + 6, 101)
+    circuit = bp.Circuit({k: PR.SV(v) for k, v in pk.items()})
+    prover = bp.Prover(setup, circuit)
+    good = [PR.SV(c) for c in cols]
+    assert len(prover.prove_with_blinding(*good, PR.SV(public), blinders)) == 624
+    bad_gate = [list(c) for c in cols]
+    bad_gate[0][1], bad_gate[1][1] = 4, 3                  # a*b + b with a, b swapped: 16 != 15, both cells are free wires
+    with pytest.raises(bp.BpError) as e:
+        prover.prove_with_blinding(*[PR.SV(c) for c in bad_gate], PR.SV(public), blinders)
+    assert e.value.code == -11
+    bad_copy = [list(c) for c in cols]
+    bad_copy[0][2] = 17                                     # row 2 reads c = 17 while row 1 wrote c = 16
+    with pytest.raises(bp.BpError) as e:
+        prover.prove_with_blinding(*[PR.SV(c) for c in bad_copy], PR.SV(public), blinders)
+    assert e.value.code == -11
+    with pytest.raises(bp.BpError) as e:                    # wrong public input: PI does not cancel e
+        prover.prove_with_blinding(*good, PR.SV([(-81) % Q] + [0] * (n - 1)), blinders)
+    assert e.value.code == -11
+    short = bp.Setup.generate_srs(n + 5, 101)               # SRS one power short
+    with pytest.raises(bp.BpError) as e:
+        bp.Prover(short, circuit).prove_with_blinding(*good, PR.SV(public), blinders)
+    assert e.value.code == -6
+    with pytest.raises(bp.BpError):
+        prover.prove_with_blinding(*good, PR.SV(public), blinders[:10])
+    with pytest.raises(bp.BpError):
+        bp.Circuit([PR.SV([0] * 8)] * 7)
+    circuit.free()
+    with pytest.raises(bp.BpError):
+        prover.prove_with_blinding(*good, PR.SV(public), blinders)          # freed circuit handle
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logn", [4, 10])
+def test_synthetic_circuit_native_vs_oracle_restatement(logn):
+    from oracle import oracle as O
+    from tests.test_gpu_prover_rounds import decode, g1_only_verify, prove_with_blinding, synthetic_circuit
+    n, tau = 1 << logn, 0x1234567
+    cols, pk, public = synthetic_circuit(n, 5 + logn)
+    blinders = [random.Random(7).randrange(1, Q) for _ in range(11)]
+    setup = bp.Setup.generate_srs(n + 6, tau)
+    circuit = bp.Circuit({k: PR.SV(v) for k, v in pk.items()})
+    prover = bp.Prover(setup, circuit)
+    blob = prover.prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), None, blinders)
+    cpu = PR.OracleBackend(O.proj_from_bytes96(setup.powers_of_x()))
+    cpu.threads = 16
+    _, _, blob_c = prove_with_blinding(cpu, n, cols, pk, public, blinders, logging=False)
+    assert blob == blob_c
+    dev = PR.GpuDeviceBackend(setup)
+    vk = {k: decode(dev.commit(dev.i_ntt_poly(dev.Polynomial(PR.SV(pk[k]), dev.LAG)))) for k in pk}
+    assert g1_only_verify(n, tau, *_split(blob), _challenges(blob), vk, [])
+    # HBM-resident witness: same bytes
+    import torch
+    t = [torch.from_numpy(PR.SV(c).view(np.int64)).cuda() for c in cols]
+    torch.cuda.synchronize()
+    assert prover.prove_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, blinders) == blob
+    circuit.free()
