@@ -11,6 +11,9 @@
 //   root_of_unity / roots_of_unity (src/utils.rs:39-52)     root_of_unity / roots_of_unity
 //   Polynomial + operators (src/polynomial.rs:14-380)       Polynomial
 //   Setup::generate_srs / commit (src/setup.rs:12-37)       Setup
+//   CommonPreprocessedInput (src/program.rs:34-50)          CommonPreprocessedInput
+//   Prover::new / prove (src/prover.rs:64-175)              Prover::prove_with_blinding (blinders are an argument)
+//   Proof (src/verifier.rs:23-40)                           Proof (624 bytes: 9 compressed points, 6 scalars)
 #pragma once
 #include <array>
 #include <cstdint>
@@ -202,10 +205,79 @@ class Setup {
     return out;
   }
 
+ uint64_t handle() const { return handle_; }
+  Context& context() const { return *ctx_; }
+
  private:
   Setup(uint64_t h, Context& c) : handle_(h), ctx_(&c) {}
   uint64_t handle_;
   Context* ctx_;
+};
+
+// src/program.rs:34-50: selector and permutation polynomials in the Lagrange basis
+struct CommonPreprocessedInput {
+  uint64_t group_order;
+  Polynomial ql, qr, qm, qo, qc, s1, s2, s3;
+};
+
+// src/verifier.rs:23-40, serialised in field order: a_1 b_1 c_1 z_1 t_lo_1 t_mid_1 t_hi_1 w_zeta_1 w_zeta_omega_1 as
+// 48-byte compressed G1 (the encoding the transcript absorbs, transcript.rs:66-69), then a_bar b_bar c_bar s1_bar
+// s2_bar z_omega_bar as Scalar::to_bytes()
+struct Proof {
+  std::array<uint8_t, 624> bytes{};
+  std::array<uint8_t, 48> point(int i) const {
+    std::array<uint8_t, 48> p{};
+    std::memcpy(p.data(), bytes.data() + 48 * i, 48);
+    return p;
+  }
+  std::array<uint8_t, 32> eval_bytes(int i) const {
+    std::array<uint8_t, 32> e{};
+    std::memcpy(e.data(), bytes.data() + 432 + 32 * i, 32);
+    return e;
+  }
+};
+
+// src/prover.rs:50-175.  The circuit front-end (Program / Assembly) stays on the reference's side; what arrives here
+// is what it produces: the preprocessed columns once, and per proof the three wire columns and the public-input column.
+class Prover {
+ public:
+  Prover(const Setup& setup, const CommonPreprocessedInput& pk) : setup_(&setup), n_(pk.group_order) {           // prover.rs:64-104
+    const Polynomial* cols[8] = {&pk.ql, &pk.qr, &pk.qm, &pk.qo, &pk.qc, &pk.s1, &pk.s2, &pk.s3};
+    const void* ptrs[8];
+    uint32_t log_n = 0;
+    while ((1ull << log_n) < n_) log_n++;
+    if ((1ull << log_n) != n_) throw Panic(BP_ERR_NOT_POW2, "group_order must be a power of two");
+    for (int k = 0; k < 8; k++) {
+      if (cols[k]->basis != Basis::Lagrange || cols[k]->values.size() != n_) throw Panic(BP_ERR_LENGTH, "preprocessed column: Lagrange, group_order values");
+      ptrs[k] = cols[k]->values.data();
+    }
+    setup.context().check(bp_circuit_load(setup.context().raw(), log_n, ptrs, BP_FR_MONT, 0, &circuit_), "Prover::new");
+  }
+  ~Prover() { bp_circuit_free(setup_->context().raw(), circuit_); }
+  Prover(const Prover&) = delete;
+  Prover& operator=(const Prover&) = delete;
+
+  // prover.rs:106-175 with b1..b11 (:110) supplied by the caller; wire columns as built at :186-227, public-input column as at :114-127
+  Proof prove_with_blinding(const std::vector<Scalar>& a, const std::vector<Scalar>& b, const std::vector<Scalar>& c,
+                            const std::vector<Scalar>& public_input, const std::array<Scalar, 11>& blinders) const {
+    if (a.size() != n_ || b.size() != n_ || c.size() != n_ || (!public_input.empty() && public_input.size() != n_))
+      throw Panic(BP_ERR_LENGTH, "witness columns must have group_order entries");
+    uint8_t bl[352];
+    for (int j = 0; j < 11; j++) {
+      auto bytes = blinders[j].to_bytes();
+      std::memcpy(bl + 32 * j, bytes.data(), 32);
+    }
+    Proof proof;
+    setup_->context().check(bp_prove(setup_->context().raw(), setup_->handle(), circuit_, a.data(), b.data(), c.data(),
+                                     public_input.empty() ? nullptr : public_input.data(), BP_FR_MONT, 0, bl, proof.bytes.data()),
+                            "Prover::prove");
+    return proof;
+  }
+
+ private:
+  const Setup* setup_;
+  uint64_t n_;
+  uint64_t circuit_ = 0;
 };
 
 }  // namespace baby_plonk

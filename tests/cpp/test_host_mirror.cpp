@@ -1,8 +1,10 @@
 // C++ parity test of the host-side mirror (baby_plonk_rust_amd/host/baby_plonk.hpp): restates the reference's own
 // unit tests for the path -- src/setup.rs:46-116 (test_generate_srs, test_monomial_commit), src/polynomial.rs:386-521,
 // src/utils.rs:239-242 -- through the mirror's Rust-shaped API.  Needs a GPU; built and run by tests/test_gpu_cpp_mirror.py.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "../../baby_plonk_rust_amd/host/baby_plonk.hpp"
 
@@ -30,7 +32,62 @@ static bool panics(F f, int code) {
   return false;
 }
 
-int main() {
+static Scalar mul(const Scalar& a, const Scalar& b) { return (mono({a}) * b).values[0]; }
+
+// tests/verify_proof_test.rs:16-44 through the mirror: program ["e public", "c <== a * b + b", "e <== c * d"], group order 8,
+// 14 powers of tau = 101, witness a=3 b=4 c=16 d=5 e=80.  The columns are what Program / Assembly produce (SURVEY.md
+// appendix A): rows (e,-,-) (a,b,c) (c,d,e) + five empty rows; cells with equal names form one permutation cycle.
+static Proof toy_proof(const std::array<Scalar, 11>& blinders) {
+  const uint64_t n = 8;
+  const char* wires[8][3] = {{"e", "", ""}, {"a", "b", "c"}, {"c", "d", "e"}, {"", "", ""}, {"", "", ""}, {"", "", ""}, {"", "", ""}, {"", "", ""}};
+  auto value = [](const std::string& w) -> uint64_t { return w == "a" ? 3 : w == "b" ? 4 : w == "c" ? 16 : w == "d" ? 5 : w == "e" ? 80 : 0; };
+  auto lag = [&](std::vector<Scalar> v) { v.resize(n, Scalar::zero()); return Polynomial(std::move(v), Basis::Lagrange); };
+  CommonPreprocessedInput pk{n, lag({S(1)}), lag({S(0), neg(S(1))}), lag({S(0), neg(S(1)), neg(S(1))}), lag({S(0), S(1), S(1)}), lag({}),
+                             lag({}), lag({}), lag({})};
+  auto roots = roots_of_unity(n);
+  std::vector<std::string> names;
+  for (auto& row : wires) for (auto* w : row) if (std::find(names.begin(), names.end(), w) == names.end()) names.push_back(w);
+  Polynomial* sigma[3] = {&pk.s1, &pk.s2, &pk.s3};
+  for (auto& name : names) {                                    // program.rs:92-99
+    std::vector<std::pair<int, int>> cells;                     // (column, row) in row-major order
+    for (int row = 0; row < 8; row++) for (int col = 0; col < 3; col++) if (name == wires[row][col]) cells.push_back({col, row});
+    for (size_t j = 0; j < cells.size(); j++) {
+      auto next = cells[(j + 1) % cells.size()];
+      sigma[cells[j].first]->values[cells[j].second] = mul(S(next.first + 1), roots[next.second]);     // utils.rs:29-36
+    }
+  }
+  std::vector<Scalar> col[3];
+  for (int j = 0; j < 3; j++) for (int row = 0; row < 8; row++) col[j].push_back(S(value(wires[row][j])));
+  std::vector<Scalar> pi(n, Scalar::zero());
+  pi[0] = neg(S(80));                                            // prover.rs:114-127
+  Setup setup = Setup::generate_srs(n + 6, le(101));
+  Prover prover(setup, pk);
+  Proof proof = prover.prove_with_blinding(col[0], col[1], col[2], pi, blinders);
+  // a witness that breaks the gate is refused the way the reference panics (prover.rs:615)
+  std::vector<Scalar> bad = col[0];
+  bad[1] = S(4);
+  bool refused = false;
+  try { prover.prove_with_blinding(bad, col[1], col[2], pi, blinders); } catch (const Panic& p) { refused = p.code == BP_ERR_ASSERT; }
+  CHECK(refused);
+  return proof;
+}
+
+int main(int argc, char** argv) {
+  if (argc == 2) {                       // 11 blinders as 11 x 64 hex digits (32-byte little-endian each): print the toy proof
+    std::array<Scalar, 11> blinders;
+    std::string hex = argv[1];
+    CHECK(hex.size() == 11 * 64);
+    for (int j = 0; j < 11; j++) {
+      std::array<uint8_t, 32> b{};
+      for (int i = 0; i < 32; i++) b[i] = (uint8_t)std::stoul(hex.substr(64 * j + 2 * i, 2), nullptr, 16);
+      blinders[j] = Scalar::from_bytes(b);
+    }
+    Proof p = toy_proof(blinders);
+    std::printf("proof ");
+    for (uint8_t v : p.bytes) std::printf("%02x", v);
+    std::printf("\n");
+    return 0;
+  }
   // ---- src/utils.rs:239-242 test_root_of_unity
   {
     Polynomial w({root_of_unity(4)}, Basis::Monomial);
