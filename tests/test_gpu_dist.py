@@ -60,9 +60,10 @@ def test_bench_two_rank_rehearsal():
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "14",
-           "--ntt-log-n", "14", "--backend", "gloo", "--skip-cpu"]
+           "--ntt-log-n", "14", "--prove-log-n", "10", "--prove-reps", "2", "--backend", "gloo", "--skip-cpu"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["ntt"]["value"] > 0
     assert line["config"]["msm_points_per_gpu"] == 1 << 14
+    assert line["prove"]["gates"] == 1 << 10 and line["prove"]["value"] > 0 and line["prove"]["parallelism"] == "independent proofs x2"

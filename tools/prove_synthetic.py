@@ -23,33 +23,10 @@ from tests.test_gpu_prover_rounds import compute_challenges, decode, g1_only_ver
 Q = M.Q
 
 
-def ints_to_mont(vals):
-    raw = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).copy()
-    out = np.zeros((len(vals), 4), dtype=np.uint64)
-    rc = _lib.load().bp_fr_convert(raw.ctypes.data, len(vals), 0, 1, out.ctypes.data)
-    assert rc == 0
-    return out
-
-
 def synthetic(n, seed):
-    rnd = random.Random(seed)
-    x = rnd.randrange(Q)
-    A, Bc, Cc = [0] * n, [0] * n, [0] * n
-    for i in range(n):
-        y = rnd.getrandbits(250)
-        A[i], Bc[i], Cc[i] = x, y, x * y % Q
-        x = Cc[i]
-    om = M.omega(n)
-    pw = [1] * n
-    for i in range(1, n):
-        pw[i] = pw[i - 1] * om % Q
-    s1, s2, s3 = list(pw), [2 * v % Q for v in pw], [3 * v % Q for v in pw]
-    for i in range(n - 1):
-        s3[i], s1[i + 1] = pw[i + 1], 3 * pw[i] % Q
-    zero = np.zeros((n, 4), dtype=np.uint64)
-    pk = dict(ql=zero, qr=zero, qm=ints_to_mont([Q - 1] * n), qo=ints_to_mont([1] * n), qc=zero,
-              s1=ints_to_mont(s1), s2=ints_to_mont(s2), s3=ints_to_mont(s3))
-    return [ints_to_mont(A), ints_to_mont(Bc), ints_to_mont(Cc)], pk, zero.copy()
+    from baby_plonk_rust_amd.synthetic import chained_multiplications
+    cols, pk = chained_multiplications(n, seed)
+    return cols, pk, np.zeros((n, 4), dtype=np.uint64)
 
 
 ap = argparse.ArgumentParser()
