@@ -211,7 +211,9 @@ void bp_destroy(bp_ctx* ctx) {
   for (auto& kv : ctx->srs) {
     if (kv.second.d_points) (void)hipFree(kv.second.d_points);
     if (kv.second.d_points28) (void)hipFree(kv.second.d_points28);
+    if (kv.second.d_table) (void)hipFree(kv.second.d_table);
   }
+  for (auto& kv : ctx->circuits) circuit_release(kv.second);
   for (auto& kv : ctx->ntt_tables) {
     (void)hipFree(kv.second.lo);
     (void)hipFree(kv.second.hi);

@@ -163,11 +163,26 @@ constexpr int N_PRE = 9;                 // ql qr qm qo qc s1 s2 s3 (+ L1 on the
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ circuit
+static int circuit_fill(bp_ctx* ctx, const fr_t* d_lag, CircuitEntry& e);
+
+// takes ownership of d_lag only on success
 int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out) {
-  const size_t n = (size_t)1 << log_n, N = 4 * n;
   CircuitEntry e;
   e.log_n = log_n;
+  int rc = circuit_fill(ctx, d_lag, e);
+  if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "circuit_build", hipGetLastError(), __FILE__, __LINE__);
+  if (rc != BP_OK) {
+    circuit_release(e);               // e.lag is still null: the caller keeps d_lag
+    return rc;
+  }
   e.lag = d_lag;
+  *out = e;
+  return BP_OK;
+}
+
+static int circuit_fill(bp_ctx* ctx, const fr_t* d_lag, CircuitEntry& e) {
+  const uint32_t log_n = e.log_n;
+  const size_t n = (size_t)1 << log_n, N = 4 * n;
   BP_HIP(ctx, hipMalloc((void**)&e.coef, 8 * n * sizeof(fr_t)));
   BP_HIP(ctx, hipMalloc((void**)&e.coset, (size_t)N_PRE * N * sizeof(fr_t)));
   BP_HIP(ctx, hipMalloc((void**)&e.coset_x, N * sizeof(fr_t)));
@@ -179,7 +194,7 @@ int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out) {
   BP_TRY(roots_run(ctx, w4n, N, e.coset_x));                                             // w_4n^i ...
   BP_TRY(fr_scalar_run(ctx, e.coset_x, g, e.coset_x, N, 2));                            // ... times g
   // coefficient forms (prover.rs:379-386 recomputes these i_ntt's in every proof)
-  BP_HIP(ctx, hipMemcpyAsync(e.coef, e.lag, 8 * n * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
+  BP_HIP(ctx, hipMemcpyAsync(e.coef, d_lag, 8 * n * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
   BP_TRY(ntt_run(ctx, e.coef, log_n, 1, 8, n));
   // their evaluations on the quotient coset, and L1's (l1_coeff = i_ntt(e_0) = [1/n; n], prover.rs:430)
   const unsigned blocks = (unsigned)((N + 255) / 256);
@@ -199,12 +214,14 @@ int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out) {
     e.zh_inv[j] = finv(fsub(fmul(gn, p), Fr::one()));
     p = fmul(p, i4);
   }
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  *out = e;
   return BP_OK;
 }
 void circuit_release(CircuitEntry& e) {
-  (void)hipFree(e.lag); (void)hipFree(e.coef); (void)hipFree(e.coset); (void)hipFree(e.coset_x); (void)hipFree(e.g_pow); (void)hipFree(e.ginv_pow);
+  fr_t** owned[6] = {&e.lag, &e.coef, &e.coset, &e.coset_x, &e.g_pow, &e.ginv_pow};
+  for (fr_t** p : owned) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ prove

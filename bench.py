@@ -37,6 +37,10 @@ import baby_plonk_rust_amd as bp
 from baby_plonk_rust_amd import dist as bpd
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+# The dominant kernel is integer-issue bound: second ceiling from this repo's own measurements --
+# tools/ubench_int.hip (profiles/r01_ubench_int_issue_rates.txt): v_mad_u64_u32 issues at 57 lanes/clk/CU, like a carry add
+VALU_PEAK_LANE_INSTR_S = 57.0 * 256 * 2.4e9
+ACC_INSTR_PER_ADD = 4900         # VALU instructions per mixed addition in msm_accumulate's loop body (ISA count; 4311 are v_mad_u64_u32)
 MSM_BYTES_PER_UNIT = 128         # 32 B scalar + 96 B affine point per scalar-mul
 NTT_BYTES_PER_UNIT = 64          # 32 B read + 32 B write per element
 GOLDEN = 0x9E3779B97F4A7C15
@@ -249,6 +253,11 @@ def main():
                          if (args.log_n == 20 and stats["window_bits"] == 16) else None,
                          "kernel_ms": acc * 1e3, "algorithmic_bytes_per_launch": MSM_BYTES_PER_UNIT * n,
                          "note": "integer-ALU bound by design (11 Fp mul per bucket add); see DESIGN.md"},
+            "roofline_valu_issue": {"bound": "valu_issue (integer multiply-add)", "kernel": "msm_accumulate",
+                                    "achieved": stats["mixed_adds"] * ACC_INSTR_PER_ADD / acc, "peak": VALU_PEAK_LANE_INSTR_S,
+                                    "unit": "lane-instructions/s", "frac": stats["mixed_adds"] * ACC_INSTR_PER_ADD / acc / VALU_PEAK_LANE_INSTR_S,
+                                    "note": "mixed additions per launch x static instruction count of the loop body / measured kernel time, against "
+                                            "the measured v_mad_u64_u32 issue rate (57 lanes/clk/CU x 256 CU x 2.4 GHz)"},
             "msm_device_ms": float(np.mean(dev_ms)),
             ("msm_with_tables" if args.no_tables else "msm_without_tables"): {
                 "value": units / other_elapsed, "unit": "scalar-muls/s", "ms_per_step": 1e3 * other_elapsed / args.steps,
