@@ -202,8 +202,12 @@ int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_
     default: hipLaunchKernelGGL(msm_accumulate<2>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial);
   }
   BP_HIP(ctx, hipEventRecord(ctx->ev[2], st));
-  hipLaunchKernelGGL(msm_fixup, dim3((total + 255) / 256), dim3(256), 0, st, offsets, plan, bucket_sum, partial, long_count, long_list,
-                     long_cap);
+  if (table_c)      // 2^15 buckets of ~8 partials each: two lanes per bucket = one wave per SIMD, half the chain
+    hipLaunchKernelGGL(msm_fixup<2>, dim3((unsigned)(((uint64_t)total * 2 + 255) / 256)), dim3(256), 0, st, offsets, plan, bucket_sum, partial,
+                       long_count, long_list, long_cap);
+  else
+    hipLaunchKernelGGL(msm_fixup<1>, dim3((total + 255) / 256), dim3(256), 0, st, offsets, plan, bucket_sum, partial, long_count, long_list,
+                       long_cap);
   hipLaunchKernelGGL(msm_fixup_long, dim3(64), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
                      long_count, long_list, long_cap);
   if (table_c) {
