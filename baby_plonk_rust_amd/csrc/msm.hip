@@ -80,10 +80,14 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   // tables: B buckets hold all W * n entries, so chunks grow with n to keep ~8 partial runs per bucket for the fix-up
   while (chunk < (table_c ? 1024u : 64u) && entries / chunk > 262144) chunk <<= 1;
   plan.chunk = env_u32("BP_MSM_CHUNK", chunk);
-  uint32_t slices = 1024 / W;
+  // count/scatter workgroups per window: each flushes its whole LDS histogram with global atomics, so fewer, fatter
+  // slices are cheaper (~32 Ki points each) as long as >= 256 workgroups remain to fill the CUs (measured: 2^16, 2^20, 2^24)
+  uint32_t slices = (uint32_t)(n >> 15), lo = 256 / W, hi = 1024 / W;
+  if (slices < lo) slices = lo;
+  if (slices > hi) slices = hi;
   if (slices < 1) slices = 1;
   while (slices > 1 && n / slices < 1024) slices >>= 1;
-  plan.slices = slices;
+  plan.slices = env_u32("BP_MSM_SLICES", slices);
   uint32_t seg = 1;
   while (seg < 32 && plan.total / seg > 65536) seg <<= 1;
   plan.seg = env_u32("BP_MSM_SEG", seg);
