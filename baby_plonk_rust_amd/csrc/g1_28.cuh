@@ -118,6 +118,70 @@ BP_HD void g1_add28(g1_proj28& r, const g1_proj28& a, const g1_proj28& b) {
   r.z = widen28<C28>(zo);
 }
 
+// ---- the same complete addition split over the lanes of a group ("cooperative" form) ---------------------------------
+// The bucket reduction and fix-up kernels are latency bound: few independent additions, each a ~6 600-instruction chain
+// on one lane.  Algorithm 7 is six independent products followed by three independent two-term products, so a group of
+// lanes that all hold both points can run it as  stage A: lane r computes product r (r < 6);  stage B: lane r computes
+// output coordinate r (r < 3)  -- a chain of one mul28 + one mul28_2 instead of 6 + 3.  The stages are pure functions of
+// (role, operands) with role-independent types (operands are widened to the union of the bounds of the candidates a slot
+// can receive, selected limb by limb), so the lanes of a wave stay convergent; the exchange of the six products between
+// the lanes is the caller's (shuffles on the GPU, a loop over roles in the host check).
+using CoopProd = F28<MASK28, 2>;                                   // a stage-A product
+using CoopSum = decltype(add28(C28(), C28()));                      // a coordinate or a sum of two
+
+template <class U, class A, class B, class C>
+BP_HD U select3_28(uint32_t which, const A& a, const B& b, const C& c) {
+  const U ua = widen28<U>(a), ub = widen28<U>(b), uc = widen28<U>(c);
+  U r;
+#pragma unroll
+  for (int i = 0; i < N28; i++) r.l[i] = which == 0 ? ua.l[i] : (which == 1 ? ub.l[i] : uc.l[i]);
+  return r;
+}
+template <class A, class B, class C>
+struct Union28 {
+  static constexpr uint64_t lb = A::limb_bound > B::limb_bound ? (A::limb_bound > C::limb_bound ? A::limb_bound : C::limb_bound)
+                                                               : (B::limb_bound > C::limb_bound ? B::limb_bound : C::limb_bound);
+  static constexpr uint32_t vb = A::value_bound > B::value_bound ? (A::value_bound > C::value_bound ? A::value_bound : C::value_bound)
+                                                                 : (B::value_bound > C::value_bound ? B::value_bound : C::value_bound);
+  using type = F28<lb, vb>;
+};
+
+// stage A: role 0..5 -> X1 X2, Y1 Y2, Z1 Z2, (X1+Y1)(X2+Y2), (Y1+Z1)(Y2+Z2), (X1+Z1)(X2+Z2); other roles -> 0
+BP_HD CoopProd g1_add28_coop_a(uint32_t role, const g1_proj28& a, const g1_proj28& b) {
+  const bool ux = role == 0 || role == 3 || role == 5, uy = role == 1 || role == 3 || role == 4, uz = role == 2 || role == 4 || role == 5;
+  CoopSum u, v;
+#pragma unroll
+  for (int i = 0; i < N28; i++) {
+    u.l[i] = (ux ? a.x.l[i] : 0u) + (uy ? a.y.l[i] : 0u) + (uz ? a.z.l[i] : 0u);      // at most two of the three are selected
+    v.l[i] = (ux ? b.x.l[i] : 0u) + (uy ? b.y.l[i] : 0u) + (uz ? b.z.l[i] : 0u);
+  }
+  return widen28<CoopProd>(mul28(u, v));
+}
+// stage B: role 0, 1, 2 -> X3, Y3, Z3 from the six products p[0..5] of stage A
+BP_HD C28 g1_add28_coop_b(uint32_t role, const CoopProd p[6]) {
+  const CoopProd &t0 = p[0], &t1 = p[1], &t2 = p[2];
+  auto t3 = norm28(sub28<8, 30>(p[3], add28(t0, t1)));
+  auto t4 = norm28(sub28<8, 30>(p[4], add28(t1, t2)));
+  auto y3a = norm28(sub28<8, 30>(p[5], add28(t0, t2)));
+  auto t0x3 = norm28(mulk28<3>(t0));
+  auto t2b = norm28(mulk28<12>(t2));                               // 3b t2
+  auto z3 = norm28(add28(t1, t2b));
+  auto t1s = norm28(sub28<32, 29>(t1, t2b));
+  auto y3 = norm28(mulk28<12>(y3a));
+  auto ny3 = norm28(neg28<128, 29>(y3));
+  //            first product      second product (the large-valued factors share slot s)
+  // role 0:  X3 = t3 t1s     +   t4 (-y3)
+  // role 1:  Y3 = z3 t1s     +   t0x3 y3
+  // role 2:  Z3 = t0x3 t3    +   t4 z3
+  using P = typename Union28<decltype(t3), decltype(z3), decltype(t0x3)>::type;
+  using Q = typename Union28<decltype(t1s), decltype(t1s), decltype(t3)>::type;
+  using R = typename Union28<decltype(t4), decltype(t0x3), decltype(t4)>::type;
+  using S = typename Union28<decltype(ny3), decltype(y3), decltype(z3)>::type;
+  const uint32_t w = role < 3 ? role : 2;
+  return widen28<C28>(mul28_2(select3_28<P>(w, t3, z3, t0x3), select3_28<Q>(w, t1s, t1s, t3), select3_28<R>(w, t4, t0x3, t4),
+                              select3_28<S>(w, ny3, y3, z3)));
+}
+
 // r = 2 p   -- RCB Algorithm 9 (g1.rs:638-667)
 BP_HD void g1_double28(g1_proj28& r, const g1_proj28& p) {
   auto t0 = mul28(p.y, p.y);

@@ -54,6 +54,21 @@ void hc_g1_28_add(uint32_t* r, const uint32_t* a_in, const uint32_t* b_in, int r
   for (int i = 0; i < reps; i++) g1_add28(x, x, y);
   g1_proj out = g1_proj_from_28(x); memcpy(r, &out, 144);
 }
+// the same chain through the cooperative form: stage A per role, "exchange", stage B per role (what 8 GPU lanes do together)
+void hc_g1_28_add_coop(uint32_t* r, const uint32_t* a_in, const uint32_t* b_in, int reps) {
+  g1_proj a, b; memcpy(&a, a_in, 144); memcpy(&b, b_in, 144);
+  g1_proj28 x = to28(a), y = to28(b);
+  for (int i = 0; i < reps; i++) {
+    CoopProd prod[6];
+    for (uint32_t role = 0; role < 6; role++) prod[role] = g1_add28_coop_a(role, x, y);
+    CoopProd idle = g1_add28_coop_a(7, x, y);                      // lanes 6, 7 select nothing
+    for (int j = 0; j < N28; j++) if (idle.l[j] != 0) prod[0].l[0] ^= 1;   // would corrupt the result
+    g1_proj28 nx;
+    nx.x = g1_add28_coop_b(0, prod); nx.y = g1_add28_coop_b(1, prod); nx.z = g1_add28_coop_b(2, prod);
+    x = nx;
+  }
+  g1_proj out = g1_proj_from_28(x); memcpy(r, &out, 144);
+}
 void hc_g1_28_double(uint32_t* r, const uint32_t* a_in, int reps) {
   g1_proj a; memcpy(&a, a_in, 144);
   g1_proj28 x = to28(a);

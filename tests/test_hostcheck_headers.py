@@ -161,6 +161,12 @@ def test_g1_28_add_double_mul_small(hc):
         for b in pts:
             assert O.g1_eq(run("hc_g1_28_add", [C.c_void_p, C.c_void_p, C.c_int], a, b, 1), O.g1_add(a, b))
         assert O.g1_eq(run("hc_g1_28_add", [C.c_void_p, C.c_void_p, C.c_int], a, O.g1_neg(a), 1), O.g1_identity())
+    # the cooperative (lane-split) form of the same addition: every pair incl. identity / doubling / inverse, and a long chain
+    for a in pts:
+        for b in pts + [O.g1_neg(a)]:
+            assert O.g1_eq(run("hc_g1_28_add_coop", [C.c_void_p, C.c_void_p, C.c_int], a, b, 1), O.g1_add(a, b))
+    assert O.g1_eq(run("hc_g1_28_add_coop", [C.c_void_p, C.c_void_p, C.c_int], pts[3], pts[4], 150),
+                   O.g1_add(pts[3], O.g1_mul(pts[4], O.fr_from_int(150))))
     # long chains keep the bounds: a + 150 b, 2^40 a
     a, b = pts[3], pts[4]
     assert O.g1_eq(run("hc_g1_28_add", [C.c_void_p, C.c_void_p, C.c_int], a, b, 150), O.g1_add(a, O.g1_mul(b, O.fr_from_int(150))))
