@@ -544,6 +544,12 @@ class Circuit:
     def free(self):
         self.ctx.check(self.ctx._lib.bp_circuit_free(self.ctx._h, self.handle), "bp_circuit_free")
 
+    def commitments(self, setup):
+        """Verifier::new (src/verifier.rs:61-68): {column name: 96-byte commitment of its coefficient form}"""
+        out = np.zeros(768, dtype=np.uint8)
+        self.ctx.check(self.ctx._lib.bp_circuit_commitments(self.ctx._h, setup.handle, self.handle, out.ctypes.data), "bp_circuit_commitments")
+        return {k: bytes(out[96 * i: 96 * i + 96]) for i, k in enumerate(CIRCUIT_COLUMNS)}
+
 
 class Prover:
     """src/prover.rs:50-175 behind bp_prove: rounds 1-5 on the GPU, Fiat-Shamir transcript on the host"""

@@ -873,6 +873,14 @@ int bp_circuit_free(bp_ctx* ctx, uint64_t handle) {
   ctx->circuits.erase(it);
   return BP_OK;
 }
+int bp_circuit_commitments(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_handle, uint8_t out768[768]) {
+  if (!ctx || !out768) return BP_ERR_INVALID_ARG;
+  auto it = ctx->circuits.find(circuit_handle);
+  if (it == ctx->circuits.end()) return fail(ctx, BP_ERR_INVALID_ARG, "unknown circuit handle", hipSuccess, __FILE__, __LINE__);
+  const size_t n = (size_t)1 << it->second.log_n;
+  for (int k = 0; k < 8; k++) BP_TRY(bp_commit_device(ctx, srs_handle, it->second.coef + (size_t)k * n, n, BP_BASIS_MONOMIAL, out768 + 96 * k));
+  return BP_OK;
+}
 int bp_prove(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_handle, const void* a, const void* b, const void* c, const void* public_input,
              int scalar_fmt, int witness_on_device, const uint8_t blinders[352], uint8_t proof[624]) {
   if (!ctx || !a || !b || !c || !blinders || !proof || !fmt_ok(scalar_fmt)) return BP_ERR_INVALID_ARG;

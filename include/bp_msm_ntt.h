@@ -183,6 +183,9 @@ int  bp_commit(bp_ctx* ctx, uint64_t srs_handle, const void* coeffs, size_t n, i
 int  bp_circuit_load(bp_ctx* ctx, uint32_t log_n, const void* const columns[8], int scalar_fmt, int columns_on_device,
                      uint64_t* circuit_handle);
 int  bp_circuit_free(bp_ctx* ctx, uint64_t circuit_handle);
+/* The verifier's preprocessing (src/verifier.rs:61-68: i_ntt + Setup::commit of each column): commitments to
+ * QL QR QM QO QC S1 S2 S3 in that order, 8 x 96 bytes (uncompressed affine), from the coefficient forms already in HBM. */
+int  bp_circuit_commitments(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_handle, uint8_t out768[768]);
 /* One proof.  a, b, c: the witness as the three Lagrange wire columns the reference builds at prover.rs:186-227;
  * public_input: the Lagrange column of prover.rs:114-127 (-x_i in the first rows, zero elsewhere), NULL = all zero;
  * 2^log_n scalars each.  blinders: b1..b11 of prover.rs:110 as 11 x 32 canonical little-endian bytes -- an input here

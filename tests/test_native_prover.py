@@ -66,6 +66,7 @@ def test_toy_circuit_native_proof_is_the_golden_proof():
     # verifier (src/verifier.rs:80-209), challenges recomputed from the proof bytes
     gpu = PR.GpuBackend(setup)
     vk = {k: decode(gpu.commit(gpu.Polynomial(gpu.i_ntt_381(PR.SV(pk[k])), gpu.MONO))) for k in pk}
+    assert {k: decode(v) for k, v in circuit.commitments(setup).items()} == vk      # Verifier::new through the library
     pts, ev = _split(blob)
     assert g1_only_verify(n, tau, pts, ev, _challenges(blob), vk, [80])
     assert not g1_only_verify(n, tau, pts, ev, _challenges(blob), vk, [81])
@@ -133,6 +134,7 @@ def test_synthetic_circuit_native_vs_oracle_restatement(logn):
     assert blob == blob_c
     dev = PR.GpuDeviceBackend(setup)
     vk = {k: decode(dev.commit(dev.i_ntt_poly(dev.Polynomial(PR.SV(pk[k]), dev.LAG)))) for k in pk}
+    assert {k: decode(v) for k, v in circuit.commitments(setup).items()} == vk
     assert g1_only_verify(n, tau, *_split(blob), _challenges(blob), vk, [])
     # HBM-resident witness: same bytes
     import torch
