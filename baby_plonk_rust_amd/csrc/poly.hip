@@ -1,6 +1,8 @@
 // poly.hip -- host drivers of the polynomial kernels (poly_kernels.cuh).
 #include <string.h>
 
+#include <algorithm>
+
 #include "ctx.hpp"
 #include "poly_kernels.cuh"
 
@@ -70,7 +72,7 @@ int fr_nonzero_stats_run(bp_ctx* ctx, const fr_t* d_a, size_t n, size_t lo, size
   unsigned long long* d_out;
   BP_TRY(ws_get(ctx, "poly.nzstats", 16, (void**)&d_out));
   BP_HIP(ctx, hipMemsetAsync(d_out, 0, 16, ctx->stream));
-  if (n) hipLaunchKernelGGL(fr_nonzero_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_a, n, lo, hi, d_out);
+  if (n) hipLaunchKernelGGL(fr_nonzero_stats, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, ctx->stream, d_a, n, lo, hi, d_out);
   unsigned long long h[2];
   BP_HIP(ctx, hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, ctx->stream));
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));

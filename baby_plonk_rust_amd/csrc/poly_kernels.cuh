@@ -284,19 +284,30 @@ __global__ void __launch_bounds__(256) grand_product_combine(const fr_t* __restr
 
 // ---- helpers of the device-resident polynomial pipeline -------------------------------------------------------
 // out[0] = 1 + index of the last non-zero element (0 when all are zero); out[1] = number of non-zero elements in [lo, hi)
+// grid-stride; one atomic pair per workgroup (both results land on the same two words, so per-wave atomics of a
+// 2^22-element launch serialise into ~0.5 ms)
 __global__ void __launch_bounds__(256) fr_nonzero_stats(const fr_t* __restrict__ a, size_t n, size_t lo, size_t hi, unsigned long long* __restrict__ out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool nz = false;
-  if (i < n) {
+  __shared__ unsigned long long s_last[4], s_cnt[4];
+  unsigned long long last = 0, cnt = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     fr_t v = load_fr(&a[i]);
-    nz = !big_is_zero(v);
+    if (!big_is_zero(v)) {
+      last = i + 1;                                              // indices grow along the loop
+      cnt += (i >= lo && i < hi) ? 1 : 0;
+    }
   }
-  // one atomic pair per wave instead of one per element
-  const unsigned long long mask = __ballot(nz), in_range = __ballot(nz && i >= lo && i < hi);
-  if ((threadIdx.x & 63) == 0 && mask) {
-    const size_t wave_base = i;                                  // lane 0 of the wave
-    atomicMax(&out[0], (unsigned long long)(wave_base + (64 - __clzll(mask))));
-    if (in_range) atomicAdd(&out[1], (unsigned long long)__popcll(in_range));
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    unsigned long long l2 = __shfl_xor(last, d, 64), c2 = __shfl_xor(cnt, d, 64);
+    last = l2 > last ? l2 : last;
+    cnt += c2;
+  }
+  if ((threadIdx.x & 63) == 0) { s_last[threadIdx.x >> 6] = last; s_cnt[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) { last = s_last[w] > last ? s_last[w] : last; cnt += s_cnt[w]; }
+    if (last) atomicMax(&out[0], last);
+    if (cnt) atomicAdd(&out[1], cnt);
   }
 }
 // out[i] = a[i] * w^i   (p(x) -> p(w x); prover.rs:661-674 monomial_z_to_z_omega)
