@@ -310,22 +310,44 @@ __global__ void __launch_bounds__(256) srs_to28(const g1_affine* __restrict__ in
   for (int j = 0; j < 7; j++) q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
 
-// Fixed-base window tables: table[w * n + i] = 2^(c w) * P_i for w < W, affine, unsaturated limbs.  One lane per
-// point walks its doubling chain; built once per SRS (bp_srs_precompute), so clarity beats speed here.
+// Fixed-base window tables: table[w * n + i] = 2^(c w) * P_i for w < W, affine, unsaturated limbs.  One lane per point
+// walks its doubling chain; the affine normalisations of a group of TABLE_GROUP rows share one field inversion
+// (Montgomery's trick, as G1Projective::batch_normalize does, g1.rs:806-839).  Built once per SRS.
+constexpr int TABLE_GROUP = 16;
 __global__ void __launch_bounds__(256) srs_window_tables(const g1_affine* __restrict__ in, size_t n, uint32_t c, uint32_t W,
                                                          g1_affine28* __restrict__ table) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  g1_proj p = g1_from_affine(load_affine(&in[i]));
-  for (uint32_t w = 1; w < W; w++) {
-    for (uint32_t j = 0; j < c; j++) g1_double(p, p);
-    g1_affine28 r = g1_affine_to_28(g1_to_affine(p));          // identity stays (0, 0)
-    uint4* q = reinterpret_cast<uint4*>(&table[(size_t)w * n + i]);
-    uint32_t wd[28];
+  const g1_affine a = load_affine(&in[i]);
+  const bool inf = g1_affine_is_identity(a);           // stays the identity in every row; a point of prime order never doubles to it
+  g1_proj p = g1_from_affine(a);
+  g1_proj row[TABLE_GROUP];
+  fp_t prefix[TABLE_GROUP];                             // prefix[j] = z_0 z_1 ... z_j of the group
+  for (uint32_t w0 = 1; w0 < W; w0 += TABLE_GROUP) {
+    const uint32_t cnt = W - w0 < (uint32_t)TABLE_GROUP ? W - w0 : (uint32_t)TABLE_GROUP;
+    for (uint32_t j = 0; j < cnt; j++) {
+      for (uint32_t d = 0; d < c; d++) g1_double(p, p);
+      row[j] = p;
+      if (j == 0) prefix[0] = p.z; else Fp::mul(prefix[j], prefix[j - 1], p.z);
+    }
+    fp_t inv;
+    fp_invert(inv, prefix[cnt - 1]);                    // 0 -> 0 for the identity
+    for (uint32_t j = cnt; j-- > 0;) {
+      fp_t zinv;
+      if (j) Fp::mul(zinv, inv, prefix[j - 1]); else zinv = inv;
+      Fp::mul(inv, inv, row[j].z);
+      g1_affine r;
+      Fp::mul(r.x, row[j].x, zinv);
+      Fp::mul(r.y, row[j].y, zinv);
+      if (inf) { r.x = Fp::zero(); r.y = Fp::zero(); }
+      const g1_affine28 r28 = g1_affine_to_28(r);
+      uint4* q = reinterpret_cast<uint4*>(&table[(size_t)(w0 + j) * n + i]);
+      uint32_t wd[28];
 #pragma unroll
-    for (int j = 0; j < N28; j++) { wd[j] = r.x.l[j]; wd[N28 + j] = r.y.l[j]; }
+      for (int t = 0; t < N28; t++) { wd[t] = r28.x.l[t]; wd[N28 + t] = r28.y.l[t]; }
 #pragma unroll
-    for (int j = 0; j < 7; j++) q[j] = make_uint4(wd[4 * j], wd[4 * j + 1], wd[4 * j + 2], wd[4 * j + 3]);
+      for (int t = 0; t < 7; t++) q[t] = make_uint4(wd[4 * t], wd[4 * t + 1], wd[4 * t + 2], wd[4 * t + 3]);
+    }
   }
 }
 
