@@ -495,9 +495,12 @@ class Setup:
     (bp_srs_precompute) unless tables=False or BP_SRS_TABLES=0."""
 
     def __init__(self, handle, ctx, tables=True):
-        self.handle, self.ctx = handle, ctx
+        self.handle, self.ctx, self.tables_error = handle, ctx, None
         if tables and os.environ.get("BP_SRS_TABLES", "1") != "0":
-            ctx.srs_precompute(handle, 0)
+            try:
+                ctx.srs_precompute(handle, 0)
+            except BpError as e:          # tables are an optimisation (they need windows x 112 B per point of HBM): commits work without
+                self.tables_error = e
 
     @staticmethod
     def generate_srs(powers, tau_int, ctx=None, tables=True):

@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 # The dominant kernel is integer-issue bound: second ceiling from this repo's own measurements --
 # tools/ubench_int.hip (profiles/r01_ubench_int_issue_rates.txt): v_mad_u64_u32 issues at 57 lanes/clk/CU, like a carry add
 VALU_PEAK_LANE_INSTR_S = 57.0 * 256 * 2.4e9
-ACC_INSTR_PER_ADD = 4900         # VALU instructions per mixed addition in msm_accumulate's loop body (ISA count; 4311 are v_mad_u64_u32)
+ACC_INSTR_PER_ADD = 5000         # VALU instructions per iteration of msm_accumulate's loop (hipcc -S: 5006, of which 3729 v_mad_u64_u32)
 MSM_BYTES_PER_UNIT = 128         # 32 B scalar + 96 B affine point per scalar-mul
 NTT_BYTES_PER_UNIT = 64          # 32 B read + 32 B write per element
 GOLDEN = 0x9E3779B97F4A7C15
@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--prove-log-n", type=int, default=20, help="gates of the synthetic circuit of the proofs/s leg = 2^prove_log_n (0 = skip)")
     ap.add_argument("--prove-reps", type=int, default=3)
     ap.add_argument("--prove-streams", type=int, default=2, help="concurrent provers per GPU in the proofs/s throughput figure")
+    ap.add_argument("--other-sizes", type=int, nargs="*", default=[16, 24], help="log2 sizes also measured at N = 1 (MSM with tables + NTT, 3 runs each)")
     ap.add_argument("--no-tables", action="store_true", help="headline = MSM on the raw SRS, no fixed-base window tables")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the N > 1 control flow on a box with fewer GPUs than ranks)")
@@ -185,6 +186,38 @@ def main():
     barrier()
     ntt_elapsed = time.perf_counter() - t1
     ntt_passes = ctx.ntt_stats()["passes"]
+
+    # ---- the metric's other sizes (BASELINE: "at 2^20 / 2^24", 2^16 = configs[1]); single GPU only, best of 3 runs ----
+    sizes = {}
+    if world == 1:
+        for lg in args.other_sizes:
+            if lg == args.log_n or lg < 10 or lg > 26:
+                continue
+            m = 1 << lg
+            ctx.srs_free(srs)
+            del scal, vec
+            torch.cuda.empty_cache()
+            srs = ctx.srs_generate_progression(m, A0, D0)
+            if not args.no_tables:
+                ctx.srs_precompute(srs, 0)
+            scal = torch.empty(m * 4, dtype=torch.int64, device=dev)
+            ctx.synthetic_scalars_device(scal.data_ptr(), m, (0x5EED0000 + lg) & (2**64 - 1))
+            vec = torch.empty(m * 4, dtype=torch.int64, device=dev)
+            ctx.synthetic_scalars_device(vec.data_ptr(), m, (0xF40000 + lg) & (2**64 - 1))
+            best_msm, best_ntt = None, None
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ctx.msm_partial(srs, None, device_ptr=scal.data_ptr(), n=m)
+                dt = time.perf_counter() - t0
+                best_msm = dt if best_msm is None or dt < best_msm else best_msm
+                ctx.ntt_device(vec.data_ptr(), lg)
+                dn = ctx.ntt_stats()["device_ms"] * 1e-3
+                best_ntt = dn if best_ntt is None or dn < best_ntt else best_ntt
+            st = ctx.msm_stats()
+            sizes["2^%d" % lg] = {"msm_scalar_muls_per_s": m / best_msm, "msm_ms": 1e3 * best_msm, "msm_accumulate_ms": st["accumulate_ms"],
+                                  "window_bits": st["window_bits"], "tables": st["tables"],
+                                  "ntt_elements_per_s": m / best_ntt, "ntt_device_ms": 1e3 * best_ntt, "ntt_passes": ctx.ntt_stats()["passes"]}
 
     # ---- prover leg (BASELINE configs[4]): independent proofs per GPU (replicas, no collective) ----
     prove = None
@@ -290,6 +323,8 @@ def main():
                                  "kernel_ms": ntt_t * 1e3, "algorithmic_bytes_per_launch": NTT_BYTES_PER_UNIT * nn}},
             "result_sha": __import__("hashlib").sha256(result).hexdigest()[:16],
         }
+        if sizes:
+            line["other_sizes"] = sizes
         if prove:
             line["prove"] = {"metric": "plonk_proofs_per_s", "value": world * prove["streams"] * args.prove_reps / prove["elapsed"], "unit": "proofs/s",
                              "gates": 1 << args.prove_log_n, "concurrent_provers_per_gpu": prove["streams"],
