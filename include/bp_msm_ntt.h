@@ -190,7 +190,8 @@ int  bp_circuit_commitments(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_h
  * public_input: the Lagrange column of prover.rs:114-127 (-x_i in the first rows, zero elsewhere), NULL = all zero;
  * 2^log_n scalars each.  blinders: b1..b11 of prover.rs:110 as 11 x 32 canonical little-endian bytes -- an input here
  * (prove_with_blinding), because the reference draws them from thread_rng and is therefore not reproducible.
- * The SRS needs 2^log_n + 6 points (verify_proof_test.rs:16).  Challenges come from the reference's transcript
+ * The SRS should hold 2^log_n + 6 points (verify_proof_test.rs:16); a shorter one truncates the commitments the way
+ * Setup::commit's zip does (msm.rs:29), as in the reference.  Challenges come from the reference's transcript
  * (src/transcript.rs:4-86; merlin 3.0.0 restated on the host).
  * proof: 9 x 48-byte compressed G1 points in Proof field order (verifier.rs:23-40: a_1 b_1 c_1 z_1 t_lo_1 t_mid_1
  * t_hi_1 w_zeta_1 w_zeta_omega_1), then a_bar b_bar c_bar s1_bar s2_bar z_omega_bar as 32-byte little-endian.

@@ -103,10 +103,12 @@ def test_witness_that_does_not_satisfy_the_circuit_is_rejected():
     with pytest.raises(bp.BpError) as e:                    # wrong public input: PI does not cancel e
         prover.prove_with_blinding(*good, PR.SV([(-81) % Q] + [0] * (n - 1)), blinders)
     assert e.value.code == -11
-    short = bp.Setup.generate_srs(n + 5, 101)               # SRS one power short
-    with pytest.raises(bp.BpError) as e:
-        bp.Prover(short, circuit).prove_with_blinding(*good, PR.SV(public), blinders)
-    assert e.value.code == -6
+    # an SRS that is too short does not panic in the reference: Setup::commit zips and truncates (msm.rs:29); same bytes here
+    from oracle import oracle as O
+    from tests.test_gpu_prover_rounds import prove_with_blinding
+    short = bp.Setup.generate_srs(n + 3, 101)
+    cpu = PR.OracleBackend(O.proj_from_bytes96(short.powers_of_x()))
+    assert bp.Prover(short, circuit).prove_with_blinding(*good, PR.SV(public), blinders) == prove_with_blinding(cpu, n, cols, pk, public, blinders)[2]
     with pytest.raises(bp.BpError):
         prover.prove_with_blinding(*good, PR.SV(public), blinders[:10])
     with pytest.raises(bp.BpError):
@@ -141,4 +143,51 @@ def test_synthetic_circuit_native_vs_oracle_restatement(logn):
     t = [torch.from_numpy(PR.SV(c).view(np.int64)).cuda() for c in cols]
     torch.cuda.synchronize()
     assert prover.prove_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, blinders) == blob
+    circuit.free()
+
+
+def _circuit_from_rows(wires, selectors, n):
+    """what Program / Assembly produce for a list of gate rows: wire-name rows -> value columns are the
+    caller's; sigma columns join equal names (empty cells included) into one cycle each, program.rs:92-99"""
+    rows = list(wires) + [(None, None, None)] * (n - len(wires))
+    pk = {k: [x % Q for x in v] + [0] * (n - len(v)) for k, v in selectors.items()}
+    om = M.omega(n)
+    groups = {}
+    for row, ws in enumerate(rows):
+        for col, name in enumerate(ws):
+            groups.setdefault(name, []).append((col, row))
+    sig = [[0] * n for _ in range(3)]
+    for cells in groups.values():
+        for j, (col, row) in enumerate(cells):
+            ncol, nrow = cells[(j + 1) % len(cells)]
+            sig[col][row] = (ncol + 1) * pow(om, nrow, Q) % Q
+    pk.update(s1=sig[0], s2=sig[1], s3=sig[2])
+    return rows, pk
+
+
+@pytest.mark.gpu
+def test_reference_prover_unit_test_configurations():
+    """src/prover.rs:682-756: `initilization()` (program ["e public"], e = 3, SRS = 14 powers of tau = 1 -- every SRS point is G)
+    and `test_prove` (the toy program on 14 powers of tau = 2), with fixed blinders instead of thread_rng"""
+    from oracle import oracle as O
+    from tests.test_gpu_prover_rounds import prove_with_blinding, toy_circuit
+    n = 8
+    blinders = [random.Random(3).randrange(1, Q) for _ in range(11)]
+    # initilization(): one row (e, -, -) with ql = 1 and PI = -e
+    rows, pk = _circuit_from_rows([("e", None, None)], dict(ql=[1], qr=[0], qm=[0], qo=[0], qc=[0]), n)
+    cols = [[3 if r[j] == "e" else 0 for r in rows] for j in range(3)]
+    public = [(-3) % Q] + [0] * (n - 1)
+    setup = bp.Setup.generate_srs(n + 6, 1)
+    circuit = bp.Circuit({k: PR.SV(v) for k, v in pk.items()})
+    blob = bp.Prover(setup, circuit).prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), PR.SV(public), blinders)
+    cpu = PR.OracleBackend(O.proj_from_bytes96(setup.powers_of_x()))
+    assert blob == prove_with_blinding(cpu, n, cols, pk, public, blinders)[2]
+    circuit.free()
+    # test_prove: the toy program, tau = 2
+    cols, pk, public = toy_circuit(n)
+    setup = bp.Setup.generate_srs(n + 6, 2)
+    circuit = bp.Circuit({k: PR.SV(v) for k, v in pk.items()})
+    blob = bp.Prover(setup, circuit).prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), PR.SV(public), blinders)
+    cpu = PR.OracleBackend(O.proj_from_bytes96(setup.powers_of_x()))
+    assert blob == prove_with_blinding(cpu, n, cols, pk, public, blinders)[2]
     circuit.free()
