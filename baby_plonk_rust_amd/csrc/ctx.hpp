@@ -34,6 +34,7 @@ struct CircuitEntry {
   fr_t* coef = nullptr;       // 8 x n coefficient forms (i_ntt, prover.rs:379-386)
   fr_t* coset = nullptr;      // 9 x 4n evaluations on the quotient coset g <w_4n> (the eight columns + L1)
   fr_t* coset_x = nullptr;    // 4n coset points g w_4n^i
+  fr_t* roots = nullptr;      // w_n^i, i < n (roots_of_unity(group_order), prover.rs:282)
   fr_t* g_pow = nullptr;      // g^i, i < n + 8
   fr_t* ginv_pow = nullptr;   // g^-i, i < 4n
   fr_t zh_inv[4];             // 1 / (X^n - 1) on the coset (period 4)
@@ -113,7 +114,8 @@ int fr_scale_powers_run(bp_ctx* ctx, const fr_t* d_a, size_t n, const fr_t& w, f
 int fr_synthetic_run(bp_ctx* ctx, fr_t* d_out, size_t n, uint64_t seed);
 int fr_scan_mul_run(bp_ctx* ctx, const fr_t* d_in, size_t n, int reverse, int inclusive, fr_t* d_out, fr_t* d_total);
 int grand_product_run(bp_ctx* ctx, const fr_t* a, const fr_t* b, const fr_t* c, const fr_t* s1, const fr_t* s2, const fr_t* s3, size_t n,
-                      const fr_t& beta, const fr_t& gamma, const fr_t& k1, const fr_t& k2, const fr_t& root, fr_t* d_z);
+                      const fr_t& beta, const fr_t& gamma, const fr_t& k1, const fr_t& k2, const fr_t& root, fr_t* d_z,
+                      const fr_t* d_roots = nullptr);
 int roots_run(bp_ctx* ctx, const fr_t& w, size_t n, fr_t* d_out);
 int srs_decode_run(bp_ctx* ctx, const uint8_t* d_bytes, size_t n, g1_affine* d_out);
 int srs_encode_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, uint8_t* d_bytes);

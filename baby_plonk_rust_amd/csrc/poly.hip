@@ -52,7 +52,7 @@ int poly_div_run(bp_ctx* ctx, fr_t* d_a, size_t na, const fr_t* d_b, size_t nb, 
                        lead_inv, K, chunks, d_q, head);
     if (chunks > 1) {
       if (chunks > 64 && m <= 4096)          // long chains: a workgroup per chain
-        hipLaunchKernelGGL(poly_div_binomial_carry_wg, dim3((unsigned)m), dim3(256), 512 * sizeof(fr_t), ctx->stream, nq, m, f, K, chunks,
+        hipLaunchKernelGGL(poly_div_binomial_carry_wg, dim3((unsigned)m), dim3(1024), 2048 * sizeof(fr_t), ctx->stream, nq, m, f, K, chunks,
                            head, carry);
       else
         hipLaunchKernelGGL(poly_div_binomial_carry, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, nq, m, f, K, chunks,
@@ -103,16 +103,17 @@ int fr_scan_mul_run(bp_ctx* ctx, const fr_t* d_in, size_t n, int reverse, int in
 
 // prover.rs:279-319 on device-resident Montgomery columns; d_z receives n values (z_0 .. z_{n-1})
 int grand_product_run(bp_ctx* ctx, const fr_t* a, const fr_t* b, const fr_t* c, const fr_t* s1, const fr_t* s2, const fr_t* s3, size_t n,
-                      const fr_t& beta, const fr_t& gamma, const fr_t& k1, const fr_t& k2, const fr_t& root, fr_t* d_z) {
+                      const fr_t& beta, const fr_t& gamma, const fr_t& k1, const fr_t& k2, const fr_t& root, fr_t* d_z, const fr_t* d_roots) {
   if (n == 0) return BP_OK;
   fr_t *roots, *num, *den, *pn, *sd, *totals;
-  BP_TRY(ws_get(ctx, "gp.roots", n * sizeof(fr_t), (void**)&roots));
+  if (d_roots) roots = const_cast<fr_t*>(d_roots);           // the caller keeps roots_of_unity(n) resident (read-only here)
+  else BP_TRY(ws_get(ctx, "gp.roots", n * sizeof(fr_t), (void**)&roots));
   BP_TRY(ws_get(ctx, "gp.num", n * sizeof(fr_t), (void**)&num));
   BP_TRY(ws_get(ctx, "gp.den", n * sizeof(fr_t), (void**)&den));
   BP_TRY(ws_get(ctx, "gp.pn", n * sizeof(fr_t), (void**)&pn));
   BP_TRY(ws_get(ctx, "gp.sd", n * sizeof(fr_t), (void**)&sd));
   BP_TRY(ws_get(ctx, "gp.totals", 2 * sizeof(fr_t), (void**)&totals));
-  BP_TRY(roots_run(ctx, root, n, roots));                                      // roots_of_unity(group_order), prover.rs:282
+  if (!d_roots) BP_TRY(roots_run(ctx, root, n, roots));                        // roots_of_unity(group_order), prover.rs:282
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(grand_product_terms, dim3(blocks), dim3(256), 0, ctx->stream, a, b, c, s1, s2, s3, roots, n, beta, gamma, k1, k2, num, den);
   BP_TRY(fr_scan_mul_run(ctx, num, n, 0, 0, pn, totals));                      // exclusive prefix products of the numerators

@@ -108,10 +108,10 @@ __global__ void __launch_bounds__(256) poly_div_binomial_carry(size_t nq, size_t
   }
 }
 // Long chains (small m, e.g. the linear divisors x - zeta of prover.rs:623-638): one workgroup per chain.  Lane t owns
-// the run of chunks [t*S, (t+1)*S): it first composes its run into an affine map carry_out = A * carry_in + B, lane 0
-// chains the 256 maps, then every lane replays its run writing the per-chunk carries.  Sequential depth 2S + 256
-// instead of the number of chunks.
-__global__ void __launch_bounds__(256) poly_div_binomial_carry_wg(size_t nq, size_t m, fr_t f, uint32_t K, size_t chunks_per_chain,
+// the run of chunks [t*S, (t+1)*S): it first composes its run into an affine map carry_out = A * carry_in + B, the maps
+// are scanned across the lanes, then every lane replays its run writing the per-chunk carries.  Sequential depth
+// 2S + log2(lanes) compositions instead of the number of chunks.
+__global__ void __launch_bounds__(1024) poly_div_binomial_carry_wg(size_t nq, size_t m, fr_t f, uint32_t K, size_t chunks_per_chain,
                                                                    const fr_t* __restrict__ chunk_head, fr_t* __restrict__ carry) {
   const size_t r = blockIdx.x;
   if (r >= m || r >= nq) return;
@@ -129,21 +129,28 @@ __global__ void __launch_bounds__(256) poly_div_binomial_carry_wg(size_t nq, siz
     Fr::mul(B, B, fp);
     Fr::add(B, B, head);
   }
-  fr_t* buf = reinterpret_cast<fr_t*>(poly_lds_raw);         // [0..255] = A, [256..511] = B, then carry-in per lane
-  buf[threadIdx.x] = A;
-  buf[blockDim.x + threadIdx.x] = B;
+  // inclusive scan of the lanes' affine maps (Hillis-Steele in LDS): after it, B of lane t is the carry leaving lane t's run
+  fr_t* bufA = reinterpret_cast<fr_t*>(poly_lds_raw);
+  fr_t* bufB = bufA + blockDim.x;
+  bufA[threadIdx.x] = A;
+  bufB[threadIdx.x] = B;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    fr_t c = Fr::zero();
-    for (uint32_t t = 0; t < blockDim.x; t++) {
-      fr_t a = buf[t], b = buf[blockDim.x + t], nc;
-      buf[t] = c;                            // carry into lane t's run
-      Fr::mul(nc, a, c);
-      Fr::add(c, nc, b);
+  for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
+    const bool has = threadIdx.x >= d;
+    fr_t a1, b1;
+    if (has) { a1 = bufA[threadIdx.x - d]; b1 = bufB[threadIdx.x - d]; }
+    __syncthreads();
+    if (has) {                                  // (A, B) after (a1, b1):  x -> A (a1 x + b1) + B
+      fr_t t;
+      Fr::mul(t, A, b1);
+      Fr::add(B, B, t);
+      Fr::mul(A, A, a1);
+      bufA[threadIdx.x] = A;
+      bufB[threadIdx.x] = B;
     }
+    __syncthreads();
   }
-  __syncthreads();
-  fr_t c = buf[threadIdx.x];
+  fr_t c = threadIdx.x ? bufB[threadIdx.x - 1] : Fr::zero();          // carry into this lane's run
   for (size_t ck = ck0; ck < ck1; ck++) {
     store_fr(&carry[ck * m + r], c);
     const size_t j_hi = len > ck * K ? len - ck * K : 0;

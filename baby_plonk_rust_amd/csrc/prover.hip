@@ -187,9 +187,11 @@ static int circuit_fill(bp_ctx* ctx, const fr_t* d_lag, CircuitEntry& e) {
   BP_HIP(ctx, hipMalloc((void**)&e.coset, (size_t)N_PRE * N * sizeof(fr_t)));
   BP_HIP(ctx, hipMalloc((void**)&e.coset_x, N * sizeof(fr_t)));
   BP_HIP(ctx, hipMalloc((void**)&e.g_pow, (n + 8) * sizeof(fr_t)));
+  BP_HIP(ctx, hipMalloc((void**)&e.roots, n * sizeof(fr_t)));
   BP_HIP(ctx, hipMalloc((void**)&e.ginv_pow, N * sizeof(fr_t)));
   const fr_t g = from_u64(COSET_GEN), w4n = root_of_unity(N);
   BP_TRY(roots_run(ctx, g, n + 8, e.g_pow));
+  BP_TRY(roots_run(ctx, root_of_unity(n), n, e.roots));
   BP_TRY(roots_run(ctx, finv(g), N, e.ginv_pow));
   BP_TRY(roots_run(ctx, w4n, N, e.coset_x));                                             // w_4n^i ...
   BP_TRY(fr_scalar_run(ctx, e.coset_x, g, e.coset_x, N, 2));                            // ... times g
@@ -217,7 +219,7 @@ static int circuit_fill(bp_ctx* ctx, const fr_t* d_lag, CircuitEntry& e) {
   return BP_OK;
 }
 void circuit_release(CircuitEntry& e) {
-  fr_t** owned[6] = {&e.lag, &e.coef, &e.coset, &e.coset_x, &e.g_pow, &e.ginv_pow};
+  fr_t** owned[7] = {&e.lag, &e.coef, &e.coset, &e.coset_x, &e.g_pow, &e.ginv_pow, &e.roots};
   for (fr_t** p : owned) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
@@ -256,7 +258,7 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   // ---- round 2 (prover.rs:279-368): permutation grand product, blinded by (b9 + b8 x + b7 x^2)(x^n - 1)
   fr_t *z_lag = zc, *z_coeff = zc + (n + 8);
   BP_TRY(grand_product_run(ctx, d_wit, d_wit + n, d_wit + 2 * n, cir.lag + 5 * n, cir.lag + 6 * n, cir.lag + 7 * n, n, beta, gamma, k1, k2,
-                           omega, z_lag));
+                           omega, z_lag, cir.roots));
   BP_TRY(ntt_run(ctx, z_lag, k, 1, 1, n));
   hipLaunchKernelGGL(fr_blind, dim3(blocks_n), dim3(256), 0, st, z_lag, n, blind[8], blind[7], blind[6], 3u, z_coeff);
   BP_HIP(ctx, hipGetLastError());
