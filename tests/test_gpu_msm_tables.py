@@ -158,3 +158,26 @@ def test_full_size_2p20_with_tables(ctx):
     lo = 123457
     assert bp.sum_partials(ctx.msm_partial(h, sc[:50000], first=lo)) == M.enc96(M.ec_mul(oracle_dot(sc[:50000], a + lo * d, d)))
     ctx.srs_free(h)
+
+
+def test_full_size_2p24_closed_form_both_paths(ctx):
+    """BASELINE configs[3] size on one GPU: 2^24 points generated in HBM, scalars generated in HBM by the same SplitMix64 stream
+    the oracle reproduces on the CPU; the result must equal the closed form (sum s_i (a + i d)) G with and without tables"""
+    import torch
+    n, a, d, seed = 1 << 24, 0x0F1E2D3C4B5A6978, 0x1122334455, 0x5EED0018
+    h = ctx.srs_generate_progression(n, a, d)
+    t = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+    ctx.synthetic_scalars_device(t.data_ptr(), n, seed)
+    sc = O.splitmix_scalars(n, seed)                                # the same stream on the host
+    assert (t[:4 * 1000].cpu().numpy().view(np.uint64).reshape(-1, 4) == sc[:1000]).all()
+    want = M.enc96(M.ec_mul(O.dot_progression(sc, a, d)))
+    plain = bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n))
+    assert plain == want and not ctx.msm_stats()["tables"]
+    info = ctx.srs_precompute(h)
+    assert info["window_bits"] == 16 and info["bytes"] == 16 * n * 112
+    assert bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n)) == want and ctx.msm_stats()["tables"]
+    # point-range shards as 8 GPUs would hold them (2^21 points each), combined on the host
+    per = n // 8
+    parts = b"".join(ctx.msm_partial(h, None, first=r * per, device_ptr=t.data_ptr() + 32 * r * per, n=per) for r in range(8))
+    assert bp.sum_partials(parts) == want
+    ctx.srs_free(h)
