@@ -53,7 +53,7 @@ static Proof toy_proof(const std::array<Scalar, 11>& blinders) {
     for (int row = 0; row < 8; row++) for (int col = 0; col < 3; col++) if (name == wires[row][col]) cells.push_back({col, row});
     for (size_t j = 0; j < cells.size(); j++) {
       auto next = cells[(j + 1) % cells.size()];
-      sigma[cells[j].first]->values[cells[j].second] = mul(S(next.first + 1), roots[next.second]);     // utils.rs:29-36
+      sigma[next.first]->values[next.second] = mul(S(cells[j].first + 1), roots[cells[j].second]);     // s[next] = label(cell), program.rs:126-137, utils.rs:29-36
     }
   }
   std::vector<Scalar> col[3];

@@ -24,17 +24,8 @@ def toy_circuit(n=8):
     sel = dict(ql=[1, 0, 0], qr=[0, -1, 0], qm=[0, -1, -1], qo=[0, 1, 1], qc=[0, 0, 0])
     pk = {k: [x % Q for x in v] + [0] * (n - 3) for k, v in sel.items()}
     cols = [[w.get(row[j], 0) if row[j] else 0 for row in wires] for j in range(3)]
-    om = M.omega(n)
-    label = lambda col, row: (col + 1) * pow(om, row, Q) % Q          # utils.rs:29-36
-    groups = {}
-    for row, ws in enumerate(wires):
-        for col, name in enumerate(ws):
-            groups.setdefault(name, []).append((col, row))              # program.rs:92-99: equal names share a cycle
-    sig = [[0] * n for _ in range(3)]
-    for cells in groups.values():
-        for j, (col, row) in enumerate(cells):
-            ncol, nrow = cells[(j + 1) % len(cells)]
-            sig[col][row] = label(ncol, nrow)
+    from tests.circuit_frontend import make_s_polynomials
+    _, sig = make_s_polynomials(wires[:3], n)                             # program.rs:76-147
     pk.update(s1=sig[0], s2=sig[1], s3=sig[2])
     public = [(-80) % Q] + [0] * (n - 1)                                 # prover.rs:114-127
     return cols, pk, public

@@ -149,18 +149,9 @@ def test_synthetic_circuit_native_vs_oracle_restatement(logn):
 def _circuit_from_rows(wires, selectors, n):
     """what Program / Assembly produce for a list of gate rows: wire-name rows -> value columns are the
     caller's; sigma columns join equal names (empty cells included) into one cycle each, program.rs:92-99"""
-    rows = list(wires) + [(None, None, None)] * (n - len(wires))
+    from tests.circuit_frontend import make_s_polynomials
     pk = {k: [x % Q for x in v] + [0] * (n - len(v)) for k, v in selectors.items()}
-    om = M.omega(n)
-    groups = {}
-    for row, ws in enumerate(rows):
-        for col, name in enumerate(ws):
-            groups.setdefault(name, []).append((col, row))
-    sig = [[0] * n for _ in range(3)]
-    for cells in groups.values():
-        for j, (col, row) in enumerate(cells):
-            ncol, nrow = cells[(j + 1) % len(cells)]
-            sig[col][row] = (ncol + 1) * pow(om, nrow, Q) % Q
+    rows, sig = make_s_polynomials(wires, n)
     pk.update(s1=sig[0], s2=sig[1], s3=sig[2])
     return rows, pk
 
