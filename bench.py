@@ -78,12 +78,18 @@ def cpu_baseline(sample_log_n, threads_all):
     t3 = time.perf_counter()
     O.ntt_fast(x)
     t4 = time.perf_counter()
+    xq = O.splitmix_scalars(1 << 8, 0xF40008)
+    t5 = time.perf_counter()
+    O.ntt_381(xq)                                 # the reference's literal O(n^2) DFT with a 256-bit pow per term (utils.rs:63-81)
+    t6 = time.perf_counter()
     return {
         "value": n / (t1 - t0), "unit": "scalar-muls/s", "cores": 1, "kind": "port",
         "sample": "2^%d-point bucket_msm(b=256,c=4) restated from src/msm.rs, same synthetic inputs, %.1f s" % (sample_log_n, t1 - t0),
         "all_cores": {"value": n / (t2 - t1), "cores": threads_all, "note": "same algorithm, 64 windows over OpenMP threads"},
         "ntt": {"value": (1 << ntt_log) / (t4 - t3), "unit": "elements/s", "cores": 1,
-                "sample": "2^%d radix-2 NTT (output-identical O(n log n) twin of utils.rs:63-81), %.2f s" % (ntt_log, t4 - t3)},
+                "sample": "2^%d radix-2 NTT (output-identical O(n log n) twin of utils.rs:63-81), %.2f s" % (ntt_log, t4 - t3),
+                "reference_quadratic_form": {"value": (1 << 8) / (t6 - t5), "unit": "elements/s",
+                                             "sample": "utils.rs:63-81 as written (n^2 terms, one pow each) at n = 2^8, %.2f s; cost grows as n^2" % (t6 - t5)}},
         "host": "%d logical CPUs" % (os.cpu_count() or 0),
     }
 
