@@ -319,6 +319,9 @@ class Polynomial:
     def __truediv__(self, other):        # polynomial.rs:314-380
         return self._binop(other, self.ctx._lib.bp_poly_div, "Polynomial / Polynomial")
 
+    def rlc(self, other, beta, gamma):   # impl Rlc for Polynomial (utils.rs:170-175): self + other * beta + gamma
+        return self + other * beta + gamma
+
     def coeffs_evaluate(self, x):        # polynomial.rs:34-45
         x = np.ascontiguousarray(x, dtype=np.uint64).reshape(4)
         out = np.zeros(4, dtype=np.uint64)
@@ -408,6 +411,9 @@ class DevicePolynomial:
 
     def __truediv__(self, o):
         return self._binop(o, self.ctx._lib.bp_poly_div_device, "Polynomial / Polynomial", max(len(self), 1))
+
+    def rlc(self, other, beta, gamma):   # impl Rlc for Polynomial (utils.rs:170-175)
+        return self + other * beta + gamma
 
     def coeffs_evaluate(self, x):
         x = np.ascontiguousarray(x, dtype=np.uint64).reshape(4)

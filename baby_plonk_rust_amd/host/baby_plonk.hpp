@@ -125,6 +125,8 @@ class Polynomial {
   Polynomial(std::vector<Scalar> v, Basis b) : values(std::move(v)), basis(b) {}
   bool operator==(const Polynomial& o) const { return basis == o.basis && values == o.values; }
 
+  // impl Rlc for Polynomial (utils.rs:170-175): self + other * beta + gamma
+  Polynomial rlc(const Polynomial& other, const Scalar& beta, const Scalar& gamma) const { return *this + other * beta + gamma; }
   Scalar coeffs_evaluate(const Scalar& x, Context& c = Context::global()) const {      // polynomial.rs:34-45
     Scalar out;
     c.check(bp_poly_evaluate(c.raw(), values.data(), values.size(), (int)basis, x.l.data(), BP_FR_MONT, out.l.data()), "coeffs_evaluate");

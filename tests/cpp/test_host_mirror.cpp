@@ -105,6 +105,7 @@ int main(int argc, char** argv) {
     CHECK((mono({S(1), S(2), S(3)}) * S(2)) == mono({S(2), S(4), S(6)}));
     CHECK((mono({S(1), S(1)}) * mono({S(1), S(1)})) == mono({S(1), S(2), S(1)}));                  // (1+x)^2, :437-451
     CHECK(mono({S(1), S(3), S(2)}).coeffs_evaluate(S(2)) == S(15));
+    CHECK(mono({S(1), S(2)}).rlc(mono({S(3), S(4)}), S(3), S(4)) == mono({S(14), S(14)}));          // utils.rs:170-175: 1 + 3*3 + 4, 2 + 4*3
     // (3x^3 - x^2 - x - 1) / (x - 1) = 3x^2 + 2x + 1
     Polynomial num = mono({neg(S(1)), neg(S(1)), neg(S(1)), S(3)}), den = mono({neg(S(1)), S(1)});
     CHECK((num / den) == mono({S(1), S(2), S(3)}));

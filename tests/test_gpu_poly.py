@@ -48,6 +48,8 @@ def test_add_sub_scalar_literals(ctx):
     assert ints(P([1, 2, 3]) - S(2)) == [Q - 1, 2, 3]
     assert ints(P([1, 2, 3], LAG) - S(2)) == [3, 4, 5]           # reference quirk (polynomial.rs:126-128)
     assert bp.scalars_to_ints(P([1, 2, 3], LAG).shift_left(1)) == [2, 3, 1]
+    assert ints(P([1, 2]).rlc(P([3, 4]), S(3), S(4))) == [14, 14]                # impl Rlc for Polynomial (utils.rs:170-175)
+    assert ints(P([1, 2], LAG).rlc(P([3, 4], LAG), S(3), S(4))) == [14, 18]
 
 
 def test_mul_literals_and_random(ctx):
