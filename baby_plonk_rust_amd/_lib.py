@@ -45,6 +45,7 @@ SIGNATURES = {
     "bp_circuit_load": (_int, [_vp, _u32, _vp, _int, _int, _pp(_u64)]),
     "bp_circuit_free": (_int, [_vp, _u64]),
     "bp_circuit_commitments": (_int, [_vp, _u64, _u64, _vp]),
+    "bp_make_s_polynomials": (_int, [_u32, _vp, _vp, _vp, _vp]),
     "bp_prove": (_int, [_vp, _u64, _u64, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp]),
     "bp_prove_last_stats": (_int, [_vp, _vp, _pp(C.c_float)]),
     "bp_transcript_test_vector": (_int, [_vp]),

@@ -600,6 +600,20 @@ class Prover:
         return {"round_ms": list(r), "total_ms": t.value}
 
 
+def make_s_polynomials(wire_ids):
+    """Program::make_s_polynomials (src/program.rs:76-147) in O(n log n) on the host (no GPU): wire_ids [n, 3] uint32, 0 = empty
+    wire, equal ids = the same variable -> (s1, s2, s3) Lagrange columns as [n, 4] Montgomery limbs"""
+    ids = np.ascontiguousarray(wire_ids, dtype=np.uint32)
+    n = ids.shape[0]
+    if ids.ndim != 2 or ids.shape[1] != 3 or n == 0 or n & (n - 1):
+        raise BpError(-2, "make_s_polynomials", "wire_ids must be [2^k, 3]")
+    out = [np.zeros((n, 4), dtype=np.uint64) for _ in range(3)]
+    rc = _lib.load().bp_make_s_polynomials(n.bit_length() - 1, ids.ctypes.data, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data)
+    if rc:
+        raise BpError(rc, "bp_make_s_polynomials", "")
+    return tuple(out)
+
+
 def transcript_test_vector():
     """merlin's conformance vector through the library's host transcript (no GPU needed)"""
     out = np.zeros(32, dtype=np.uint8)

@@ -873,6 +873,37 @@ int bp_circuit_free(bp_ctx* ctx, uint64_t handle) {
   ctx->circuits.erase(it);
   return BP_OK;
 }
+int bp_make_s_polynomials(uint32_t log_n, const uint32_t* wire_ids, void* s1, void* s2, void* s3) {
+  if (!wire_ids || !s1 || !s2 || !s3 || log_n > 26) return BP_ERR_INVALID_ARG;
+  const size_t n = (size_t)1 << log_n, cells = 3 * n;
+  fr_t w;
+  host_root_of_unity(w, n);
+  std::vector<fr_t> root(n);                                  // roots_of_unity(group_order), utils.rs:45-52
+  root[0] = Fr::one();
+  for (size_t i = 1; i < n; i++) Fr::mul(root[i], root[i - 1], w);
+  fr_t col[3], two, three;
+  col[0] = Fr::one();
+  Fr::add(two, col[0], col[0]);
+  Fr::add(three, two, col[0]);
+  col[1] = two;
+  col[2] = three;
+  auto label = [&](size_t cell) { fr_t r; Fr::mul(r, root[cell / 3], col[cell % 3]); return r; };      // Cell::label, utils.rs:28-37
+  // cells grouped by variable, row-major inside a group (program.rs:80-99)
+  std::vector<uint64_t> order(cells);
+  for (size_t k = 0; k < cells; k++) order[k] = ((uint64_t)wire_ids[k] << 32) | k;
+  std::sort(order.begin(), order.end());
+  fr_t* out[3] = {(fr_t*)s1, (fr_t*)s2, (fr_t*)s3};
+  for (size_t a = 0; a < cells;) {
+    size_t b = a;
+    while (b < cells && (order[b] >> 32) == (order[a] >> 32)) b++;
+    for (size_t j = a; j < b; j++) {                          // uses[j] -> uses[j + 1 cyclically] receives label(uses[j]), :126-137
+      const size_t cell = (size_t)(order[j] & 0xffffffffu), next = (size_t)(order[j + 1 < b ? j + 1 : a] & 0xffffffffu);
+      out[next % 3][next / 3] = label(cell);
+    }
+    a = b;
+  }
+  return BP_OK;
+}
 int bp_circuit_commitments(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_handle, uint8_t out768[768]) {
   if (!ctx || !out768) return BP_ERR_INVALID_ARG;
   auto it = ctx->circuits.find(circuit_handle);

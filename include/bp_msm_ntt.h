@@ -186,6 +186,13 @@ int  bp_circuit_free(bp_ctx* ctx, uint64_t circuit_handle);
 /* The verifier's preprocessing (src/verifier.rs:61-68: i_ntt + Setup::commit of each column): commitments to
  * QL QR QM QO QC S1 S2 S3 in that order, 8 x 96 bytes (uncompressed affine), from the coefficient forms already in HBM. */
 int  bp_circuit_commitments(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_handle, uint8_t out768[768]);
+/* Program::make_s_polynomials (src/program.rs:76-147) for circuits of any size: the reference labels every cell with
+ * roots_of_unity(group_order)[row] recomputed per cell (utils.rs:29-36), i.e. O(n^2) field work; this is the same map in
+ * O(n log n) on the host (no GPU needed).  wire_ids: 3 * 2^log_n variable ids, row-major, columns L R O inside a row;
+ * 0 = empty wire (the reference's None), equal ids = the same variable name.  Empty rows after the constraints are rows
+ * of zeros.  Cells of one variable form a cycle in row-major order and the NEXT cell of the cycle receives THIS cell's
+ * label column * w^row, columns numbered 1 2 3 (program.rs:126-137).  s1 s2 s3: 2^log_n Montgomery scalars each, host. */
+int  bp_make_s_polynomials(uint32_t log_n, const uint32_t* wire_ids, void* s1, void* s2, void* s3);
 /* One proof.  a, b, c: the witness as the three Lagrange wire columns the reference builds at prover.rs:186-227;
  * public_input: the Lagrange column of prover.rs:114-127 (-x_i in the first rows, zero elsewhere), NULL = all zero;
  * 2^log_n scalars each.  blinders: b1..b11 of prover.rs:110 as 11 x 32 canonical little-endian bytes -- an input here

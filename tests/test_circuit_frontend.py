@@ -34,3 +34,45 @@ def test_cycle_orientation_of_longer_cycles():
 def test_make_gate_polynomials_shape():
     g = make_gate_polynomials([(1, 0, 0, 0, 0), (0, -1, -1, 1, 0)], 8)
     assert g["ql"] == [1] + [0] * 7 and g["qr"][1] == Q - 1 and g["qo"][1] == 1 and len(g["qc"]) == 8
+
+
+def test_library_make_s_polynomials_matches_the_restatement():
+    """bp_make_s_polynomials (host-side entry of the library, no GPU): the reference's own test case, the toy program, and random
+    wirings with shared variables, against the line-by-line restatement above"""
+    import random
+
+    import numpy as np
+
+    import baby_plonk_rust_amd as bp
+    from oracle import oracle as O
+
+    def run(wires, n):
+        names = {}
+        ids = np.zeros((n, 3), dtype=np.uint32)
+        for r, ws in enumerate(wires):
+            for c, name in enumerate(ws):
+                if name is not None:
+                    ids[r, c] = names.setdefault(name, 7 + 3 * len(names))     # arbitrary distinct non-zero ids
+        got = [O.fr_array_to_ints(x) for x in bp.make_s_polynomials(ids)]
+        _, want = make_s_polynomials(wires, n)
+        assert got == want
+
+    run([("a", "b", "c"), ("a", "e", "b")], 8)                                  # program.rs:206-239
+    run([("e", None, None), ("a", "b", "c"), ("c", "d", "e")], 8)               # tests/verify_proof_test.rs
+    run([("x", None, None), ("x", None, None), ("x", "x", "x")], 8)
+    run([], 8)
+    rnd = random.Random(4)
+    for n in (8, 64, 1024):
+        pool = ["v%d" % i for i in range(max(2, n // 3))]
+        wires = [tuple(rnd.choice(pool + [None]) for _ in range(3)) for _ in range(rnd.randrange(1, n + 1))]
+        run(wires, n)
+    # a 2^16-row chain: the 2-cycles {(O, i), (L, i + 1)} of baby_plonk_rust_amd.synthetic
+    n = 1 << 16
+    ids = np.zeros((n, 3), dtype=np.uint32)
+    ids[:, 0] = np.arange(1, n + 1)
+    ids[:, 1] = np.arange(n + 1, 2 * n + 1)
+    ids[:, 2] = np.arange(2, n + 2)
+    s1, s2, s3 = (O.fr_array_to_ints(x) for x in bp.make_s_polynomials(ids))
+    w = M.omega(n)
+    assert s1[0] == 1 and s1[5] == 3 * pow(w, 4, Q) % Q and s3[4] == pow(w, 5, Q) and s2[9] == 2 * pow(w, 9, Q) % Q
+    assert s3[n - 1] == 2 and s2[0] == 3 * pow(w, n - 1, Q) % Q     # id n + 1 is both (O, n - 1) and (R, 0): a 2-cycle
