@@ -31,14 +31,14 @@ def chained_multiplications(n, seed):
         y = rnd.getrandbits(250)
         a[i], b[i], c[i] = x, y, x * y % Q
         x = c[i]
-    om = pow(ROOT_OF_UNITY, (1 << 32) // n, Q)
-    pw = [1] * n
-    for i in range(1, n):
-        pw[i] = pw[i - 1] * om % Q
-    s1, s2, s3 = list(pw), [2 * v % Q for v in pw], [3 * v % Q for v in pw]
-    for i in range(n - 1):                        # cycle {(C, i), (A, i + 1)}
-        s3[i], s1[i + 1] = pw[i + 1], 3 * pw[i] % Q
+    # wires: row i = (x_i, y_i, z_i) with x_{i+1} = z_i -> variable ids: x_i = z_{i-1} shares id i, y_i is used once, z_i has id i + 1
+    ids = np.zeros((n, 3), dtype=np.uint32)
+    ids[:, 0] = np.arange(1, n + 1, dtype=np.uint32)
+    ids[:, 1] = np.arange(n + 2, 2 * n + 2, dtype=np.uint32)
+    ids[:, 2] = np.arange(2, n + 2, dtype=np.uint32)
+    from .api import make_s_polynomials
+    s1m, s2m, s3m = make_s_polynomials(ids)                      # Program::make_s_polynomials (program.rs:76-147)
     zero = np.zeros((n, 4), dtype=np.uint64)
     pk = dict(ql=zero, qr=zero, qm=ints_to_mont([Q - 1] * n), qo=ints_to_mont([1] * n), qc=zero,
-              s1=ints_to_mont(s1), s2=ints_to_mont(s2), s3=ints_to_mont(s3))
+              s1=s1m, s2=s2m, s3=s3m)
     return [ints_to_mont(a), ints_to_mont(b), ints_to_mont(c)], pk
