@@ -158,13 +158,13 @@ int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_
   uint32_t *counts, *offsets, *cursors, *sorted;
   proj28_slot *bucket_sum, *partial, *block_out, *window_sum;
   BP_TRY(ws_get(ctx, "msm.digits", max_entries * sizeof(int16_t), (void**)&digits));
-  BP_TRY(ws_get(ctx, "msm.counts", (size_t)total * 4, (void**)&counts));
+  BP_TRY(ws_get(ctx, "msm.counts", (size_t)total * 4 + 8, (void**)&counts));       // + [0] long-bucket counter, [1] scalar status: one memset
   BP_TRY(ws_get(ctx, "msm.offsets", ((size_t)total + 1) * 4, (void**)&offsets));
   BP_TRY(ws_get(ctx, "msm.cursors", (size_t)total * 4, (void**)&cursors));
   // a bucket is "long" when it spans >= FIXUP_LONG chunks, so at most n_chunks / FIXUP_LONG + 1 buckets can be long
   const uint32_t long_cap = (uint32_t)(n_chunks / FIXUP_LONG + 1);
   uint32_t *long_count, *long_list;
-  BP_TRY(ws_get(ctx, "msm.long_count", 8, (void**)&long_count));     // [0] long-bucket counter, [1] scalar status
+  long_count = counts + total;
   BP_TRY(ws_get(ctx, "msm.long_list", (size_t)long_cap * 4, (void**)&long_list));
   uint32_t* tile_sums;
   BP_TRY(ws_get(ctx, "msm.tile_sums", 4096 * 4, (void**)&tile_sums));
@@ -173,7 +173,7 @@ int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_
   BP_TRY(ws_get(ctx, "msm.partial", 2 * n_chunks * sizeof(proj28_slot), (void**)&partial));
   const uint32_t n_planes = Wr * per_window;        // tables: A and the c - 1 bit planes; else one sum per window
   BP_TRY(ws_get(ctx, "msm.block_out", (size_t)Wr * blocks_per_window * per_block * sizeof(proj28_slot), (void**)&block_out));
-  BP_TRY(ws_get(ctx, "msm.window_sum", (size_t)n_planes * sizeof(proj28_slot), (void**)&window_sum));
+  BP_TRY(ws_get(ctx, "msm.window_sum", (size_t)n_planes * sizeof(proj28_slot) + 16, (void**)&window_sum));     // + the status word
   proj28_slot* h_windows;
   BP_TRY(pinned_get(ctx, (size_t)n_planes * sizeof(proj28_slot) + 16, (void**)&h_windows));
   uint32_t* h_status = reinterpret_cast<uint32_t*>(h_windows + n_planes);
@@ -187,8 +187,7 @@ int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_
   }
   hipStream_t st = ctx->stream;
   BP_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-  BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4, st));
-  BP_HIP(ctx, hipMemsetAsync(long_count, 0, 8, st));
+  BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4 + 8, st));
   hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits, long_count + 1);
   const size_t hist_bytes = (size_t)B * 4;
   const unsigned hist_threads = B >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
@@ -217,15 +216,16 @@ int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_
   if (table_c) {
     hipLaunchKernelGGL(msm_planes_block, dim3(blocks_per_window, Wr), dim3(256), 512 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
                        l1, block_out);
-    hipLaunchKernelGGL(msm_planes_window, dim3(l1 + 1, Wr), dim3(128), 256 * sizeof(proj28_slot), st, block_out, l1, l2, window_sum);
+    hipLaunchKernelGGL(msm_planes_window, dim3(l1 + 1, Wr), dim3(128), 256 * sizeof(proj28_slot), st, block_out, l1, l2, window_sum,
+                       long_count + 1, reinterpret_cast<uint32_t*>(window_sum + n_planes));
   } else {
     hipLaunchKernelGGL(msm_reduce, dim3(blocks_per_window, Wr), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
                        block_out);
-    hipLaunchKernelGGL(msm_window_finish, dim3(Wr), dim3(256), 256 * sizeof(proj28_slot), st, block_out, blocks_per_window, window_sum);
+    hipLaunchKernelGGL(msm_window_finish, dim3(Wr), dim3(256), 256 * sizeof(proj28_slot), st, block_out, blocks_per_window, window_sum,
+                       long_count + 1, reinterpret_cast<uint32_t*>(window_sum + n_planes));
   }
   BP_HIP(ctx, hipGetLastError());
-  BP_HIP(ctx, hipMemcpyAsync(h_windows, window_sum, (size_t)n_planes * sizeof(proj28_slot), hipMemcpyDeviceToHost, st));
-  BP_HIP(ctx, hipMemcpyAsync(h_status, long_count + 1, 4, hipMemcpyDeviceToHost, st));
+  BP_HIP(ctx, hipMemcpyAsync(h_windows, window_sum, (size_t)n_planes * sizeof(proj28_slot) + 4, hipMemcpyDeviceToHost, st));    // sums + status
   BP_HIP(ctx, hipEventRecord(ctx->ev[3], st));
   BP_HIP(ctx, hipStreamSynchronize(st));
   if (*h_status) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q in a canonical-bytes input", hipSuccess, __FILE__, __LINE__);

@@ -541,9 +541,12 @@ msm_reduce(const uint32_t* __restrict__ offsets, MsmPlan plan, const proj28_slot
 }
 
 // window_sum[w] = sum of the block shares of window w: one workgroup per window, LDS tree over <= 256 shares
+// (the last kernel of an MSM also moves the scalar-status word behind the sums, so that one copy brings everything to the host)
 __global__ void __launch_bounds__(256, 2) msm_window_finish(const proj28_slot* __restrict__ block_out, uint32_t blocks_per_window,
-                                                             proj28_slot* __restrict__ window_sum) {
+                                                             proj28_slot* __restrict__ window_sum, const uint32_t* __restrict__ status_in,
+                                                             uint32_t* __restrict__ status_out) {
   const uint32_t w = blockIdx.x;
+  if (w == 0 && threadIdx.x == 0) *status_out = *status_in;
   g1_proj28 v = g1_identity28();
   for (uint32_t j = threadIdx.x; j < blocks_per_window; j += blockDim.x) {       // > 256 shares: fold first
     g1_proj28 q = load_proj28(&block_out[(size_t)w * blocks_per_window + j]);
@@ -613,9 +616,11 @@ msm_planes_block(const uint32_t* __restrict__ offsets, MsmPlan plan, const proj2
 //   v > 0: plane v - 1, a plain sum over the blocks.
 // out[w * (l1 + l2 + 1) + {0: A, 1 + j: T_j}]
 __global__ void __launch_bounds__(128, 1)
-msm_planes_window(const proj28_slot* __restrict__ in, uint32_t l1, uint32_t l2, proj28_slot* __restrict__ out) {
+msm_planes_window(const proj28_slot* __restrict__ in, uint32_t l1, uint32_t l2, proj28_slot* __restrict__ out,
+                  const uint32_t* __restrict__ status_in, uint32_t* __restrict__ status_out) {
   proj28_slot* buf = reinterpret_cast<proj28_slot*>(msm_lds_tree);
   const uint32_t v = blockIdx.x, w = blockIdx.y, nblk = 1u << l2, c = l1 + l2 + 1;
+  if (v == 0 && w == 0 && threadIdx.x == 0) *status_out = *status_in;       // rides to the host behind the sums
   if (threadIdx.x < nblk) buf[threadIdx.x] = in[((size_t)w * nblk + threadIdx.x) * (l1 + 1) + v];
   __syncthreads();
   const proj28_slot* root = planes_tree(buf, buf + 128, l2, v == 0);
