@@ -10,8 +10,9 @@
  *   - plain pointers and sizes only; no ownership transfer; every call returns BP_OK (0) or a negative code
  *     and never throws.  Where the reference panics (assert!, unwrap), the call returns an error instead and
  *     the Rust shim turns it back into a panic.
- *   - one bp_ctx drives one GPU from one host thread (the reference is single-threaded).  Multi-GPU = one
- *     process and one ctx per GPU; partial MSM results are exchanged by the caller (RCCL all-gather of the
+ *   - one bp_ctx drives one GPU from one host thread (the reference is single-threaded); a ctx owns its HIP stream,
+ *     workspaces, SRS and circuit handles, so several contexts (one host thread each) may share a GPU and overlap
+ *     their work.  Multi-GPU = one process and one ctx per GPU; partial MSM results are exchanged by the caller (RCCL all-gather of the
  *     144-byte projective partials, see bp_msm_g1_partial / bp_g1_sum_partials).
  *   - wire formats are the reference's own:
  *       scalar  fmt BP_FR_BYTES_LE : 32-byte little-endian canonical  (Scalar::to_bytes,  scalar.rs:292-304)
