@@ -42,6 +42,7 @@ SIGNATURES = {
     "bp_srs_precompute": (_int, [_vp, _u64, _u32]),
     "bp_srs_table_info": (_int, [_vp, _u64, _pp(_u32), _pp(_u32), _pp(_u64)]),
     "bp_msm_last_used_tables": (_int, [_vp]),
+    "bp_g1_bytes96_to_compressed48": (_int, [_vp, _vp]),
     "bp_circuit_load": (_int, [_vp, _u32, _vp, _int, _int, _pp(_u64)]),
     "bp_circuit_free": (_int, [_vp, _u64]),
     "bp_circuit_commitments": (_int, [_vp, _u64, _u64, _vp]),

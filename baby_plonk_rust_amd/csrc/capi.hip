@@ -439,6 +439,13 @@ int bp_g1_bytes96_to_partial(const uint8_t in96[96], uint8_t out144[144]) {
   return BP_OK;
 }
 
+int bp_g1_bytes96_to_compressed48(const uint8_t in96[96], uint8_t out48[48]) {
+  if (!in96 || !out48) return BP_ERR_INVALID_ARG;
+  g1_proj p;
+  if (!host_decode96(p, in96)) return BP_ERR_BAD_POINT;
+  host_compress48(out48, p);
+  return BP_OK;
+}
 int bp_msm_last_used_tables(bp_ctx* ctx) { return ctx ? (ctx->msm_tables ? 1 : 0) : BP_ERR_INVALID_ARG; }
 int bp_msm_last_stats(bp_ctx* ctx, float* accumulate_ms, float* total_device_ms, uint64_t* mixed_adds, uint32_t* window_bits) {
   if (!ctx) return BP_ERR_INVALID_ARG;

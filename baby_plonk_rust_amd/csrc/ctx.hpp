@@ -131,5 +131,6 @@ void host_horner(g1_proj& out, const g1_proj* window_sums, uint32_t W, uint32_t 
 void host_plane_horner(g1_proj& out, const g1_proj* planes, uint32_t W, uint32_t c);
 void host_encode96(uint8_t out96[96], const g1_proj& p);
 bool host_decode96(g1_proj& out, const uint8_t in96[96]);
+void host_compress48(uint8_t out48[48], const g1_proj& p);
 
 }  // namespace bp

@@ -24,6 +24,34 @@
 #include "transcript.hpp"
 
 namespace bp {
+
+// G1Affine::to_compressed (g1.rs:221-244): big-endian x, bit 7 compressed, bit 6 infinity, bit 5 y lexicographically largest
+void host_compress48(uint8_t out[48], const g1_proj& p) {
+  memset(out, 0, 48);
+  if (g1_is_identity(p)) {
+    out[0] = 0xc0;
+    return;
+  }
+  g1_affine a = g1_to_affine(p);
+  fp_t x, y, ny;
+  Fp::from_mont(x, a.x);
+  Fp::from_mont(y, a.y);
+  Fp::neg(ny, a.y);
+  Fp::from_mont(ny, ny);
+  for (int i = 0; i < 12; i++) {
+    uint8_t* q = out + 4 * (11 - i);
+    q[0] = (uint8_t)(x.l[i] >> 24); q[1] = (uint8_t)(x.l[i] >> 16); q[2] = (uint8_t)(x.l[i] >> 8); q[3] = (uint8_t)x.l[i];
+  }
+  bool larger = false;                                       // y > -y  (fp.rs:273-298)
+  for (int i = 11; i >= 0; i--) {
+    if (y.l[i] != ny.l[i]) {
+      larger = y.l[i] > ny.l[i];
+      break;
+    }
+  }
+  out[0] |= 0x80 | (larger ? 0x20 : 0);
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ host field helpers
@@ -61,40 +89,13 @@ fr_t root_of_unity(uint64_t order) {                         // utils.rs:39-43
   return fpow(fr_root_of_unity(false), ((uint64_t)1 << 32) / order);
 }
 
-// G1Affine::to_compressed (g1.rs:221-244): big-endian x, bit 7 compressed, bit 6 infinity, bit 5 y lexicographically largest
-void compress48(uint8_t out[48], const g1_proj& p) {
-  memset(out, 0, 48);
-  if (g1_is_identity(p)) {
-    out[0] = 0xc0;
-    return;
-  }
-  g1_affine a = g1_to_affine(p);
-  fp_t x, y, ny;
-  Fp::from_mont(x, a.x);
-  Fp::from_mont(y, a.y);
-  Fp::neg(ny, a.y);
-  Fp::from_mont(ny, ny);
-  for (int i = 0; i < 12; i++) {
-    uint8_t* q = out + 4 * (11 - i);
-    q[0] = (uint8_t)(x.l[i] >> 24); q[1] = (uint8_t)(x.l[i] >> 16); q[2] = (uint8_t)(x.l[i] >> 8); q[3] = (uint8_t)x.l[i];
-  }
-  bool larger = false;                                       // y > -y  (fp.rs:273-298)
-  for (int i = 11; i >= 0; i--) {
-    if (y.l[i] != ny.l[i]) {
-      larger = y.l[i] > ny.l[i];
-      break;
-    }
-  }
-  out[0] |= 0x80 | (larger ? 0x20 : 0);
-}
-
 // src/transcript.rs:4-86 (alpha is drawn under the label "z_1", :24; challenges are rejection-sampled until canonical
 // and non-zero and then re-absorbed, :70-82)
 struct PlonkTranscript {
   MerlinTranscript t{"plonk"};                               // prover.rs:112
   void point(const char* label, const g1_proj& p) {
     uint8_t c[48];
-    compress48(c, p);
+    host_compress48(c, p);
     t.append_message(label, c, 48);
   }
   void scalar(const char* label, const fr_t& v) {
@@ -390,7 +391,7 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   const double t_r5 = now_ms();
 
   // ---- Proof (verifier.rs:23-40 field order): 9 compressed points, then the 6 evaluations as 32-byte little-endian
-  for (int j = 0; j < 9; j++) compress48(proof + 48 * j, cm[j]);
+  for (int j = 0; j < 9; j++) host_compress48(proof + 48 * j, cm[j]);
   const fr_t evals[6] = {a_bar, b_bar, c_bar, s1_bar, s2_bar, zw_bar};
   for (int j = 0; j < 6; j++) to_le32(proof + 432 + 32 * j, evals[j]);
   ctx->prove_ms[0] = (float)(t_r1 - t_start); ctx->prove_ms[1] = (float)(t_r2 - t_r1); ctx->prove_ms[2] = (float)(t_r3 - t_r2);

@@ -100,6 +100,9 @@ int  bp_g1_sum_partials(const uint8_t* partials144, size_t n, uint8_t out96[96])
 /* Host-side conversions of single points (for the Rust shim's G1Projective <-> bytes plumbing). */
 int  bp_g1_partial_to_bytes96(const uint8_t in144[144], uint8_t out96[96]);
 int  bp_g1_bytes96_to_partial(const uint8_t in96[96], uint8_t out144[144]);
+/* G1Affine::to_compressed (g1.rs:221-244): the 48-byte encoding the transcript absorbs (transcript.rs:66-69) and
+ * bp_prove emits; host-side, no GPU. */
+int  bp_g1_bytes96_to_compressed48(const uint8_t in96[96], uint8_t out48[48]);
 /* HIP-event duration of the bucket-accumulation kernel of the last MSM on this ctx, and its adds. */
 int  bp_msm_last_stats(bp_ctx* ctx, float* accumulate_ms, float* total_device_ms, uint64_t* mixed_adds,
                        uint32_t* window_bits);

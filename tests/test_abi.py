@@ -69,3 +69,21 @@ def test_root_of_unity_host():
     with pytest.raises(bp.BpError):
         bp.root_of_unity(0)
     assert (bp.scalar_from_int(12345) == O.fr_from_int(12345)).all()
+
+
+def test_host_point_compression_against_the_reference_fixture():
+    """bp_g1_bytes96_to_compressed48 (G1Affine::to_compressed, g1.rs:221-244 -- the encoding the transcript absorbs and bp_prove
+    emits) over the reference's own 1000 + 1000 wire vectors (src/tests/mod.rs:3-55); host-side, no GPU"""
+    import numpy as np
+    from baby_plonk_rust_amd import _lib
+    here = os.path.dirname(__file__)
+    unc = open(os.path.join(here, "golden", "g1_uncompressed_valid_test_vectors.dat"), "rb").read()
+    comp = open(os.path.join(here, "golden", "g1_compressed_valid_test_vectors.dat"), "rb").read()
+    lib = _lib.load()
+    for i in range(1000):
+        a = np.frombuffer(unc[96 * i: 96 * i + 96], dtype=np.uint8).copy()
+        out = np.zeros(48, dtype=np.uint8)
+        assert lib.bp_g1_bytes96_to_compressed48(a.ctypes.data, out.ctypes.data) == 0
+        assert bytes(out) == comp[48 * i: 48 * i + 48], i
+    bad = np.full(96, 0xFF, dtype=np.uint8)
+    assert lib.bp_g1_bytes96_to_compressed48(bad.ctypes.data, out.ctypes.data) == -3
