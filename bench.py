@@ -325,7 +325,8 @@ def main():
             "ntt": {"metric": "fr_ntt_elements_per_s", "value": world * nn * args.steps / ntt_elapsed, "unit": "elements/s",
                     "ms_per_step": 1e3 * ntt_elapsed / args.steps, "passes": ntt_passes,
                     "roofline": {"bound": "hbm", "kernel": "ntt_pass_* (all passes of one transform)", "achieved": ntt_achieved,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_achieved / HBM_PEAK_GBS, "traffic": None,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_achieved / HBM_PEAK_GBS,
+                                 "traffic": measured_traffic("ntt_2p20_two_passes") if (args.ntt_log_n == 20 and ntt_passes == 2) else None,
                                  "kernel_ms": ntt_t * 1e3, "algorithmic_bytes_per_launch": NTT_BYTES_PER_UNIT * nn}},
             "result_sha": __import__("hashlib").sha256(result).hexdigest()[:16],
         }
