@@ -364,9 +364,14 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
   }
   if (window_bits == BP_SRS_TABLES_OFF) return BP_OK;
   uint32_t c = window_bits;
-  if (c == 0) {                       // auto: reduction work 2^c stays below the bucket-add work W * n
-    c = 4;
-    while (c < 16 && (1ull << (c + 1)) <= 4 * (uint64_t)e->n) c++;
+  if (c == 0) {                       // auto
+    uint32_t lg = 0;
+    while ((2ull << lg) <= (uint64_t)e->n) lg++;           // floor(log2 n)
+    if (e->n >= (1u << 14)) {         // throughput regime: reduction work 2^c stays below the bucket-add work W * n
+      c = lg + 2 > 16 ? 16 : lg + 2;
+    } else {                          // latency regime (a few thousand points): every kernel is a dependent chain, and the
+      c = lg > 8 ? lg - 4 : 4;        // reduction tree has c - 1 levels -- measured optimum 2^10: 6, 2^12: 8
+    }
   }
   if (c < 4 || c > 16) return fail(ctx, BP_ERR_INVALID_ARG, "window_bits must be 0 (auto), 1 (off) or 4..16", hipSuccess, __FILE__, __LINE__);
   BP_TRY(srs_tables_run(ctx, e->d_points, e->d_points28, e->n, c, &e->d_table, &e->table_W));

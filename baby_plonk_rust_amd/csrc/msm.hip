@@ -211,7 +211,7 @@ int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_
   else
     hipLaunchKernelGGL(msm_fixup<1>, dim3((total + 255) / 256), dim3(256), 0, st, offsets, plan, bucket_sum, partial, long_count, long_list,
                        long_cap);
-  hipLaunchKernelGGL(msm_fixup_long, dim3(64), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
+  hipLaunchKernelGGL(msm_fixup_long, dim3(1024), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
                      long_count, long_list, long_cap);
   if (table_c) {
     hipLaunchKernelGGL(msm_planes_block, dim3(blocks_per_window, Wr), dim3(256), 512 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
