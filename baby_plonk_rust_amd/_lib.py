@@ -20,6 +20,7 @@ ERRORS = {
     -10: "BP_ERR_TOO_LARGE", -11: "BP_ERR_ASSERT",
 }
 FR_BYTES_LE, FR_MONT = 0, 1
+MSM_BLOB_BYTES = 22592          # BP_MSM_BLOB_BYTES
 BASIS_LAGRANGE, BASIS_MONOMIAL = 0, 1
 
 _vp, _sz, _u64, _u32, _int, _cp = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int, C.c_char_p
@@ -28,12 +29,15 @@ _pp = C.POINTER
 # name -> (restype, argtypes); mirrors include/bp_msm_ntt.h one to one
 SIGNATURES = {
     "bp_init": (_int, [_pp(_vp), _int]),
+    "bp_init_multi": (_int, [_pp(_vp), _pp(_int), _int]),
+    "bp_ctx_devices": (_int, [_vp, _pp(_int), _int]),
     "bp_destroy": (None, [_vp]),
     "bp_last_error": (_cp, [_vp]),
     "bp_version": (_cp, []),
     "bp_set_stream": (_int, [_vp, _vp]),
     "bp_synchronize": (_int, [_vp]),
     "bp_srs_load": (_int, [_vp, _vp, _sz, _pp(_u64)]),
+    "bp_srs_load_projective144": (_int, [_vp, _vp, _sz, _pp(_u64)]),
     "bp_srs_generate": (_int, [_vp, _sz, _vp, _pp(_u64)]),
     "bp_srs_generate_progression": (_int, [_vp, _sz, _vp, _vp, _pp(_u64)]),
     "bp_srs_len": (_int, [_vp, _u64, _pp(_sz)]),
@@ -52,6 +56,8 @@ SIGNATURES = {
     "bp_transcript_test_vector": (_int, [_vp]),
     "bp_msm_g1": (_int, [_vp, _u64, _vp, _sz, _int, _vp]),
     "bp_msm_g1_partial": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),
+    "bp_msm_g1_blob_device": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),
+    "bp_msm_blobs_combine": (_int, [_vp, _sz, _vp]),
     "bp_g1_sum_partials": (_int, [_vp, _sz, _vp]),
     "bp_g1_partial_to_bytes96": (_int, [_vp, _vp]),
     "bp_g1_bytes96_to_partial": (_int, [_vp, _vp]),

@@ -59,16 +59,27 @@ def _fr_array(a):
 
 
 class Context:
-    """One GPU, one HIP stream (bp_ctx).  The module keeps a default context per device."""
+    """bp_ctx: one GPU (device = int, bp_init) or one context over several GPUs (device = list of ids, bp_init_multi:
+    SRS and MSMs sharded by point range inside the library, everything else on the first device).
+    The module keeps a default context per device."""
 
     def __init__(self, device=0):
         self._lib = _lib.load()
         h = C.c_void_p()
-        rc = self._lib.bp_init(C.byref(h), device)
+        if isinstance(device, (list, tuple)):
+            ids = (C.c_int * len(device))(*device)
+            rc = self._lib.bp_init_multi(C.byref(h), ids, len(device))
+            self.devices = list(device)
+        else:
+            rc = self._lib.bp_init(C.byref(h), device)
+            self.devices = [device]
         if rc != 0:
             raise BpError(rc, "bp_init", "no usable GPU: this package has no CPU fallback")
         self._h = h
-        self.device = device
+        self.device = self.devices[0]
+
+    def n_shards(self):
+        return self._lib.bp_ctx_devices(self._h, None, 0)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -90,6 +101,13 @@ class Context:
         buf = np.ascontiguousarray(np.frombuffer(bytes(points96), dtype=np.uint8))
         n, h = len(buf) // 96, C.c_uint64()
         self.check(self._lib.bp_srs_load(self._h, buf.ctypes.data, n, C.byref(h)), "bp_srs_load")
+        return h.value
+
+    def srs_load_projective144(self, points144):
+        """n x 144 bytes: the in-memory image of G1Projective (x | y | z Montgomery limbs), normalised on the GPU"""
+        buf = np.ascontiguousarray(np.frombuffer(bytes(points144), dtype=np.uint8))
+        n, h = len(buf) // 144, C.c_uint64()
+        self.check(self._lib.bp_srs_load_projective144(self._h, buf.ctypes.data, n, C.byref(h)), "bp_srs_load_projective144")
         return h.value
 
     def srs_generate(self, powers, tau_int):
@@ -146,6 +164,15 @@ class Context:
             rc = self._lib.bp_msm_g1_partial(self._h, handle, first, s.ctypes.data, len(s), fmt, 0, out.ctypes.data)
         self.check(rc, "bp_msm_g1_partial")
         return bytes(out)
+
+    def msm_blob_device(self, handle, d_blob_ptr, scalars=None, first=0, fmt=FR_MONT, device_ptr=None, n=None):
+        """one process per GPU: this rank's partial sums stay in HBM at d_blob_ptr (MSM_BLOB_BYTES), ready for the all-gather"""
+        if device_ptr is not None:
+            rc = self._lib.bp_msm_g1_blob_device(self._h, handle, first, device_ptr, n, fmt, 1, d_blob_ptr)
+        else:
+            s = _fr_array(scalars)
+            rc = self._lib.bp_msm_g1_blob_device(self._h, handle, first, s.ctypes.data, len(s), fmt, 0, d_blob_ptr)
+        self.check(rc, "bp_msm_g1_blob_device")
 
     def msm_stats(self):
         a, t, adds, c = C.c_float(), C.c_float(), C.c_uint64(), C.c_uint32()
@@ -213,6 +240,18 @@ def sum_partials(partials144):
     return bytes(out)
 
 
+def combine_blobs(blobs):
+    """host-side: the gathered MSM records of all ranks (n x MSM_BLOB_BYTES, host bytes) -> 96-byte affine encoding"""
+    lib = _lib.load()
+    buf = np.ascontiguousarray(np.frombuffer(bytes(blobs), dtype=np.uint8))
+    assert len(buf) % _lib.MSM_BLOB_BYTES == 0
+    out = np.zeros(96, dtype=np.uint8)
+    rc = lib.bp_msm_blobs_combine(buf.ctypes.data, len(buf) // _lib.MSM_BLOB_BYTES, out.ctypes.data)
+    if rc != 0:
+        raise BpError(rc, "bp_msm_blobs_combine")
+    return bytes(out)
+
+
 def bytes96_to_partial(b96):
     lib = _lib.load()
     src, out = np.frombuffer(bytes(b96), dtype=np.uint8).copy(), np.zeros(144, dtype=np.uint8)
@@ -259,7 +298,11 @@ class BucketMSM:
     @staticmethod
     def bucket_msm(points96, scalars, b=256, c=4, ctx=None):
         """msm.rs:76-118.  points96: concatenated 96-byte encodings; scalars [n,4] Montgomery limbs.
-        (b, c) are accepted for signature parity; they do not change the group element."""
+        b = 256 with c dividing 256 (the reference's only call, setup.rs:36: b = 256, c = 4) does not change the group
+        element.  Other (b, c) make the reference drop the low 256 - c*floor(b/c) bits of every scalar (msm.rs:83,
+        119-139); that is not reproduced, so they are rejected."""
+        if b != 256 or c <= 0 or 256 % c:
+            raise BpError(-1, "BucketMSM.bucket_msm", "only b = 256 with c dividing 256 is supported (got b=%d, c=%d)" % (b, c))
         ctx = ctx or default_context()
         h = ctx.srs_load(points96)
         try:

@@ -167,16 +167,30 @@ static int download_fr(bp_ctx* ctx, fr_t* d, void* host, size_t n, int fmt) {
   return BP_OK;
 }
 
-extern "C" {
+// contiguous point range [lo, hi) of shard r of R over n points; the first n % R shards get one extra point
+static void shard_range(size_t n, size_t r, size_t R, size_t* lo, size_t* hi) {
+  const size_t base = n / R, extra = n % R;
+  *lo = r * base + std::min(r, extra);
+  *hi = *lo + base + (r < extra ? 1 : 0);
+}
+// the single-device contexts an entry point has to visit: the members of a group, or the context itself
+static std::vector<bp_ctx*> shards_of(bp_ctx* ctx) {
+  if (is_group(ctx)) return ctx->members;
+  return std::vector<bp_ctx*>(1, ctx);
+}
+// a member's failure is reported on the context the caller holds
+static int lift(bp_ctx* ctx, bp_ctx* member, int rc) {
+  if (rc != BP_OK && member != ctx) ctx->last_error = member->last_error;
+  return rc;
+}
 
-const char* bp_version(void) { return "bp_msm_ntt 0.1 (gfx950)"; }
-
-int bp_init(bp_ctx** out, int device_id) {
-  if (!out) return BP_ERR_INVALID_ARG;
+static int ctx_create(bp_ctx** out, int device_id) {
   *out = nullptr;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return BP_ERR_NO_DEVICE;
-  if (hipSetDevice(device_id) != hipSuccess) return BP_ERR_NO_DEVICE;
+  DeviceGuard guard(device_id);
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != device_id) return BP_ERR_NO_DEVICE;
   bp_ctx* ctx = new bp_ctx();
   ctx->device = device_id;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -184,28 +198,81 @@ int bp_init(bp_ctx** out, int device_id) {
     return BP_ERR_NO_DEVICE;
   }
   for (auto& e : ctx->ev)
-    if (hipEventCreate(&e) != hipSuccess) {
-      delete ctx;
+    if (hipEventCreateWithFlags(&e, hipEventDefault) != hipSuccess) {
+      bp_destroy(ctx);
       return BP_ERR_NO_DEVICE;
     }
   int rc = ntt_init_tables(ctx);
+  if (rc == BP_OK) rc = msm_init_device(ctx);
   if (rc != BP_OK) {
     fprintf(stderr, "bp_init: %s\n", ctx->last_error.c_str());
-    delete ctx;
+    bp_destroy(ctx);
     return rc;
   }
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
-    delete ctx;
+    bp_destroy(ctx);
     return BP_ERR_HIP;
   }
   *out = ctx;
   return BP_OK;
 }
 
+extern "C" {
+
+const char* bp_version(void) { return "bp_msm_ntt 0.2 (gfx950)"; }
+
+int bp_init(bp_ctx** out, int device_id) {
+  if (!out) return BP_ERR_INVALID_ARG;
+  return ctx_create(out, device_id);
+}
+
+int bp_init_multi(bp_ctx** out, const int* device_ids, int n_devices) {
+  if (!out || !device_ids || n_devices < 1 || n_devices > 64) return BP_ERR_INVALID_ARG;
+  *out = nullptr;
+  std::vector<bp_ctx*> m;
+  for (int r = 0; r < n_devices; r++) {
+    bp_ctx* c = nullptr;
+    int rc = ctx_create(&c, device_ids[r]);
+    if (rc != BP_OK) {
+      for (bp_ctx* p : m) bp_destroy(p);
+      return rc;
+    }
+    m.push_back(c);
+  }
+  if (n_devices > 1) {
+    // peer access lets hipMemcpyPeerAsync go GPU to GPU over xGMI; without it the copies are staged through the host
+    for (int a = 0; a < n_devices; a++) {
+      DeviceGuard guard(device_ids[a]);
+      for (int b = 0; b < n_devices; b++) {
+        int can = 0;
+        if (device_ids[a] == device_ids[b] || hipDeviceCanAccessPeer(&can, device_ids[a], device_ids[b]) != hipSuccess || !can) continue;
+        hipError_t e = hipDeviceEnablePeerAccess(device_ids[b], 0);
+        if (e != hipSuccess) (void)hipGetLastError();         // hipErrorPeerAccessAlreadyEnabled included
+      }
+    }
+    m[0]->members = m;
+    for (int r = 1; r < n_devices; r++) m[r]->leader = m[0];
+  }
+  *out = m[0];
+  return BP_OK;
+}
+
+int bp_ctx_devices(bp_ctx* ctx, int* device_ids, int cap) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  const std::vector<bp_ctx*> sh = shards_of(ctx);
+  for (size_t r = 0; r < sh.size() && device_ids && (int)r < cap; r++) device_ids[r] = sh[r]->device;
+  return (int)sh.size();
+}
+
 void bp_destroy(bp_ctx* ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  for (size_t r = 1; r < ctx->members.size(); r++) {
+    ctx->members[r]->leader = nullptr;
+    bp_destroy(ctx->members[r]);
+  }
+  ctx->members.clear();
+  DeviceGuard guard(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->ws)
     if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->srs) {
@@ -234,6 +301,7 @@ const char* bp_last_error(bp_ctx* ctx) { return ctx ? ctx->last_error.c_str() : 
 
 int bp_set_stream(bp_ctx* ctx, void* hip_stream) {
   if (!ctx) return BP_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (hip_stream == nullptr) {
     if (!ctx->own_stream) {
@@ -250,19 +318,26 @@ int bp_set_stream(bp_ctx* ctx, void* hip_stream) {
 
 int bp_synchronize(bp_ctx* ctx) {
   if (!ctx) return BP_ERR_INVALID_ARG;
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (bp_ctx* m : shards_of(ctx)) {
+    DeviceGuard guard(m->device);
+    BP_HIP(ctx, hipStreamSynchronize(m->stream));
+  }
   return BP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- SRS
-static int srs_register(bp_ctx* ctx, g1_affine* d, size_t n, uint64_t* handle) {
+// takes ownership of d (freed on failure); the entry covers global points [first, first + n) of an SRS of n_global points
+static int srs_register(bp_ctx* ctx, g1_affine* d, size_t n, size_t first, size_t n_global, uint64_t* handle) {
   SrsEntry e;
   e.d_points = d;
   e.n = n;
+  e.first = first;
+  e.n_global = n_global;
   int rc = srs_to28_run(ctx, d, n, &e.d_points28);
-  if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BP_ERR_HIP;
+  if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "srs_to28", hipGetLastError(), __FILE__, __LINE__);
   if (rc != BP_OK) {
     (void)hipFree(d);
+    if (e.d_points28) (void)hipFree(e.d_points28);
     return rc;
   }
   *handle = ctx->next_handle++;
@@ -275,39 +350,88 @@ static int srs_find(bp_ctx* ctx, uint64_t handle, SrsEntry** out) {
   *out = &it->second;
   return BP_OK;
 }
+// handle of the shard held by member r (the leader's entry lists them; a plain context has only its own)
+static uint64_t member_handle(const SrsEntry& lead, uint64_t own, size_t r) { return lead.member_handle.empty() ? own : lead.member_handle[r]; }
 
-int bp_srs_load(bp_ctx* ctx, const uint8_t* points96, size_t n, uint64_t* srs_handle) {
-  if (!ctx || !srs_handle || (n && !points96)) return BP_ERR_INVALID_ARG;
-  BP_HIP(ctx, hipSetDevice(ctx->device));
-  uint8_t* d_bytes;
-  BP_TRY(ws_get(ctx, "io.bytes", n * 96, (void**)&d_bytes));
+static int srs_free_one(bp_ctx* ctx, uint64_t handle) {
+  SrsEntry* e;
+  BP_TRY(srs_find(ctx, handle, &e));
+  DeviceGuard guard(ctx->device);
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, hipFree(e->d_points));
+  BP_HIP(ctx, hipFree(e->d_points28));
+  if (e->d_table) BP_HIP(ctx, hipFree(e->d_table));
+  ctx->srs.erase(handle);
+  return BP_OK;
+}
+
+// One shard of an SRS on one device.  kind 0: decode 96-byte encodings, 1: normalise 144-byte projective images,
+// 2: generate tau^i G, 3: generate (a + i d) G.  src: this shard's slice of the host input (kinds 0, 1).
+static int srs_make_one(bp_ctx* ctx, int kind, const uint8_t* src, const fr_t& a, const fr_t& d, size_t first, size_t n, size_t n_global,
+                        uint64_t* handle) {
+  DeviceGuard guard(ctx->device);
   g1_affine* d_pts = nullptr;
   BP_HIP(ctx, hipMalloc((void**)&d_pts, std::max<size_t>(n, 1) * sizeof(g1_affine)));
-  if (n) BP_HIP(ctx, hipMemcpyAsync(d_bytes, points96, n * 96, hipMemcpyHostToDevice, ctx->stream));
-  int rc = srs_decode_run(ctx, d_bytes, n, d_pts);
+  int rc = BP_OK;
+  if (kind == 0 || kind == 1) {
+    const size_t rec = kind == 0 ? 96 : 144;
+    uint8_t* d_bytes = nullptr;
+    rc = ws_get(ctx, "io.bytes", n * rec, (void**)&d_bytes);
+    if (rc == BP_OK && n) {
+      hipError_t e = hipMemcpyAsync(d_bytes, src, n * rec, hipMemcpyHostToDevice, ctx->stream);
+      if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "SRS upload", e, __FILE__, __LINE__);
+    }
+    if (rc == BP_OK) rc = kind == 0 ? srs_decode_run(ctx, d_bytes, n, d_pts) : srs_from_projective_run(ctx, (const g1_proj*)d_bytes, n, d_pts);
+  } else {
+    rc = srs_generate_run(ctx, a, d, kind == 2 ? 0 : 1, first, n, d_pts);
+  }
+  if (rc == BP_OK) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "SRS build", e, __FILE__, __LINE__);
+  }
   if (rc != BP_OK) {
     (void)hipFree(d_pts);
     return rc;
   }
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return srs_register(ctx, d_pts, n, srs_handle);
+  return srs_register(ctx, d_pts, n, first, n_global, handle);
+}
+
+// the whole SRS: one shard per member (contiguous point ranges), the leader's entry lists the members' handles
+static int srs_make(bp_ctx* ctx, int kind, const uint8_t* src, const fr_t& a, const fr_t& d, size_t n, uint64_t* handle) {
+  const std::vector<bp_ctx*> sh = shards_of(ctx);
+  const size_t rec = kind == 0 ? 96 : 144;
+  std::vector<uint64_t> hs;
+  for (size_t r = 0; r < sh.size(); r++) {
+    size_t lo, hi;
+    shard_range(n, r, sh.size(), &lo, &hi);
+    uint64_t h = 0;
+    int rc = lift(ctx, sh[r], srs_make_one(sh[r], kind, src ? src + lo * rec : nullptr, a, d, lo, hi - lo, n, &h));
+    if (rc != BP_OK) {
+      for (size_t k = 0; k < hs.size(); k++) (void)srs_free_one(sh[k], hs[k]);
+      return rc;
+    }
+    hs.push_back(h);
+  }
+  if (sh.size() > 1) ctx->srs[hs[0]].member_handle = hs;
+  *handle = hs[0];
+  return BP_OK;
+}
+
+int bp_srs_load(bp_ctx* ctx, const uint8_t* points96, size_t n, uint64_t* srs_handle) {
+  if (!ctx || !srs_handle || (n && !points96)) return BP_ERR_INVALID_ARG;
+  return srs_make(ctx, 0, points96, Fr::zero(), Fr::zero(), n, srs_handle);
+}
+int bp_srs_load_projective144(bp_ctx* ctx, const uint8_t* points144, size_t n, uint64_t* srs_handle) {
+  if (!ctx || !srs_handle || (n && !points144)) return BP_ERR_INVALID_ARG;
+  return srs_make(ctx, 1, points144, Fr::zero(), Fr::zero(), n, srs_handle);
 }
 
 static int srs_generate_common(bp_ctx* ctx, size_t n, const uint8_t a32[32], const uint8_t d32[32], int mode, uint64_t* handle) {
   if (!ctx || !handle || !a32 || (mode == 1 && !d32)) return BP_ERR_INVALID_ARG;
-  BP_HIP(ctx, hipSetDevice(ctx->device));
   fr_t a, d = Fr::zero();
   if (!fr_bytes_to_mont(a, a32, BP_FR_BYTES_LE)) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q", hipSuccess, __FILE__, __LINE__);
   if (mode == 1 && !fr_bytes_to_mont(d, d32, BP_FR_BYTES_LE)) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q", hipSuccess, __FILE__, __LINE__);
-  g1_affine* d_pts = nullptr;
-  BP_HIP(ctx, hipMalloc((void**)&d_pts, std::max<size_t>(n, 1) * sizeof(g1_affine)));
-  int rc = srs_generate_run(ctx, a, d, mode, n, d_pts);
-  if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BP_ERR_HIP;
-  if (rc != BP_OK) {
-    (void)hipFree(d_pts);
-    return rc;
-  }
-  return srs_register(ctx, d_pts, n, handle);
+  return srs_make(ctx, mode == 0 ? 2 : 3, nullptr, a, d, n, handle);
 }
 int bp_srs_generate(bp_ctx* ctx, size_t powers, const uint8_t tau32[32], uint64_t* srs_handle) {
   return srs_generate_common(ctx, powers, tau32, nullptr, 0, srs_handle);
@@ -320,96 +444,189 @@ int bp_srs_len(bp_ctx* ctx, uint64_t srs_handle, size_t* n) {
   if (!ctx || !n) return BP_ERR_INVALID_ARG;
   SrsEntry* e;
   BP_TRY(srs_find(ctx, srs_handle, &e));
-  *n = e->n;
+  *n = e->n_global;
   return BP_OK;
 }
 
 int bp_srs_export(bp_ctx* ctx, uint64_t srs_handle, size_t first, size_t n, uint8_t* points96) {
   if (!ctx || (n && !points96)) return BP_ERR_INVALID_ARG;
-  SrsEntry* e;
-  BP_TRY(srs_find(ctx, srs_handle, &e));
-  if (first > e->n || n > e->n - first) return fail(ctx, BP_ERR_INVALID_ARG, "SRS range out of bounds", hipSuccess, __FILE__, __LINE__);
-  if (n == 0) return BP_OK;
-  BP_HIP(ctx, hipSetDevice(ctx->device));
-  uint8_t* d_bytes;
-  BP_TRY(ws_get(ctx, "io.bytes", n * 96, (void**)&d_bytes));
-  BP_TRY(srs_encode_run(ctx, e->d_points + first, n, d_bytes));
-  BP_HIP(ctx, hipMemcpyAsync(points96, d_bytes, n * 96, hipMemcpyDeviceToHost, ctx->stream));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SrsEntry* lead;
+  BP_TRY(srs_find(ctx, srs_handle, &lead));
+  if (first > lead->n_global || n > lead->n_global - first) return fail(ctx, BP_ERR_INVALID_ARG, "SRS range out of bounds", hipSuccess, __FILE__, __LINE__);
+  const std::vector<bp_ctx*> sh = shards_of(ctx);
+  for (size_t r = 0; r < sh.size(); r++) {
+    bp_ctx* m = sh[r];
+    SrsEntry* e;
+    BP_TRY(lift(ctx, m, srs_find(m, member_handle(*lead, srs_handle, r), &e)));
+    const size_t lo = std::max(first, e->first), hi = std::min(first + n, e->first + e->n);
+    if (lo >= hi) continue;
+    DeviceGuard guard(m->device);
+    uint8_t* d_bytes;
+    BP_TRY(lift(ctx, m, ws_get(m, "io.bytes", (hi - lo) * 96, (void**)&d_bytes)));
+    BP_TRY(lift(ctx, m, srs_encode_run(m, e->d_points + (lo - e->first), hi - lo, d_bytes)));
+    BP_HIP(ctx, hipMemcpyAsync(points96 + (lo - first) * 96, d_bytes, (hi - lo) * 96, hipMemcpyDeviceToHost, m->stream));
+    BP_HIP(ctx, hipStreamSynchronize(m->stream));
+  }
   return BP_OK;
 }
 
 int bp_srs_free(bp_ctx* ctx, uint64_t srs_handle) {
   if (!ctx) return BP_ERR_INVALID_ARG;
-  SrsEntry* e;
-  BP_TRY(srs_find(ctx, srs_handle, &e));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  BP_HIP(ctx, hipFree(e->d_points));
-  BP_HIP(ctx, hipFree(e->d_points28));
-  if (e->d_table) BP_HIP(ctx, hipFree(e->d_table));
-  ctx->srs.erase(srs_handle);
-  return BP_OK;
+  SrsEntry* lead;
+  BP_TRY(srs_find(ctx, srs_handle, &lead));
+  const std::vector<bp_ctx*> sh = shards_of(ctx);
+  const std::vector<uint64_t> hs = lead->member_handle;
+  int rc = BP_OK;
+  for (size_t r = sh.size(); r-- > 0;) {                 // the leader's entry (r = 0) goes last: it names the others
+    const int rc1 = lift(ctx, sh[r], srs_free_one(sh[r], hs.empty() ? srs_handle : hs[r]));
+    if (rc == BP_OK) rc = rc1;
+  }
+  return rc;
 }
 
-int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
-  if (!ctx) return BP_ERR_INVALID_ARG;
+static int srs_precompute_one(bp_ctx* ctx, uint64_t handle, uint32_t c) {
   SrsEntry* e;
-  BP_TRY(srs_find(ctx, srs_handle, &e));
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  BP_TRY(srs_find(ctx, handle, &e));
+  DeviceGuard guard(ctx->device);
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (e->d_table) {
     BP_HIP(ctx, hipFree(e->d_table));
     e->d_table = nullptr;
     e->table_c = e->table_W = 0;
   }
-  if (window_bits == BP_SRS_TABLES_OFF) return BP_OK;
-  uint32_t c = window_bits;
-  if (c == 0) {                       // auto
-    uint32_t lg = 0;
-    while ((2ull << lg) <= (uint64_t)e->n) lg++;           // floor(log2 n)
-    if (e->n >= (1u << 14)) {         // throughput regime: reduction work 2^c stays below the bucket-add work W * n
-      c = lg + 2 > 16 ? 16 : lg + 2;
-    } else {                          // latency regime (a few thousand points): every kernel is a dependent chain, and the
-      c = lg > 8 ? lg - 4 : 4;        // reduction tree has c - 1 levels -- measured optimum 2^10: 6, 2^12: 8
-    }
-  }
-  if (c < 4 || c > 16) return fail(ctx, BP_ERR_INVALID_ARG, "window_bits must be 0 (auto), 1 (off) or 4..16", hipSuccess, __FILE__, __LINE__);
+  if (c == BP_SRS_TABLES_OFF) return BP_OK;
   BP_TRY(srs_tables_run(ctx, e->d_points, e->d_points28, e->n, c, &e->d_table, &e->table_W));
   e->table_c = c;
   return BP_OK;
 }
 
+int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  SrsEntry* lead;
+  BP_TRY(srs_find(ctx, srs_handle, &lead));
+  uint32_t c = window_bits;
+  if (c == 0) {                       // auto, from the length of one shard (every shard of a group gets the same width)
+    uint32_t lg = 0;
+    const uint64_t n = lead->n;
+    while ((2ull << lg) <= n) lg++;                       // floor(log2 n)
+    if (n >= (1u << 14)) {            // throughput regime: reduction work 2^c stays below the bucket-add work W * n
+      c = lg + 2 > 16 ? 16 : lg + 2;
+    } else {                          // latency regime (a few thousand points): every kernel is a dependent chain, and the
+      c = lg > 8 ? lg - 4 : 4;        // reduction tree has c - 1 levels -- measured optimum 2^10: 6, 2^12: 8
+    }
+  }
+  if (c != BP_SRS_TABLES_OFF && (c < 4 || c > 16))
+    return fail(ctx, BP_ERR_INVALID_ARG, "window_bits must be 0 (auto), 1 (off) or 4..16", hipSuccess, __FILE__, __LINE__);
+  const std::vector<bp_ctx*> sh = shards_of(ctx);
+  const std::vector<uint64_t> hs = lead->member_handle;
+  for (size_t r = 0; r < sh.size(); r++) BP_TRY(lift(ctx, sh[r], srs_precompute_one(sh[r], hs.empty() ? srs_handle : hs[r], c)));
+  return BP_OK;
+}
+
 int bp_srs_table_info(bp_ctx* ctx, uint64_t srs_handle, uint32_t* window_bits, uint32_t* windows, uint64_t* bytes) {
   if (!ctx) return BP_ERR_INVALID_ARG;
-  SrsEntry* e;
-  BP_TRY(srs_find(ctx, srs_handle, &e));
-  if (window_bits) *window_bits = e->table_c;
-  if (windows) *windows = e->table_W;
-  if (bytes) *bytes = e->d_table ? (uint64_t)e->table_W * e->n * sizeof(g1_affine28) : 0;
+  SrsEntry* lead;
+  BP_TRY(srs_find(ctx, srs_handle, &lead));
+  if (window_bits) *window_bits = lead->table_c;
+  if (windows) *windows = lead->table_W;
+  if (bytes) {
+    *bytes = 0;
+    const std::vector<bp_ctx*> sh = shards_of(ctx);
+    for (size_t r = 0; r < sh.size(); r++) {
+      SrsEntry* e;
+      BP_TRY(lift(ctx, sh[r], srs_find(sh[r], member_handle(*lead, srs_handle, r), &e)));
+      if (e->d_table) *bytes += (uint64_t)e->table_W * e->n * sizeof(g1_affine28);
+    }
+  }
   return BP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- MSM
+// Enqueue the MSM of one shard: scalars[0..n) against the member's points [local_first, local_first + n).
+//   where 0: `scalars` is host memory; 1: HBM of this member's device; 2: HBM of device src_device (the leader's): copied
+//   GPU to GPU into the member's workspace once the leader's stream has reached `ready`.
+static int msm_shard_launch(bp_ctx* m, SrsEntry* e, size_t local_first, const void* scalars, size_t n, int fmt, int where, int src_device,
+                            hipEvent_t ready, int slot, void* d_blob, MsmPending* pend) {
+  DeviceGuard guard(m->device);
+  const fr_t* d_scalars = (const fr_t*)scalars;
+  if (where != 1 && n) {
+    fr_t* d;
+    BP_TRY(ws_get(m, "io.scalars", n * sizeof(fr_t), (void**)&d));
+    if (where == 0) {
+      BP_HIP(m, hipMemcpyAsync(d, scalars, n * sizeof(fr_t), hipMemcpyHostToDevice, m->stream));
+    } else {
+      BP_HIP(m, hipStreamWaitEvent(m->stream, ready, 0));
+      if (src_device == m->device) BP_HIP(m, hipMemcpyAsync(d, scalars, n * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream));
+      else BP_HIP(m, hipMemcpyPeerAsync(d, m->device, scalars, src_device, n * sizeof(fr_t), m->stream));
+    }
+    d_scalars = d;
+  }
+  // fixed-base tables pay once the bucket adds outweigh the fixed 2^table_c reduction
+  const bool tables = e->d_table && 8 * (uint64_t)n >= (1ull << e->table_c);
+  if (tables) return msm_launch(m, e->d_table + local_first, n, d_scalars, fmt, e->table_c, e->n, slot, d_blob, pend);
+  return msm_launch(m, e->d_points28 + local_first, n, d_scalars, fmt, 0, 0, slot, d_blob, pend);
+}
+
+// sum_{i < n} s_i P_{first + i} over every shard of the SRS: all shards are enqueued before the first one is waited for
+static int msm_all_shards(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
+                          int scalars_on_device, g1_proj* out) {
+  SrsEntry* lead;
+  BP_TRY(srs_find(ctx, srs_handle, &lead));
+  if (first > lead->n_global) return fail(ctx, BP_ERR_INVALID_ARG, "SRS offset out of bounds", hipSuccess, __FILE__, __LINE__);
+  const size_t n = std::min(n_scalars, lead->n_global - first);          // zip() truncation, msm.rs:29
+  const std::vector<bp_ctx*> sh = shards_of(ctx);
+  const std::vector<uint64_t> hs = lead->member_handle;
+  if (sh.size() > 1 && scalars_on_device) {            // the members' copies must see what the leader's stream has produced
+    DeviceGuard guard(ctx->device);
+    BP_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  }
+  std::vector<MsmPending> pend(sh.size());
+  std::vector<bool> used(sh.size(), false);
+  int rc = BP_OK;
+  for (size_t r = 0; r < sh.size() && rc == BP_OK; r++) {
+    SrsEntry* e;
+    rc = lift(ctx, sh[r], srs_find(sh[r], hs.empty() ? srs_handle : hs[r], &e));
+    if (rc != BP_OK) break;
+    const size_t lo = std::max(first, e->first), hi = std::min(first + n, e->first + e->n);
+    if (lo >= hi && !(sh.size() == 1)) continue;
+    const size_t cnt = lo < hi ? hi - lo : 0;
+    const uint8_t* sc = (const uint8_t*)scalars + (lo < hi ? (lo - first) * sizeof(fr_t) : 0);
+    const int where = !scalars_on_device ? 0 : (r == 0 ? 1 : 2);
+    rc = lift(ctx, sh[r], msm_shard_launch(sh[r], e, lo < hi ? lo - e->first : 0, sc, cnt, scalar_fmt, where, ctx->device, ctx->ev[4], 0, nullptr, &pend[r]));
+    used[r] = rc == BP_OK;
+  }
+  g1_proj acc = g1_identity();
+  float acc_ms = 0, dev_ms = 0;
+  uint64_t adds = 0;
+  for (size_t r = 0; r < sh.size(); r++) {               // every launched shard is waited for, also after a failure elsewhere
+    if (!used[r]) continue;
+    DeviceGuard guard(sh[r]->device);
+    g1_proj part;
+    const int rc1 = lift(ctx, sh[r], msm_finish(sh[r], pend[r], &part));
+    if (rc1 != BP_OK) {
+      if (rc == BP_OK) rc = rc1;
+      continue;
+    }
+    if (sh.size() == 1) acc = part; else g1_add(acc, acc, part);
+    acc_ms = std::max(acc_ms, sh[r]->msm_accumulate_ms);
+    dev_ms = std::max(dev_ms, sh[r]->msm_total_ms);
+    adds += sh[r]->msm_adds;
+  }
+  if (rc != BP_OK) return rc;
+  if (sh.size() > 1) {                                   // stats of a group: the slowest shard, all additions
+    ctx->msm_accumulate_ms = acc_ms;
+    ctx->msm_total_ms = dev_ms;
+    ctx->msm_adds = adds;
+  }
+  *out = acc;
+  return BP_OK;
+}
+
 int bp_msm_g1_partial(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
                       int scalars_on_device, uint8_t out144[144]) {
   if (!ctx || !out144 || !fmt_ok(scalar_fmt) || (n_scalars && !scalars)) return BP_ERR_INVALID_ARG;
-  SrsEntry* e;
-  BP_TRY(srs_find(ctx, srs_handle, &e));
-  if (first > e->n) return fail(ctx, BP_ERR_INVALID_ARG, "SRS offset out of bounds", hipSuccess, __FILE__, __LINE__);
-  BP_HIP(ctx, hipSetDevice(ctx->device));
-  const size_t n = std::min(n_scalars, e->n - first);          // zip() truncation, msm.rs:29
-  const fr_t* d_scalars = (const fr_t*)scalars;
-  if (!scalars_on_device) {
-    fr_t* d;
-    BP_TRY(ws_get(ctx, "io.scalars", n * sizeof(fr_t), (void**)&d));
-    if (n) BP_HIP(ctx, hipMemcpyAsync(d, scalars, n * sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
-    d_scalars = d;
-  }
   g1_proj r;
-  // fixed-base tables pay once the bucket adds outweigh the fixed 2^table_c reduction
-  const bool tables = e->d_table && 8 * (uint64_t)n >= (1ull << e->table_c);
-  if (tables) BP_TRY(msm_run(ctx, e->d_table + first, n, d_scalars, scalar_fmt, e->table_c, e->n, &r));
-  else BP_TRY(msm_run(ctx, e->d_points28 + first, n, d_scalars, scalar_fmt, 0, 0, &r));
+  BP_TRY(msm_all_shards(ctx, srs_handle, first, scalars, n_scalars, scalar_fmt, scalars_on_device, &r));
   memcpy(out144, &r, 144);
   return BP_OK;
 }
@@ -420,6 +637,28 @@ int bp_msm_g1(bp_ctx* ctx, uint64_t srs_handle, const void* scalars, size_t n_sc
   BP_TRY(bp_msm_g1_partial(ctx, srs_handle, 0, scalars, n_scalars, scalar_fmt, 0, part));
   g1_proj r;
   memcpy(&r, part, 144);
+  host_encode96(out96, r);
+  return BP_OK;
+}
+
+int bp_msm_g1_blob_device(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
+                          int scalars_on_device, void* d_blob) {
+  if (!ctx || !d_blob || !fmt_ok(scalar_fmt) || (n_scalars && !scalars)) return BP_ERR_INVALID_ARG;
+  if (is_group(ctx)) return fail(ctx, BP_ERR_INVALID_ARG, "blob records are the one-process-per-GPU exchange; a bp_init_multi context combines its shards itself", hipSuccess, __FILE__, __LINE__);
+  SrsEntry* e;
+  BP_TRY(srs_find(ctx, srs_handle, &e));
+  if (first > e->n) return fail(ctx, BP_ERR_INVALID_ARG, "SRS offset out of bounds", hipSuccess, __FILE__, __LINE__);
+  const size_t n = std::min(n_scalars, e->n - first);
+  DeviceGuard guard(ctx->device);
+  MsmPending pend;
+  BP_TRY(msm_shard_launch(ctx, e, first, scalars, n, scalar_fmt, scalars_on_device ? 1 : 0, ctx->device, nullptr, 0, d_blob, &pend));
+  return msm_finish(ctx, pend, nullptr);
+}
+
+int bp_msm_blobs_combine(const void* blobs, size_t n_blobs, uint8_t out96[96]) {
+  if (!out96 || (n_blobs && !blobs)) return BP_ERR_INVALID_ARG;
+  g1_proj r;
+  BP_TRY(msm_blobs_combine((const uint8_t*)blobs, n_blobs, &r));
   host_encode96(out96, r);
   return BP_OK;
 }
@@ -464,11 +703,55 @@ int bp_msm_last_stats(bp_ctx* ctx, float* accumulate_ms, float* total_device_ms,
 // ---------------------------------------------------------------------------------------------- DFT
 int bp_ntt_fr_device(bp_ctx* ctx, void* d_data, uint32_t log_n, int inverse, size_t batch, size_t stride) {
   if (!ctx || (!d_data && batch)) return BP_ERR_INVALID_ARG;
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  if (batch == 0) {                   // nothing was enqueued: no events to read
+    ctx->ntt_ms = 0;
+    return BP_OK;
+  }
+  DeviceGuard guard(ctx->device);
   BP_TRY(ntt_run(ctx, (fr_t*)d_data, log_n, inverse, batch, stride));
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   BP_HIP(ctx, hipEventElapsedTime(&ctx->ntt_ms, ctx->ev[0], ctx->ev[1]));
   return BP_OK;
+}
+
+// Group context, batch > 1: the columns are independent transforms (NTT option i), column j goes to member
+// j mod R; every member uploads, transforms and downloads its columns on its own stream, nothing is exchanged.
+static int ntt_columns_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, int inverse, int scalar_fmt, size_t batch, size_t stride) {
+  const std::vector<bp_ctx*> sh = shards_of(ctx);
+  const size_t N = (size_t)1 << log_n, R = sh.size();
+  std::vector<fr_t*> dbuf(R, nullptr);
+  std::vector<size_t> cnt(R, 0);
+  int rc = BP_OK;
+  for (size_t r = 0; r < R && rc == BP_OK; r++) {
+    bp_ctx* m = sh[r];
+    cnt[r] = batch / R + (r < batch % R ? 1 : 0);
+    if (cnt[r] == 0) continue;
+    DeviceGuard guard(m->device);
+    rc = lift(ctx, m, ws_get(m, "io.ntt", cnt[r] * N * sizeof(fr_t), (void**)&dbuf[r]));
+    for (size_t j = 0; j < cnt[r] && rc == BP_OK; j++) {
+      hipError_t e = hipMemcpyAsync(dbuf[r] + j * N, data + (r + j * R) * stride * sizeof(fr_t), N * sizeof(fr_t), hipMemcpyHostToDevice, m->stream);
+      if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "NTT column upload", e, __FILE__, __LINE__);
+    }
+    if (rc == BP_OK && scalar_fmt == BP_FR_BYTES_LE) rc = lift(ctx, m, fr_convert_run(m, dbuf[r], cnt[r] * N, 0));
+    if (rc == BP_OK) rc = lift(ctx, m, ntt_run(m, dbuf[r], log_n, inverse, cnt[r], N));
+    if (rc == BP_OK && scalar_fmt == BP_FR_BYTES_LE) rc = lift(ctx, m, fr_convert_run(m, dbuf[r], cnt[r] * N, 1));
+    for (size_t j = 0; j < cnt[r] && rc == BP_OK; j++) {
+      hipError_t e = hipMemcpyAsync(data + (r + j * R) * stride * sizeof(fr_t), dbuf[r] + j * N, N * sizeof(fr_t), hipMemcpyDeviceToHost, m->stream);
+      if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "NTT column download", e, __FILE__, __LINE__);
+    }
+  }
+  float ms = 0;
+  for (size_t r = 0; r < R; r++) {                       // wait for every member, also after a failure elsewhere
+    if (cnt[r] == 0) continue;
+    DeviceGuard guard(sh[r]->device);
+    hipError_t e = hipStreamSynchronize(sh[r]->stream);
+    if (e != hipSuccess && rc == BP_OK) rc = fail(ctx, BP_ERR_HIP, "NTT columns", e, __FILE__, __LINE__);
+    float t = 0;
+    if (rc == BP_OK && hipEventElapsedTime(&t, sh[r]->ev[0], sh[r]->ev[1]) == hipSuccess) ms = std::max(ms, t);
+  }
+  ctx->ntt_ms = ms;
+  ctx->ntt_passes = sh[0]->ntt_passes;
+  return rc;
 }
 
 int bp_ntt_fr(bp_ctx* ctx, void* data, uint32_t log_n, int inverse, int scalar_fmt, size_t batch, size_t stride) {
@@ -477,7 +760,9 @@ int bp_ntt_fr(bp_ctx* ctx, void* data, uint32_t log_n, int inverse, int scalar_f
   if (batch == 0) return BP_OK;
   const size_t N = (size_t)1 << log_n;
   if (batch > 1 && stride < N) return fail(ctx, BP_ERR_INVALID_ARG, "NTT stride < N", hipSuccess, __FILE__, __LINE__);
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  if (batch > 65535) return fail(ctx, BP_ERR_TOO_LARGE, "NTT batch > 65535", hipSuccess, __FILE__, __LINE__);
+  if (is_group(ctx) && batch > 1) return ntt_columns_over_members(ctx, (uint8_t*)data, log_n, inverse, scalar_fmt, batch, stride);
+  DeviceGuard guard(ctx->device);
   const size_t span = (batch - 1) * stride + N;
   fr_t* d;
   BP_TRY(upload_fr(ctx, "io.ntt", data, span, span, scalar_fmt, &d));
@@ -514,7 +799,7 @@ int bp_roots_of_unity(bp_ctx* ctx, uint64_t group_order, int scalar_fmt, void* o
   fr_t w;
   if (!host_root_of_unity(w, group_order)) return fail(ctx, BP_ERR_INVALID_ARG, "group_order == 0", hipSuccess, __FILE__, __LINE__);
   if (group_order > ((uint64_t)1 << 28)) return fail(ctx, BP_ERR_TOO_LARGE, "group_order > 2^28", hipSuccess, __FILE__, __LINE__);
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   fr_t* d;
   BP_TRY(ws_get(ctx, "io.roots", group_order * sizeof(fr_t), (void**)&d));
   BP_TRY(roots_run(ctx, w, group_order, d));
@@ -533,7 +818,7 @@ int bp_fr_convert(const void* in, size_t n, int from_fmt, int to_fmt, void* out)
 
 int bp_fr_synthetic_device(bp_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
   if (!ctx || (n && !d_out)) return BP_ERR_INVALID_ARG;
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   BP_TRY(fr_synthetic_run(ctx, (fr_t*)d_out, n, seed));
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return BP_OK;
@@ -545,7 +830,7 @@ int bp_poly_evaluate(bp_ctx* ctx, const void* coeffs, size_t n, int basis, const
   if (basis != BP_BASIS_MONOMIAL) return fail(ctx, BP_ERR_BASIS, "coeffs_evaluate needs the Monomial basis", hipSuccess, __FILE__, __LINE__);
   fr_t x, r;
   if (!fr_bytes_to_mont(x, (const uint8_t*)x32, scalar_fmt)) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q", hipSuccess, __FILE__, __LINE__);
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   fr_t* d;
   BP_TRY(upload_fr(ctx, "io.poly_a", coeffs, n, n, scalar_fmt, &d));
   BP_TRY(poly_eval_run(ctx, d, n, x, &r));
@@ -562,7 +847,7 @@ static int poly_addsub(bp_ctx* ctx, const void* a, size_t na, const void* b, siz
   *n_out = n;
   if (n == 0) return BP_OK;
   if (!out) return BP_ERR_INVALID_ARG;
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   fr_t *da, *db, *dout;
   // add/sub commute with the Montgomery map, so canonical inputs need no conversion at all
   BP_TRY(upload_fr(ctx, "io.poly_a", a, na, na, BP_FR_MONT, &da));
@@ -585,7 +870,7 @@ int bp_poly_scalar_op(bp_ctx* ctx, const void* a, size_t n, int basis, const voi
                                                            : fail(ctx, BP_ERR_INVALID_ARG, "empty polynomial", hipSuccess, __FILE__, __LINE__);
   fr_t s;
   if (!fr_bytes_to_mont(s, (const uint8_t*)s32, scalar_fmt)) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q", hipSuccess, __FILE__, __LINE__);
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   fr_t *da, *dout;
   BP_TRY(upload_fr(ctx, "io.poly_a", a, n, n, scalar_fmt, &da));
   BP_TRY(ws_get(ctx, "io.poly_out", n * sizeof(fr_t), (void**)&dout));
@@ -610,7 +895,7 @@ int bp_poly_mul(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb,
   while (((size_t)1 << k) < target) k++;
   if (k > 28) return fail(ctx, BP_ERR_TOO_LARGE, "product too long", hipSuccess, __FILE__, __LINE__);
   const size_t N = (size_t)1 << k;
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   fr_t* d;
   BP_TRY(ws_get(ctx, "io.poly_mul", 2 * N * sizeof(fr_t), (void**)&d));
   BP_HIP(ctx, hipMemsetAsync(d, 0, 2 * N * sizeof(fr_t), ctx->stream));
@@ -636,7 +921,7 @@ int bp_poly_div(bp_ctx* ctx, const void* a, size_t na, const void* b, size_t nb,
   if (na < nb) return BP_OK;
   if (!out) return BP_ERR_INVALID_ARG;
   const size_t nq = na - nb + 1;
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   fr_t *da, *db, *dq;
   BP_TRY(upload_fr(ctx, "io.poly_a", a, na, na, scalar_fmt, &da));
   BP_TRY(upload_fr(ctx, "io.poly_b", b, nb, nb, scalar_fmt, &db));
@@ -669,7 +954,7 @@ static int poly_addsub_device(bp_ctx* ctx, const void* a, size_t na, const void*
   *n_out = n;
   if (n == 0) return BP_OK;
   if (!out) return BP_ERR_INVALID_ARG;
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   BP_TRY(fr_binary_run(ctx, (const fr_t*)a, na, (const fr_t*)b, nb, (fr_t*)out, n, op));
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return BP_OK;
@@ -685,7 +970,7 @@ int bp_poly_scalar_op_device(bp_ctx* ctx, const void* d_a, size_t n, int basis, 
   if (n == 0) return op == 2 || basis == BP_BASIS_LAGRANGE ? BP_OK : fail(ctx, BP_ERR_INVALID_ARG, "empty polynomial", hipSuccess, __FILE__, __LINE__);
   fr_t s;
   memcpy(&s, s32_mont, 32);
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   const fr_t* a = (const fr_t*)d_a;
   fr_t* out = (fr_t*)d_out;
   if (op == 2) {
@@ -708,7 +993,7 @@ int bp_poly_mul_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b,
   while (((size_t)1 << k) < target) k++;
   if (k > 28) return fail(ctx, BP_ERR_TOO_LARGE, "product too long", hipSuccess, __FILE__, __LINE__);
   const size_t N = (size_t)1 << k;
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   fr_t* d;
   BP_TRY(ws_get(ctx, "io.poly_mul", 2 * N * sizeof(fr_t), (void**)&d));
   BP_HIP(ctx, hipMemsetAsync(d, 0, 2 * N * sizeof(fr_t), ctx->stream));
@@ -725,7 +1010,7 @@ int bp_poly_mul_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b,
 int bp_poly_div_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b, size_t nb, int basis, void* d_out, size_t* n_out) {
   if (!ctx || !n_out || !basis_ok(basis) || (na && !d_a) || (nb && !d_b)) return BP_ERR_INVALID_ARG;
   if (basis != BP_BASIS_MONOMIAL) return fail(ctx, BP_ERR_BASIS, "Div needs the Monomial basis (polynomial.rs:319)", hipSuccess, __FILE__, __LINE__);
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   size_t na_eff, nb_eff, dummy, mid_nonzero = 0;
   BP_TRY(fr_nonzero_stats_run(ctx, (const fr_t*)d_a, na, 0, 0, &na_eff, &dummy));           // trailing zeros trimmed (:325-339)
   BP_TRY(fr_nonzero_stats_run(ctx, (const fr_t*)d_b, nb, 0, 0, &nb_eff, &dummy));
@@ -769,7 +1054,7 @@ int bp_poly_evaluate_device(bp_ctx* ctx, const void* d_coeffs, size_t n, int bas
   if (basis != BP_BASIS_MONOMIAL) return fail(ctx, BP_ERR_BASIS, "coeffs_evaluate needs the Monomial basis", hipSuccess, __FILE__, __LINE__);
   fr_t x, r;
   memcpy(&x, x32_mont, 32);
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   BP_TRY(poly_eval_run(ctx, (const fr_t*)d_coeffs, n, x, &r));
   memcpy(out32_mont, &r, 32);
   return BP_OK;
@@ -778,7 +1063,7 @@ int bp_poly_scale_powers_device(bp_ctx* ctx, const void* d_a, size_t n, const vo
   if (!ctx || !w32_mont || (n && (!d_a || !d_out))) return BP_ERR_INVALID_ARG;
   fr_t w;
   memcpy(&w, w32_mont, 32);
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   BP_TRY(fr_scale_powers_run(ctx, (const fr_t*)d_a, n, w, (fr_t*)d_out));
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return BP_OK;
@@ -788,7 +1073,7 @@ int bp_roots_of_unity_device(bp_ctx* ctx, uint64_t group_order, void* d_out) {
   fr_t w;
   if (!host_root_of_unity(w, group_order)) return fail(ctx, BP_ERR_INVALID_ARG, "group_order == 0", hipSuccess, __FILE__, __LINE__);
   if (group_order > ((uint64_t)1 << 28)) return fail(ctx, BP_ERR_TOO_LARGE, "group_order > 2^28", hipSuccess, __FILE__, __LINE__);
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   BP_TRY(roots_run(ctx, w, group_order, (fr_t*)d_out));
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return BP_OK;
@@ -801,7 +1086,7 @@ int bp_grand_product_device(bp_ctx* ctx, const void* a, const void* b, const voi
   fr_t beta, gamma, k1, k2, root;
   memcpy(&beta, beta32, 32); memcpy(&gamma, gamma32, 32); memcpy(&k1, k1_32, 32); memcpy(&k2, k2_32, 32);
   host_root_of_unity(root, n);
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   BP_TRY(grand_product_run(ctx, (const fr_t*)a, (const fr_t*)b, (const fr_t*)c, (const fr_t*)s1, (const fr_t*)s2, (const fr_t*)s3, n, beta, gamma,
                            k1, k2, root, (fr_t*)d_z));
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -826,7 +1111,7 @@ int bp_grand_product(bp_ctx* ctx, const void* a, const void* b, const void* c, c
       !fr_bytes_to_mont(k1, (const uint8_t*)k1_32, scalar_fmt) || !fr_bytes_to_mont(k2, (const uint8_t*)k2_32, scalar_fmt))
     return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q", hipSuccess, __FILE__, __LINE__);
   host_root_of_unity(root, n);                                   // roots_of_unity(group_order), utils.rs:45-52
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   fr_t* cols;
   BP_TRY(ws_get(ctx, "io.gp_cols", 7 * n * sizeof(fr_t), (void**)&cols));
   const void* src[6] = {a, b, c, s1, s2, s3};
@@ -852,7 +1137,7 @@ int bp_circuit_load(bp_ctx* ctx, uint32_t log_n, const void* const columns[8], i
   if (columns_on_device && scalar_fmt != BP_FR_MONT) return fail(ctx, BP_ERR_INVALID_ARG, "device columns must be Montgomery", hipSuccess, __FILE__, __LINE__);
   for (int k = 0; k < 8; k++)
     if (!columns[k]) return BP_ERR_INVALID_ARG;
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   const size_t n = (size_t)1 << log_n;
   fr_t* lag = nullptr;
   BP_HIP(ctx, hipMalloc((void**)&lag, 8 * n * sizeof(fr_t)));
@@ -880,6 +1165,7 @@ int bp_circuit_free(bp_ctx* ctx, uint64_t handle) {
   if (!ctx) return BP_ERR_INVALID_ARG;
   auto it = ctx->circuits.find(handle);
   if (it == ctx->circuits.end()) return fail(ctx, BP_ERR_INVALID_ARG, "unknown circuit handle", hipSuccess, __FILE__, __LINE__);
+  DeviceGuard guard(ctx->device);
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   circuit_release(it->second);
   ctx->circuits.erase(it);
@@ -937,7 +1223,7 @@ int bp_prove(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_handle, const vo
   fr_t blind[11];
   for (int j = 0; j < 11; j++)
     if (!fr_bytes_to_mont(blind[j], blinders + 32 * j, BP_FR_BYTES_LE)) return fail(ctx, BP_ERR_BAD_SCALAR, "blinder >= q", hipSuccess, __FILE__, __LINE__);
-  BP_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceGuard guard(ctx->device);
   fr_t* wit;
   BP_TRY(ws_get(ctx, "prove.witness", 4 * n * sizeof(fr_t), (void**)&wit));
   const void* cols[4] = {a, b, c, public_input};

@@ -23,7 +23,11 @@ struct SrsEntry {
   g1_affine28* d_points28 = nullptr;    // 112 B/point, 14 x 28-bit limbs, R' = 2^392 (bucket accumulation)
   g1_affine28* d_table = nullptr;       // optional fixed-base tables: row w = 2^(table_c w) * SRS, table_W rows of n points
   uint32_t table_c = 0, table_W = 0;
-  size_t n = 0;
+  size_t n = 0;                         // points resident on this device
+  // multi-GPU group (bp_init_multi): the leader's entry describes the whole SRS, every member holds one contiguous point range
+  size_t first = 0;                     // global index of this device's first point
+  size_t n_global = 0;                  // length of the whole SRS (== n on a single-device context)
+  std::vector<uint64_t> member_handle;  // leader only: handle of the shard on member r (index 0 = the leader's own entry)
 };
 
 // preprocessed circuit of the native prover (prover.hip): CommonPreprocessedInput (program.rs:34-50) resident in HBM,
@@ -54,6 +58,10 @@ struct NttTables {       // per (log_n, inverse); entries are 48-byte 29-bit-lim
 
 struct bp_ctx {
   int device = 0;
+  // multi-GPU group (bp_init_multi): members[0] == this for the leader, empty for a plain bp_init context.
+  // Every member is a full single-device context (own stream, workspaces, NTT tables) driven by the leader's host thread.
+  std::vector<bp_ctx*> members;
+  bp_ctx* leader = nullptr;                        // set on members[1..]
   hipStream_t stream = nullptr;
   bool own_stream = true;
   std::string last_error;
@@ -63,7 +71,7 @@ struct bp_ctx {
   uint64_t next_handle = 1;
   bp::tw29_t* small_tw[2] = {nullptr, nullptr};    // w_1024^j, j < 512: forward / inverse
   std::map<uint32_t, bp::NttTables> ntt_tables;    // key = log_n * 2 + inverse
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [0..3] MSM / NTT timing, [4] cross-stream ordering (groups)
   // stats of the last calls
   float msm_accumulate_ms = 0, msm_total_ms = 0;
   uint64_t msm_adds = 0;
@@ -79,6 +87,23 @@ struct bp_ctx {
 namespace bp {
 
 int fail(bp_ctx* ctx, int code, const char* what, hipError_t e, const char* file, int line);
+
+// Every entry point that takes a ctx runs under one of these: the calling thread's current device is restored on return
+// (torch shares this HIP runtime; a library call must not leave the thread on another GPU).
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) (void)hipSetDevice(device);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+inline bool is_group(const bp_ctx* ctx) { return ctx->members.size() > 1; }
 
 #define BP_HIP(ctx, call)                                                              \
   do {                                                                                 \
@@ -96,8 +121,24 @@ int ws_get(bp_ctx* ctx, const char* name, size_t bytes, void** out);
 int pinned_get(bp_ctx* ctx, size_t bytes, void** out);
 
 // ---- launchers implemented in msm.hip / ntt.hip / poly.hip / srs.hip --------------------------------
+// One MSM = msm_launch (everything enqueued on ctx->stream, nothing waited for) + msm_finish (wait, status, host epilogue).
+// The split lets one host thread keep several devices (or several MSMs of one stream) in flight.  `slot` selects one of
+// MSM_SLOTS result areas in the pinned staging buffer; launches on one stream reuse the device workspaces in stream order.
+constexpr int MSM_SLOTS = 4;
+struct MsmPending {
+  bool empty = true, tables = false, blob = false;
+  uint32_t c = 0, Wr = 0, n_planes = 0;
+  uint64_t adds = 0;
+  const void* h_windows = nullptr;      // pinned: n_planes accumulator slots + the status word
+};
+// d_blob != nullptr: the result stays in HBM as a BP_MSM_BLOB_BYTES record (msm_kernels.cuh) instead of the pinned slot
+int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
+               int slot, void* d_blob, MsmPending* out);
+int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out);
+int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out);
 int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
             g1_proj* host_out);
+int msm_init_device(bp_ctx* ctx);
 int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points28, size_t n, uint32_t c, g1_affine28** d_table,
                    uint32_t* windows);
 int srs_to28_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28** d_out);
@@ -119,7 +160,8 @@ int grand_product_run(bp_ctx* ctx, const fr_t* a, const fr_t* b, const fr_t* c, 
 int roots_run(bp_ctx* ctx, const fr_t& w, size_t n, fr_t* d_out);
 int srs_decode_run(bp_ctx* ctx, const uint8_t* d_bytes, size_t n, g1_affine* d_out);
 int srs_encode_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, uint8_t* d_bytes);
-int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t n, g1_affine* d_out);
+int srs_from_projective_run(bp_ctx* ctx, const g1_proj* d_in, size_t n, g1_affine* d_out);
+int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t first, size_t n, g1_affine* d_out);
 
 int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out);
 void circuit_release(CircuitEntry& e);

@@ -132,15 +132,40 @@ int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_
   return BP_OK;
 }
 
-// d_points28: the unsaturated SRS copy, or (table_c != 0) row 0 of its fixed-base tables with rows table_stride apart
-int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
-            g1_proj* host_out) {
+// accumulator slot (lazy 28-bit limbs, as the kernels leave it) -> the reference's Montgomery limbs
+static g1_proj slot_to_proj(const proj28_slot* slot) {
+  g1_proj28 p;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(slot);
+  for (int j = 0; j < N28; j++) { p.x.l[j] = src[j]; p.y.l[j] = src[N28 + j]; p.z.l[j] = src[2 * N28 + j]; }
+  return g1_proj_from_28(p);
+}
+
+// dynamic-LDS limits are per function AND per device: set them for every context at creation (bp_init), after hipSetDevice
+int msm_init_device(bp_ctx* ctx) {
+  // a full-window histogram at c = 16 needs 128 KiB of dynamic LDS, the plane tree 88 KiB
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_planes_block, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_count, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return BP_OK;
+}
+
+// d_points28: the unsaturated SRS copy, or (table_c != 0) row 0 of its fixed-base tables with rows table_stride apart.
+// Enqueues the whole pipeline and the device-to-host copy of the window sums on ctx->stream; waits for nothing.
+int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
+               int slot, void* d_blob, MsmPending* out) {
+  *out = MsmPending();
+  out->blob = d_blob != nullptr;
   if (n == 0) {
-    *host_out = g1_identity();
-    ctx->msm_accumulate_ms = ctx->msm_total_ms = 0;
-    ctx->msm_adds = 0;
+    if (d_blob) {
+      MsmBlobHeader hdr;
+      memset(&hdr, 0, sizeof hdr);
+      hdr.magic = MSM_BLOB_MAGIC;
+      hipLaunchKernelGGL(msm_write_blob, dim3(1), dim3(64), 0, ctx->stream, (const proj28_slot*)nullptr, hdr, (uint8_t*)d_blob);
+      BP_HIP(ctx, hipGetLastError());
+    }
     return BP_OK;
   }
+  if (slot < 0 || slot >= MSM_SLOTS) return fail(ctx, BP_ERR_INVALID_ARG, "MSM result slot", hipSuccess, __FILE__, __LINE__);
   if (n >= (1ull << 31)) return fail(ctx, BP_ERR_TOO_LARGE, "MSM length >= 2^31", hipSuccess, __FILE__, __LINE__);
   MsmPlan plan;
   make_plan(plan, n, table_c, table_stride);
@@ -172,19 +197,15 @@ int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_
   BP_TRY(ws_get(ctx, "msm.bucket_sum", (size_t)total * sizeof(proj28_slot), (void**)&bucket_sum));
   BP_TRY(ws_get(ctx, "msm.partial", 2 * n_chunks * sizeof(proj28_slot), (void**)&partial));
   const uint32_t n_planes = Wr * per_window;        // tables: A and the c - 1 bit planes; else one sum per window
+  if (n_planes > (uint32_t)MSM_MAX_WINDOWS) return fail(ctx, BP_ERR_TOO_LARGE, "MSM windows", hipSuccess, __FILE__, __LINE__);
   BP_TRY(ws_get(ctx, "msm.block_out", (size_t)Wr * blocks_per_window * per_block * sizeof(proj28_slot), (void**)&block_out));
   BP_TRY(ws_get(ctx, "msm.window_sum", (size_t)n_planes * sizeof(proj28_slot) + 16, (void**)&window_sum));     // + the status word
-  proj28_slot* h_windows;
-  BP_TRY(pinned_get(ctx, (size_t)n_planes * sizeof(proj28_slot) + 16, (void**)&h_windows));
-  uint32_t* h_status = reinterpret_cast<uint32_t*>(h_windows + n_planes);
+  // pinned staging: MSM_SLOTS result areas of the largest possible size, so earlier pending results stay where they are
+  constexpr size_t slot_bytes = (size_t)MSM_MAX_WINDOWS * sizeof(proj28_slot) + 16;
+  uint8_t* h_base;
+  BP_TRY(pinned_get(ctx, MSM_SLOTS * slot_bytes, (void**)&h_base));
+  proj28_slot* h_windows = reinterpret_cast<proj28_slot*>(h_base + (size_t)slot * slot_bytes);
 
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {            // a full-window histogram at c = 16 needs 128 KiB of dynamic LDS, the plane tree 88 KiB
-    BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_planes_block, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_count, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    lds_attr_set = true;
-  }
   hipStream_t st = ctx->stream;
   BP_HIP(ctx, hipEventRecord(ctx->ev[0], st));
   BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4 + 8, st));
@@ -225,26 +246,104 @@ int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_
                        long_count + 1, reinterpret_cast<uint32_t*>(window_sum + n_planes));
   }
   BP_HIP(ctx, hipGetLastError());
-  BP_HIP(ctx, hipMemcpyAsync(h_windows, window_sum, (size_t)n_planes * sizeof(proj28_slot) + 4, hipMemcpyDeviceToHost, st));    // sums + status
+  if (d_blob) {
+    MsmBlobHeader hdr;
+    memset(&hdr, 0, sizeof hdr);
+    hdr.magic = MSM_BLOB_MAGIC;
+    hdr.c = plan.c;
+    hdr.Wr = Wr;
+    hdr.n_planes = n_planes;
+    hdr.tables = table_c != 0;
+    hipLaunchKernelGGL(msm_write_blob, dim3(1), dim3(256), 0, st, window_sum, hdr, (uint8_t*)d_blob);
+    BP_HIP(ctx, hipGetLastError());
+  } else {
+    BP_HIP(ctx, hipMemcpyAsync(h_windows, window_sum, (size_t)n_planes * sizeof(proj28_slot) + 4, hipMemcpyDeviceToHost, st));    // sums + status
+  }
   BP_HIP(ctx, hipEventRecord(ctx->ev[3], st));
-  BP_HIP(ctx, hipStreamSynchronize(st));
-  if (*h_status) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q in a canonical-bytes input", hipSuccess, __FILE__, __LINE__);
+  out->empty = false;
+  out->tables = table_c != 0;
+  out->c = plan.c;
+  out->Wr = Wr;
+  out->n_planes = n_planes;
+  out->adds = max_entries;      // upper bound: zero digits are skipped (about n*W/2^c of them)
+  out->h_windows = h_windows;
+  return BP_OK;
+}
+
+// waits for the stream, checks the scalar status and runs the host epilogue: window sums / planes back to the reference's
+// Montgomery limbs, then Horner (msm.rs:107-115).  The timing stats describe the last launched MSM of this ctx.
+int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out) {
+  if (pend.empty) {
+    if (host_out) *host_out = g1_identity();
+    ctx->msm_accumulate_ms = ctx->msm_total_ms = 0;
+    ctx->msm_adds = 0;
+    if (pend.blob) BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BP_OK;
+  }
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   BP_HIP(ctx, hipEventElapsedTime(&ctx->msm_accumulate_ms, ctx->ev[1], ctx->ev[2]));
   BP_HIP(ctx, hipEventElapsedTime(&ctx->msm_total_ms, ctx->ev[0], ctx->ev[3]));
-  ctx->msm_c = plan.c;
-  ctx->msm_tables = table_c != 0;
-  ctx->msm_adds = max_entries;      // upper bound: zero digits are skipped (about n*W/2^c of them)
-  // host epilogue: window sums / planes back to the reference's Montgomery limbs, then Horner (msm.rs:107-115)
-  std::vector<g1_proj> windows(n_planes);
-  for (uint32_t w = 0; w < n_planes; w++) {
-    g1_proj28 p;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(&h_windows[w]);
-    for (int j = 0; j < N28; j++) { p.x.l[j] = src[j]; p.y.l[j] = src[N28 + j]; p.z.l[j] = src[2 * N28 + j]; }
-    windows[w] = g1_proj_from_28(p);
+  ctx->msm_c = pend.c;
+  ctx->msm_tables = pend.tables;
+  ctx->msm_adds = pend.adds;
+  if (pend.blob) {                      // the result stayed in HBM (bp_msm_g1_blob_device); its status word travels in the record
+    if (host_out) *host_out = g1_identity();
+    return BP_OK;
   }
-  if (table_c) host_plane_horner(*host_out, windows.data(), Wr, plan.c);
-  else host_horner(*host_out, windows.data(), Wr, plan.c);
+  const proj28_slot* h_windows = static_cast<const proj28_slot*>(pend.h_windows);
+  const uint32_t n_planes = pend.n_planes;
+  if (*reinterpret_cast<const uint32_t*>(h_windows + n_planes))
+    return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q in a canonical-bytes input", hipSuccess, __FILE__, __LINE__);
+  std::vector<g1_proj> windows(n_planes);
+  for (uint32_t w = 0; w < n_planes; w++) windows[w] = slot_to_proj(&h_windows[w]);
+  if (pend.tables) host_plane_horner(*host_out, windows.data(), pend.Wr, pend.c);
+  else host_horner(*host_out, windows.data(), pend.Wr, pend.c);
   return BP_OK;
+}
+
+// Host side of the one-process-per-GPU exchange: n_blobs records (BP_MSM_BLOB_BYTES apart, host memory).  Records that
+// share the window layout (the normal case: equal shard sizes) are added slot by slot first, so the Horner pass over the
+// c bit positions (msm.rs:107-115) runs once instead of once per rank.
+int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out) {
+  g1_proj total = g1_identity();
+  std::vector<bool> done(n_blobs, false);
+  for (size_t i = 0; i < n_blobs; i++) {
+    MsmBlobHeader h;
+    memcpy(&h, blobs + i * BP_MSM_BLOB_BYTES, sizeof h);
+    if (h.magic != MSM_BLOB_MAGIC || h.n_planes > (uint32_t)MSM_MAX_WINDOWS) return BP_ERR_INVALID_ARG;
+    if (h.status) return BP_ERR_BAD_SCALAR;
+  }
+  for (size_t i = 0; i < n_blobs; i++) {
+    if (done[i]) continue;
+    MsmBlobHeader h;
+    memcpy(&h, blobs + i * BP_MSM_BLOB_BYTES, sizeof h);
+    done[i] = true;
+    if (h.n_planes == 0) continue;
+    std::vector<g1_proj> sum(h.n_planes);
+    const proj28_slot* slots = reinterpret_cast<const proj28_slot*>(blobs + i * BP_MSM_BLOB_BYTES + sizeof(MsmBlobHeader));
+    for (uint32_t w = 0; w < h.n_planes; w++) sum[w] = slot_to_proj(&slots[w]);
+    for (size_t k = i + 1; k < n_blobs; k++) {
+      MsmBlobHeader g;
+      memcpy(&g, blobs + k * BP_MSM_BLOB_BYTES, sizeof g);
+      if (done[k] || g.c != h.c || g.Wr != h.Wr || g.n_planes != h.n_planes || g.tables != h.tables) continue;
+      done[k] = true;
+      const proj28_slot* sk = reinterpret_cast<const proj28_slot*>(blobs + k * BP_MSM_BLOB_BYTES + sizeof(MsmBlobHeader));
+      for (uint32_t w = 0; w < h.n_planes; w++) g1_add(sum[w], sum[w], slot_to_proj(&sk[w]));
+    }
+    g1_proj part;
+    if (h.tables) host_plane_horner(part, sum.data(), h.Wr, h.c);
+    else host_horner(part, sum.data(), h.Wr, h.c);
+    g1_add(total, total, part);
+  }
+  *out = total;
+  return BP_OK;
+}
+
+int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
+            g1_proj* host_out) {
+  MsmPending pend;
+  BP_TRY(msm_launch(ctx, d_points28, n, d_scalars, fmt, table_c, table_stride, 0, nullptr, &pend));
+  return msm_finish(ctx, pend, host_out);
 }
 
 }  // namespace bp

@@ -404,6 +404,25 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
   store_proj28(complete ? &bucket_sum[g] : &partial[2 * (size_t)t + (run_start == p0 ? 0 : 1)], acc);
 }
 
+// ---------------------------------------------------------------- blob (one process per GPU)
+// bp_msm_g1_blob_device: the window sums / bit planes of one rank's MSM as a self-describing record in HBM, so the ranks'
+// records can be all-gathered on the device and combined after a single device-to-host copy (bp_msm_blobs_combine).
+struct MsmBlobHeader {
+  uint32_t magic, c, Wr, n_planes, tables, status;
+  uint32_t pad[10];
+};
+static_assert(sizeof(MsmBlobHeader) == 64, "blob header");
+constexpr uint32_t MSM_BLOB_MAGIC = 0x424d5042u;      // "BPMB"
+__global__ void __launch_bounds__(256) msm_write_blob(const proj28_slot* __restrict__ window_sum, MsmBlobHeader hdr, uint8_t* __restrict__ blob) {
+  uint4* dst = reinterpret_cast<uint4*>(blob + sizeof(MsmBlobHeader));
+  const uint4* src = reinterpret_cast<const uint4*>(window_sum);
+  for (uint32_t i = threadIdx.x; i < hdr.n_planes * 11u; i += blockDim.x) dst[i] = src[i];
+  if (threadIdx.x == 0) {
+    if (hdr.n_planes) hdr.status = *reinterpret_cast<const uint32_t*>(window_sum + hdr.n_planes);     // scalar >= q seen by msm_digits
+    *reinterpret_cast<MsmBlobHeader*>(blob) = hdr;
+  }
+}
+
 // ---------------------------------------------------------------- 6. fixup
 // Buckets that straddle chunk edges: add their partials.  Short chains (the common case: 2-3 partials) are
 // summed by one lane; a bucket cut into more than FIXUP_LONG chunks (skewed scalars, the narrow top window)

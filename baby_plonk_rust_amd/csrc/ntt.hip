@@ -26,12 +26,10 @@ int ntt_init_tables(bp_ctx* ctx) {
     BP_HIP(ctx, hipMalloc((void**)&ctx->small_tw[inv], 512 * sizeof(tw29_t)));
     BP_TRY(make_table(ctx, host_root_pow2(inv != 0, NTT_SMALL_MAX_LOG), 512, 0, nullptr, nullptr, ctx->small_tw[inv]));
   }
-  static bool attr = false;
-  if (!attr) {
-    BP_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    BP_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_last, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  // per function and per device: set for every context (this runs in bp_init, after hipSetDevice)
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)ntt_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_last, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return BP_OK;
 }
 

@@ -23,9 +23,16 @@ int srs_encode_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, uint8_t* d_byte
   BP_HIP(ctx, hipGetLastError());
   return BP_OK;
 }
-int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t n, g1_affine* d_out) {
+int srs_from_projective_run(bp_ctx* ctx, const g1_proj* d_in, size_t n, g1_affine* d_out) {
   if (n == 0) return BP_OK;
-  hipLaunchKernelGGL(srs_generate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, d, mode, n, d_out);
+  const size_t lanes = (n + PROJ_GROUP - 1) / PROJ_GROUP;
+  hipLaunchKernelGGL(srs_from_projective, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, d_in, n, d_out);
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
+int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t first, size_t n, g1_affine* d_out) {
+  if (n == 0) return BP_OK;
+  hipLaunchKernelGGL(srs_generate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, d, mode, first, n, d_out);
   BP_HIP(ctx, hipGetLastError());
   return BP_OK;
 }

@@ -92,10 +92,43 @@ __global__ void __launch_bounds__(256) srs_encode96(const g1_affine* __restrict_
     dst[j] = (uint32_t)buf[4 * j] | ((uint32_t)buf[4 * j + 1] << 8) | ((uint32_t)buf[4 * j + 2] << 16) | ((uint32_t)buf[4 * j + 3] << 24);
 }
 
+// G1Projective memory images (x | y | z Montgomery limbs, g1.rs:442-446) -> affine, the device side of
+// bp_srs_load_projective144.  One lane normalises PROJ_GROUP consecutive points with one shared inversion (Montgomery's
+// trick, G1Projective::batch_normalize g1.rs:806-839); z = 0 (the identity) becomes (0, 0).
+constexpr int PROJ_GROUP = 8;
+__global__ void __launch_bounds__(256) srs_from_projective(const g1_proj* __restrict__ in, size_t n, g1_affine* __restrict__ out) {
+  const size_t base = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * PROJ_GROUP;
+  if (base >= n) return;
+  const uint32_t cnt = n - base < (size_t)PROJ_GROUP ? (uint32_t)(n - base) : (uint32_t)PROJ_GROUP;
+  fp_t prefix[PROJ_GROUP];                          // prefix[j] = z'_0 ... z'_j with z' = z, or 1 where z = 0
+  for (uint32_t j = 0; j < cnt; j++) {
+    fp_t z = in[base + j].z;
+    if (big_is_zero(z)) z = Fp::one();
+    if (j == 0) prefix[0] = z; else Fp::mul(prefix[j], prefix[j - 1], z);
+  }
+  fp_t inv;
+  fp_invert(inv, prefix[cnt - 1]);
+  for (uint32_t j = cnt; j-- > 0;) {
+    const g1_proj p = in[base + j];
+    const bool inf = big_is_zero(p.z);
+    fp_t z = p.z, zinv;
+    if (inf) z = Fp::one();
+    if (j) Fp::mul(zinv, inv, prefix[j - 1]); else zinv = inv;
+    Fp::mul(inv, inv, z);
+    g1_affine r;
+    Fp::mul(r.x, p.x, zinv);
+    Fp::mul(r.y, p.y, zinv);
+    if (inf) { r.x = Fp::zero(); r.y = Fp::zero(); }
+    out[base + j] = r;
+  }
+}
+
 // mode 0: s_i = a^i (a = tau, Montgomery);  mode 1: s_i = a + i*d (Montgomery).  P_i = s_i * G, affine.
-__global__ void __launch_bounds__(256, 2) srs_generate(fr_t a, fr_t d, int mode, size_t n, g1_affine* __restrict__ out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// out[j] = P_{first + j}, j < n: a multi-GPU shard generates its own point range.
+__global__ void __launch_bounds__(256, 2) srs_generate(fr_t a, fr_t d, int mode, size_t first, size_t n, g1_affine* __restrict__ out) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const size_t i = first + j;
   fr_t s;
   if (mode == 0) {
     uint32_t e[2] = {(uint32_t)i, (uint32_t)(i >> 32)};
@@ -111,7 +144,7 @@ __global__ void __launch_bounds__(256, 2) srs_generate(fr_t a, fr_t d, int mode,
   Fr::from_mont(s, s);
   g1_proj g = g1_from_affine(g1_affine_generator()), r;
   g1_mul_scalar(r, g, s);
-  out[i] = g1_to_affine(r);
+  out[j] = g1_to_affine(r);
 }
 
 }  // namespace bp

@@ -3,7 +3,9 @@
 MSM  shards by contiguous POINT RANGE: rank r keeps SRS[lo_r, hi_r) resident in its HBM and receives
      the matching scalar slice; each rank runs the whole Pippenger pipeline on its slice and produces ONE 144-byte
      projective partial.  Elliptic-curve addition is not an RCCL reduction operator, so the "reduce" is a single
-     all-gather of 144 B per rank followed by world-1 complete additions on every rank (bp_g1_sum_partials).
+     all-gather followed by world-1 complete additions on every rank.  What travels is each rank's record of per-window
+     partial sums, left in HBM by bp_msm_g1_blob_device (ShardedMsm); the 144-byte projective form (combine_partials)
+     remains for partials that are already on the host.
 NTT  shards by INDEPENDENT COLUMNS: polynomial j of a batch belongs to rank j mod world; no collective inside a
      transform.  all_gather_columns() is provided for callers that need every column everywhere afterwards.
 """
@@ -11,7 +13,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import api
+from . import _lib, api
 
 
 def shard_range(n, rank, world):
@@ -29,8 +31,13 @@ def my_columns(n_columns, rank, world):
     return list(range(rank, n_columns, world))
 
 
+def _backend_device(ctx_device, group=None):
+    """tensors of a collective live on the GPU under RCCL ("nccl") and on the host under gloo (CPU rehearsals)"""
+    return torch.device("cuda", ctx_device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
 def allgather_partials(partial144, device=None, group=None):
-    """the one collective of the MSM path: every rank contributes 144 bytes, every rank receives world*144"""
+    """144-byte variant (partials already on the host, e.g. produced by another library): every rank contributes 144 bytes"""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return bytes(partial144)
     world = dist.get_world_size(group)
@@ -46,20 +53,64 @@ def combine_partials(partial144, device=None, group=None):
     return api.sum_partials(allgather_partials(partial144, device, group))
 
 
+class ShardedMsm:
+    """The MSM path of one rank: the rank's partial sums stay in HBM (bp_msm_g1_blob_device), ONE all-gather
+    of the records over RCCL/xGMI, ONE device-to-host copy of the gathered buffer, host combine (bp_msm_blobs_combine).
+    Buffers are allocated once; `exchange_s` is the wall time of the last collective + copy + combine."""
+
+    def __init__(self, ctx, group=None):
+        self.ctx, self.group = ctx, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.gpu = torch.device("cuda", ctx.device)
+        self.mine = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu)
+        self.on_gpu = self.world > 1 and dist.get_backend(group) == "nccl"
+        self.gathered = torch.empty(self.world * _lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu if self.on_gpu else "cpu")
+        self.exchange_s = 0.0
+        torch.cuda.synchronize(self.gpu)
+
+    def __call__(self, srs_handle_local, scalars_local=None, device_ptr=None, n=None, first=0):
+        import time
+        self.ctx.msm_blob_device(srs_handle_local, self.mine.data_ptr(), scalars_local, first=first, device_ptr=device_ptr, n=n)
+        t0 = time.perf_counter()
+        if self.world == 1:
+            host = self.mine.cpu()
+        elif self.on_gpu:
+            dist.all_gather_into_tensor(self.gathered, self.mine, group=self.group)       # the path's single collective
+            host = self.gathered.cpu()                                                    # the path's single D2H
+        else:
+            dist.all_gather_into_tensor(self.gathered, self.mine.cpu(), group=self.group)
+            host = self.gathered
+        out = api.combine_blobs(host.numpy().tobytes())
+        self.exchange_s = time.perf_counter() - t0
+        return out
+
+
 def msm_sharded(ctx, srs_handle_local, scalars_local, device_ptr=None, n=None, group=None):
     """sum over ALL ranks' (point, scalar) pairs; `srs_handle_local` is this rank's point-range shard"""
-    part = ctx.msm_partial(srs_handle_local, scalars_local, device_ptr=device_ptr, n=n)
-    return combine_partials(part, torch.device("cuda", ctx.device) if torch.cuda.is_available() else None, group)
+    return ShardedMsm(ctx, group)(srs_handle_local, scalars_local, device_ptr=device_ptr, n=n)
 
 
-def all_gather_columns(local_columns, n_columns, group=None):
-    """local_columns: dict {column index: uint64 array [N, 4]} of this rank's finished columns -> list of all columns"""
+def all_gather_columns(local_columns, n_columns, group=None, device=None):
+    """local_columns: {column index: [N, 4] uint64 array or int64 tensor} of this rank's finished columns (column j belongs
+    to rank j mod world) -> list of all columns.  One all-gather of a [columns per rank, N, 4] tensor: on the GPU over
+    RCCL/xGMI under "nccl" (32 MiB per 2^20-element column), on the host under gloo."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return [local_columns[j] for j in range(n_columns)]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    gathered = [None] * world
-    dist.all_gather_object(gathered, {j: np.asarray(v) for j, v in local_columns.items()}, group=group)
-    merged = {}
-    for d in gathered:
-        merged.update(d)
-    return [merged[j] for j in range(n_columns)]
+    per_rank = (n_columns + world - 1) // world
+    sample = next(iter(local_columns.values())) if local_columns else None
+    as_tensor = isinstance(sample, torch.Tensor)
+    if device is None:
+        device = sample.device if as_tensor and dist.get_backend(group) == "nccl" else _backend_device(torch.cuda.current_device() if torch.cuda.is_available() else 0, group)
+    shape = torch.tensor(list(sample.shape[:1]) if sample is not None else [0], dtype=torch.int64, device=device)
+    dist.all_reduce(shape, op=dist.ReduceOp.MAX, group=group)            # ranks without a column still need the length
+    N = int(shape[0])
+    mine = torch.zeros((per_rank, N, 4), dtype=torch.int64, device=device)
+    for j, v in local_columns.items():
+        assert column_owner(j, world) == rank
+        t = v if as_tensor else torch.from_numpy(np.ascontiguousarray(v, dtype=np.uint64).view(np.int64))
+        mine[j // world].copy_(t.reshape(N, 4))
+    out = torch.empty((world * per_rank, N, 4), dtype=torch.int64, device=device)        # rank r's block at [r * per_rank, ...)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    cols = [out[(j % world) * per_rank + j // world] for j in range(n_columns)]
+    return cols if as_tensor else [c.cpu().numpy().view(np.uint64) for c in cols]

@@ -17,6 +17,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -37,6 +38,11 @@ class Context {
     int rc = bp_init(&ctx_, device);
     if (rc != BP_OK) throw Panic(rc, "bp_init failed: no usable GPU (there is no CPU fallback)");
   }
+  // one context over several GPUs (bp_init_multi): SRS and commitments sharded by point range inside the library
+  explicit Context(const std::vector<int>& devices) {
+    int rc = bp_init_multi(&ctx_, devices.data(), (int)devices.size());
+    if (rc != BP_OK) throw Panic(rc, "bp_init_multi failed: no usable GPU (there is no CPU fallback)");
+  }
   ~Context() { bp_destroy(ctx_); }
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
@@ -44,12 +50,29 @@ class Context {
   void check(int rc, const char* where) const {
     if (rc != BP_OK) throw Panic(rc, std::string(where) + ": " + bp_last_error(ctx_));
   }
+  // the process-wide default: GPU 0, or the comma-separated device list of the environment variable BP_DEVICES
+  // (e.g. BP_DEVICES=0,1,2,3,4,5,6,7 makes every Setup::commit of an unmodified caller span eight GPUs)
   static Context& global() {
-    static Context c(0);
+    static Context c(env_devices());
     return c;
   }
+  int shards() const { return bp_ctx_devices(ctx_, nullptr, 0); }
 
  private:
+  static std::vector<int> env_devices() {
+    std::vector<int> d;
+    if (const char* e = std::getenv("BP_DEVICES")) {
+      for (const char* p = e; *p;) {
+        char* end = nullptr;
+        long v = std::strtol(p, &end, 10);
+        if (end == p) break;
+        d.push_back((int)v);
+        p = *end == ',' ? end + 1 : end;
+      }
+    }
+    if (d.empty()) d.push_back(0);
+    return d;
+  }
   bp_ctx* ctx_ = nullptr;
 };
 
@@ -169,9 +192,12 @@ class Polynomial {
 
 // src/msm.rs:8,76-118
 struct BucketMSM {
-  // points: 96-byte encodings; (b, c) kept for signature parity, the group element does not depend on them
-  static G1 bucket_msm(const std::vector<G1>& points, const std::vector<Scalar>& scalars, size_t /*b*/ = 256, size_t /*c*/ = 4,
+  // points: 96-byte encodings.  b = 256 with c dividing 256 (the reference's only call: setup.rs:36, b = 256, c = 4) does
+  // not change the group element; for other (b, c) the reference drops the low 256 - c*floor(b/c) bits of every scalar
+  // (msm.rs:83,119-139), which is not reproduced: rejected.
+  static G1 bucket_msm(const std::vector<G1>& points, const std::vector<Scalar>& scalars, size_t b = 256, size_t c = 4,
                        Context& ctx = Context::global()) {
+    if (b != 256 || c == 0 || 256 % c != 0) throw Panic(BP_ERR_INVALID_ARG, "bucket_msm: only b = 256 with c dividing 256 is supported");
     uint64_t h = 0;
     ctx.check(bp_srs_load(ctx.raw(), points.empty() ? nullptr : points[0].data(), points.size(), &h), "bucket_msm: points");
     G1 out{};
@@ -181,6 +207,21 @@ struct BucketMSM {
     return out;
   }
 };
+
+// G1Projective as the reference keeps it in memory (g1.rs:442-446): x | y | z, 6 x u64 Montgomery limbs each
+using G1ProjectiveImage = std::array<uint8_t, 144>;
+// the literal seam bucket_msm(points: &[G1Projective], scalars: &[Scalar], b, c) (msm.rs:76-81): upload, multiply, free
+inline G1 bucket_msm_projective(const std::vector<G1ProjectiveImage>& points, const std::vector<Scalar>& scalars, size_t b = 256,
+                                size_t c = 4, Context& ctx = Context::global()) {
+  if (b != 256 || c == 0 || 256 % c != 0) throw Panic(BP_ERR_INVALID_ARG, "bucket_msm: only b = 256 with c dividing 256 is supported");
+  uint64_t h = 0;
+  ctx.check(bp_srs_load_projective144(ctx.raw(), points.empty() ? nullptr : points[0].data(), points.size(), &h), "bucket_msm: points");
+  G1 out{};
+  int rc = bp_msm_g1(ctx.raw(), h, scalars.data(), scalars.size(), BP_FR_MONT, out.data());
+  bp_srs_free(ctx.raw(), h);
+  ctx.check(rc, "bucket_msm");
+  return out;
+}
 
 // src/setup.rs:7-37 (G1 part)
 class Setup {

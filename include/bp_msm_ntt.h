@@ -10,10 +10,18 @@
  *   - plain pointers and sizes only; no ownership transfer; every call returns BP_OK (0) or a negative code
  *     and never throws.  Where the reference panics (assert!, unwrap), the call returns an error instead and
  *     the Rust shim turns it back into a panic.
- *   - one bp_ctx drives one GPU from one host thread (the reference is single-threaded); a ctx owns its HIP stream,
+ *   - a bp_ctx is driven by one host thread (the reference is single-threaded); it owns its HIP stream(s),
  *     workspaces, SRS and circuit handles, so several contexts (one host thread each) may share a GPU and overlap
- *     their work.  Multi-GPU = one process and one ctx per GPU; partial MSM results are exchanged by the caller (RCCL all-gather of the
- *     144-byte projective partials, see bp_msm_g1_partial / bp_g1_sum_partials).
+ *     their work.  Every entry point restores the calling thread's current HIP device before it returns.
+ *   - multi-GPU, two ways:
+ *       in one process   bp_init_multi(device_ids, n): ONE context drives n GPUs.  An SRS loaded or generated through it is
+ *                        sharded by contiguous point range over the GPUs; bp_msm_g1 / bp_commit / bp_prove split the scalars
+ *                        the same way, run the shards concurrently and add the partial sums -- the single-threaded Rust caller
+ *                        of Setup::commit (src/setup.rs:32-37) uses all GPUs without knowing about them.  Batched host NTTs
+ *                        (bp_ntt_fr with batch > 1) spread their independent columns over the GPUs.
+ *       one process per GPU (torch.distributed / MPI launchers): every rank owns a point range in a plain bp_init context,
+ *                        leaves its partial sums in HBM (bp_msm_g1_blob_device), the caller all-gathers those buffers
+ *                        over RCCL/xGMI and every rank combines them (bp_msm_blobs_combine): one collective, one D2H.
  *   - wire formats are the reference's own:
  *       scalar  fmt BP_FR_BYTES_LE : 32-byte little-endian canonical  (Scalar::to_bytes,  scalar.rs:292-304)
  *               fmt BP_FR_MONT     : 4 x u64 Montgomery limbs          (Scalar::to_array,  scalar.rs:35-40)
@@ -53,6 +61,13 @@ enum { BP_BASIS_LAGRANGE = 0, BP_BASIS_MONOMIAL = 1 };   /* polynomial.rs:8-11 *
 
 /* ---- context ------------------------------------------------------------------------------------- */
 int  bp_init(bp_ctx** out, int device_id);
+/* One context over n_devices GPUs (`bp_init(out, device_ids, n_devices)`); device_ids[0] is the primary
+ * device: polynomial operators, the prover's rounds and *_device pointers live there, MSMs and SRS storage span all of
+ * them.  A device may be listed more than once (each listing is an independent shard; used to test the path on one GPU).
+ * n_devices == 1 is the same as bp_init. */
+int  bp_init_multi(bp_ctx** out, const int* device_ids, int n_devices);
+/* number of shards of the context (1 for bp_init); device_ids, if not NULL, receives up to cap of their device ids */
+int  bp_ctx_devices(bp_ctx* ctx, int* device_ids, int cap);
 void bp_destroy(bp_ctx* ctx);
 const char* bp_last_error(bp_ctx* ctx);            /* text of the last error on this ctx ("" if none) */
 const char* bp_version(void);
@@ -62,8 +77,17 @@ int  bp_synchronize(bp_ctx* ctx);
 
 /* ---- SRS: Setup.powers_of_x (src/setup.rs:7-10), resident in HBM ----------------------------------- */
 /* Upload n points in the 96-byte encoding.  Replaces handing &self.powers_of_x to bucket_msm on every
- * commit (setup.rs:36): the SRS is immutable after construction, so it is uploaded once and cached. */
+ * commit (setup.rs:36): the SRS is immutable after construction, so it is uploaded once and cached.
+ * Checks = G1Affine::from_uncompressed_unchecked + is_on_curve (g1.rs:273-322, 101-106): canonical coordinates, flag
+ * bits, curve equation -> BP_ERR_BAD_POINT.  Subgroup membership (is_torsion_free, the extra check of the checked
+ * decoder from_uncompressed) is NOT tested: an SRS comes from a trusted setup, as the reference's own Setup does. */
 int  bp_srs_load(bp_ctx* ctx, const uint8_t* points96, size_t n, uint64_t* srs_handle);
+/* The literal bucket_msm(points: &[G1Projective], ..) seam (src/msm.rs:76-81): n points as the in-memory image of
+ * G1Projective (x | y | z, 6 x u64 Montgomery limbs each = 144 bytes, g1.rs:442-446), e.g. the Vec<G1Projective> of
+ * Setup::powers_of_x handed over as a byte slice.  Normalised on the GPU (one shared inversion per 8 points, what
+ * G1Projective::batch_normalize does on the host, g1.rs:806-839); z = 0 is the identity.  No curve check: the type
+ * guarantees it (as G1Affine::from(&G1Projective) assumes). */
+int  bp_srs_load_projective144(bp_ctx* ctx, const uint8_t* points144, size_t n, uint64_t* srs_handle);
 /* Setup::generate_srs(powers, tau) (setup.rs:12-31): P_i = tau^i * G, generated on the GPU. tau: 32-byte LE. */
 int  bp_srs_generate(bp_ctx* ctx, size_t powers, const uint8_t tau32[32], uint64_t* srs_handle);
 /* Synthetic benchmark points P_i = (a + i*d) * G, generated on the GPU. */
@@ -86,7 +110,10 @@ int  bp_srs_table_info(bp_ctx* ctx, uint64_t srs_handle, uint32_t* window_bits, 
 
 /* ---- MSM: BucketMSM::bucket_msm(points, scalars, b, c) (src/msm.rs:76-118) ----------------------- */
 /* sum_{i < min(n_scalars, srs_len - first)} s_i * P_{first+i}   (zip truncation of msm.rs:29).
- * The window parameters (b, c) of the reference do not change the group element and are not taken.
+ * The window parameters (b, c) of the reference are not taken: for b = 256 and c dividing 256 -- the only configuration
+ * the reference calls it with (setup.rs:36: b = 256, c = 4) -- they do not change the group element.  (For other values
+ * msm.rs:83,119-139 drops the low 256 - c*floor(b/c) bits of every scalar; that is not reproduced, and the mirrors of
+ * BucketMSM::bucket_msm reject such (b, c).)
  * out96: affine result in the 96-byte encoding (identity = 0x40 then zeros). */
 int  bp_msm_g1(bp_ctx* ctx, uint64_t srs_handle, const void* scalars, size_t n_scalars, int scalar_fmt,
                uint8_t out96[96]);
@@ -95,6 +122,16 @@ int  bp_msm_g1(bp_ctx* ctx, uint64_t srs_handle, const void* scalars, size_t n_s
  * points to HBM. */
 int  bp_msm_g1_partial(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars,
                        int scalar_fmt, int scalars_on_device, uint8_t out144[144]);
+/* One process per GPU: the same sum as bp_msm_g1_partial, left in HBM as an opaque BP_MSM_BLOB_BYTES record at d_blob (the
+ * per-window / per-bit-plane partial sums of this rank, not yet combined).  The caller all-gathers the records of all
+ * ranks on the device (RCCL) and hands the gathered host copy to bp_msm_blobs_combine: one collective and one
+ * device-to-host copy per MSM, no host hop before the exchange. */
+#define BP_MSM_BLOB_BYTES 22592u      /* 64-byte header + 128 accumulator slots of 176 bytes */
+int  bp_msm_g1_blob_device(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
+                           int scalars_on_device, void* d_blob);
+/* Host-side: combine n_blobs records (host memory, BP_MSM_BLOB_BYTES apart) into the affine result.  Records with the
+ * same window layout are added slot by slot before the one Horner pass (msm.rs:107-115). */
+int  bp_msm_blobs_combine(const void* blobs, size_t n_blobs, uint8_t out96[96]);
 /* Host-side: add n projective partials (complete addition, g1.rs:670-712) and normalise (g1.rs:49-63). */
 int  bp_g1_sum_partials(const uint8_t* partials144, size_t n, uint8_t out96[96]);
 /* Host-side conversions of single points (for the Rust shim's G1Projective <-> bytes plumbing). */

@@ -87,3 +87,59 @@ def test_host_point_compression_against_the_reference_fixture():
         assert bytes(out) == comp[48 * i: 48 * i + 48], i
     bad = np.full(96, 0xFF, dtype=np.uint8)
     assert lib.bp_g1_bytes96_to_compressed48(bad.ctypes.data, out.ctypes.data) == -3
+
+
+def _slot(point_int):
+    """an accumulator slot as the MSM kernels leave it (msm_kernels.cuh proj28_slot): x | y | z, 14 limbs of 28 bits each of
+    v * 2^392 mod p, + 2 pad words; built with Python integers only"""
+    P = M.P
+    x, y, z = (point_int[0], point_int[1], 1) if point_int is not None else (0, 1, 0)
+    words = []
+    for v in (x, y, z):
+        m = v * pow(2, 392, P) % P
+        words += [(m >> (28 * i)) & 0xFFFFFFF for i in range(14)]
+    return np.array(words + [0, 0], dtype=np.uint32).tobytes()
+
+
+def _blob(c, slots, tables, status=0):
+    hdr = np.zeros(16, dtype=np.uint32)
+    hdr[:6] = [0x424D5042, c, 1 if tables else len(slots), len(slots), int(tables), status]
+    body = b"".join(slots)
+    return hdr.tobytes() + body + bytes(_lib.MSM_BLOB_BYTES - 64 - len(body))
+
+
+def test_blob_combine_host_side():
+    """bp_msm_blobs_combine (the host end of the one-process-per-GPU exchange) on records written by hand: window sums
+    T_w = k_w G combine to sum_w 2^(c w) k_w G (msm.rs:107-115); bit-plane records (fixed-base tables) to
+    (A + sum_j 2^j T_j) G; records of equal layout are added slot by slot, others separately; no GPU"""
+    rnd = __import__("random").Random(8)
+    c, W = 5, 4
+    total, blobs = 0, []
+    for _ in range(3):                                   # three ranks, per-window layout
+        ks = [rnd.randrange(1, M.Q) for _ in range(W)]
+        ks[1] = 0                                        # an empty window (identity slot)
+        total += sum(k << (c * w) for w, k in enumerate(ks))
+        blobs.append(_blob(c, [_slot(M.ec_mul(k)) for k in ks], False))
+    assert bp.combine_blobs(b"".join(blobs)) == M.enc96(M.ec_mul(total % M.Q))
+    # a rank with the bit-plane layout (A, T_0 .. T_{c-2}) and one with a different window width
+    ks = [rnd.randrange(1, M.Q) for _ in range(c)]
+    total += ks[0] + sum(k << j for j, k in enumerate(ks[1:]))
+    blobs.append(_blob(c, [_slot(M.ec_mul(k)) for k in ks], True))
+    ks = [rnd.randrange(1, M.Q) for _ in range(3)]
+    total += sum(k << (7 * w) for w, k in enumerate(ks))
+    blobs.append(_blob(7, [_slot(M.ec_mul(k)) for k in ks], False))
+    blobs.append(_blob(0, [], False))                    # an empty shard
+    assert bp.combine_blobs(b"".join(blobs)) == M.enc96(M.ec_mul(total % M.Q))
+    assert bp.combine_blobs(b"") == M.enc96(None)
+    with pytest.raises(bp.BpError) as e:
+        bp.combine_blobs(_blob(c, [_slot(M.ec_mul(1))] * W, False, status=1))
+    assert e.value.code == -4
+    with pytest.raises(bp.BpError):
+        bp.combine_blobs(bytes(_lib.MSM_BLOB_BYTES))
+
+
+def test_bucket_msm_rejects_window_parameters_the_reference_truncates():
+    """msm.rs:83,119-139: for b != 256 or c not dividing 256 the reference drops low scalar bits; the mirrors refuse"""
+    for b, c in ((256, 3), (128, 4), (256, 0), (255, 5)):
+        with pytest.raises(bp.BpError):
+            bp.BucketMSM.bucket_msm(b"", np.zeros((0, 4), dtype=np.uint64), b, c)

@@ -1,0 +1,175 @@
+"""-m gpu: multi-GPU behind the C ABI (VERDICT r01 "missing" 1, 2 and 5).
+
+bp_init_multi -- ONE context over a device list: SRS sharded by contiguous point range, MSM / commit / bp_prove fanned out
+over the shards and summed, batched host NTTs spread by independent columns.  A 1-GPU box runs it with the device listed
+twice or three times (independent shards on one card); with more cards visible the real list is used too.
+bp_msm_g1_blob_device / bp_msm_blobs_combine -- the one-process-per-GPU exchange: records stay in HBM, one gather, one D2H.
+bp_srs_load_projective144 -- the literal bucket_msm(&[G1Projective], ..) seam."""
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import baby_plonk_rust_amd as bp
+from baby_plonk_rust_amd import _lib
+from oracle import oracle as O
+from tests import bigint_model as M
+from tests import gpu_common as G
+from tests import prover_rounds as PR
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+Q = M.Q
+
+
+def device_lists():
+    lists = [[0, 0], [0, 0, 0]]
+    if torch.cuda.device_count() >= 2:
+        lists.append(list(range(min(torch.cuda.device_count(), 8))))
+    return lists
+
+
+def test_cpp_single_process_multi_device(tmp_path):
+    """the Done-criterion of VERDICT r01 next #2: a single-process C++ program commits through an n-device context and gets
+    the single-GPU bytes"""
+    exe = str(tmp_path / "test_multi_device")
+    libdir = os.path.join(ROOT, "baby_plonk_rust_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "test_multi_device.cpp"), "-o", exe,
+                           "-L" + libdir, "-lbp_msm_ntt", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    for devs in device_lists():
+        out = subprocess.run([exe, ",".join(map(str, devs))], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "multi device ok (%d shards)" % len(devs) in out.stdout
+
+
+@pytest.mark.parametrize("devs", device_lists())
+def test_group_context_msm_srs_and_tables(devs):
+    one, many = bp.Context(0), bp.Context(devs)
+    assert many.n_shards() == len(devs) and one.n_shards() == 1
+    # the reference's own 1000-point fixture (i * G): load, export, MSM with a closed form
+    raw = open(os.path.join(ROOT, "tests", "golden", "g1_uncompressed_valid_test_vectors.dat"), "rb").read()
+    h1, hm = one.srs_load(raw), many.srs_load(raw)
+    assert many.srs_len(hm) == 1000 and many.srs_export(hm) == raw and many.srs_export(hm, 331, 340) == raw[96 * 331: 96 * 671]
+    sc = O.splitmix_scalars(1000, 0xABCD)
+    ints = O.fr_array_to_ints(sc)
+    want = M.enc96(M.ec_mul(sum(i * s for i, s in enumerate(ints)) % Q))
+    assert one.msm(h1, sc) == want and many.msm(hm, sc) == want
+    # ranges that start and end inside shards; more scalars than points (zip truncation); device-resident scalars
+    for first, cnt in ((0, 1), (333, 1), (332, 3), (100, 777), (999, 5), (1000, 4)):
+        w = M.enc96(M.ec_mul(sum((first + i) * s for i, s in enumerate(ints[:min(cnt, 1000 - first)])) % Q))
+        assert bp.sum_partials(many.msm_partial(hm, sc[:cnt], first=first)) == w, (first, cnt)
+    dsc = torch.from_numpy(sc.view(np.int64)).to("cuda:%d" % devs[0])
+    torch.cuda.synchronize()
+    assert bp.sum_partials(many.msm_partial(hm, None, first=7, device_ptr=dsc.data_ptr(), n=900)) == \
+        M.enc96(M.ec_mul(sum((7 + i) * s for i, s in enumerate(ints[:900])) % Q))
+    # canonical-bytes scalars; a value >= q is refused whichever shard meets it
+    le = np.frombuffer(b"".join(s.to_bytes(32, "little") for s in ints), dtype=np.uint8).reshape(-1, 32).copy()
+    assert many.msm(hm, le, fmt=bp.FR_BYTES_LE) == want
+    le[998] = 0xFF
+    with pytest.raises(bp.BpError) as e:
+        many.msm(hm, le, fmt=bp.FR_BYTES_LE)
+    assert e.value.code == -4
+    # fixed-base tables on every shard: same bytes, and the table path was taken
+    info = many.srs_precompute(hm, 6)
+    assert info["window_bits"] == 6 and info["bytes"] == info["windows"] * 1000 * 112
+    assert many.msm(hm, sc) == want and many.msm_stats()["tables"]
+    many.srs_precompute(hm, bp.SRS_TABLES_OFF)
+    assert many.msm(hm, sc) == want and not many.msm_stats()["tables"]
+    many.srs_free(hm)
+    with pytest.raises(bp.BpError):
+        many.srs_len(hm)
+    # generated SRSs: every shard produces its own range
+    n, tau, a, d = 3001, 0x5EED, 987654321, 1234567
+    assert many.srs_export(many.srs_generate(n, tau)) == one.srs_export(one.srs_generate(n, tau))
+    hp = many.srs_generate_progression(n, a, d)
+    assert many.srs_export(hp, n - 5, 5) == G.progression_bytes(n, a, d)[96 * (n - 5):]
+    sc = O.splitmix_scalars(n, 0x77)
+    assert many.msm(hp, sc) == M.enc96(M.ec_mul(G.oracle_dot(sc, a, d)))
+    # fewer points than shards
+    ht = many.srs_generate(1, tau)
+    assert many.msm(ht, O.splitmix_scalars(4, 1)) == M.enc96(M.ec_mul(O.fr_array_to_ints(O.splitmix_scalars(4, 1))[0]))
+    assert many.msm(many.srs_load(b""), sc) == M.enc96(None)
+
+
+def test_group_context_msm_2p18_closed_form():
+    """a size where every shard runs the full-width pipeline (c = 15 / 16, tables): closed form"""
+    many = bp.Context([0, 0])
+    n, a, d = 1 << 18, G.Q - 12345, 0x1F2E3D4C5B6A7988
+    h = many.srs_generate_progression(n, a, d)
+    sc = O.splitmix_scalars(n, 0x5EED0012)
+    want = M.enc96(M.ec_mul(O.dot_progression(sc, a, d)))
+    assert many.msm(h, sc) == want
+    many.srs_precompute(h, 0)
+    assert many.msm(h, sc) == want and many.msm_stats()["tables"]
+
+
+def test_group_context_ntt_columns_and_prove():
+    from tests.test_gpu_prover_rounds import synthetic_circuit
+    one, many = bp.Context(0), bp.Context([0, 0, 0])
+    x = np.stack([O.splitmix_scalars(1 << 12, 0xF400 + j) for j in range(7)])
+    got = many.ntt_batch(x)
+    assert (got == one.ntt_batch(x)).all() and (got[3] == O.ntt_fast(x[3])).all()
+    assert (many.ntt_batch(got, inverse=True) == x).all()
+    # bp_prove through the group: the nine commitments are sharded, the proof bytes do not change
+    pn, tau = 1 << 10, 0x1234567
+    cols, pk, public = synthetic_circuit(pn, 11)
+    blinders = [random.Random(3).randrange(1, Q) for _ in range(11)]
+    blobs = []
+    for ctx in (one, many):
+        for tables in (False, True):
+            setup = bp.Setup.generate_srs(pn + 6, tau, ctx, tables=tables)
+            circuit = bp.Circuit({k: PR.SV(v) for k, v in pk.items()}, ctx)
+            blobs.append(bp.Prover(setup, circuit).prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), None, blinders))
+            assert circuit.commitments(setup) == bp.Circuit({k: PR.SV(v) for k, v in pk.items()}, one).commitments(
+                bp.Setup.generate_srs(pn + 6, tau, one, tables=False))
+    assert len(blobs[0]) == 624 and all(b == blobs[0] for b in blobs)
+
+
+def test_blob_records_one_gather_one_copy():
+    """what every rank of the one-process-per-GPU path does, here with three 'ranks' on one card: records written to HBM,
+    gathered (a concatenated device tensor stands in for the RCCL all-gather), ONE copy to the host, combined"""
+    ctx = bp.Context(0)
+    n, a, d = 40000, 424242, 171717
+    sc = O.splitmix_scalars(n, 0xD157)
+    want = M.enc96(M.ec_mul(G.oracle_dot(sc, a, d)))
+    edges = [0, 13000, 13001, 40000]                          # ragged, one single-point shard
+    for tables in (False, True):
+        gathered = torch.zeros((3, _lib.MSM_BLOB_BYTES), dtype=torch.uint8, device="cuda:0")
+        for r in range(3):
+            lo, hi = edges[r], edges[r + 1]
+            h = ctx.srs_generate_progression(hi - lo, a + lo * d, d)
+            if tables:
+                ctx.srs_precompute(h, 0)
+            ctx.msm_blob_device(h, gathered[r].data_ptr(), sc[lo:hi])
+        assert bp.combine_blobs(gathered.cpu().numpy().tobytes()) == want
+    # an empty shard contributes the identity; a corrupt record and a bad scalar are refused
+    h = ctx.srs_generate_progression(10, a, d)
+    rec = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device="cuda:0")
+    ctx.msm_blob_device(h, rec.data_ptr(), sc[:0])
+    assert bp.combine_blobs(rec.cpu().numpy().tobytes()) == M.enc96(None)
+    with pytest.raises(bp.BpError):
+        bp.combine_blobs(bytes(_lib.MSM_BLOB_BYTES))
+    bad = np.full((10, 32), 0xFF, dtype=np.uint8)
+    ctx.msm_blob_device(h, rec.data_ptr(), bad, fmt=bp.FR_BYTES_LE)
+    with pytest.raises(bp.BpError) as e:
+        bp.combine_blobs(rec.cpu().numpy().tobytes())
+    assert e.value.code == -4
+
+
+def test_projective_image_seam():
+    """bucket_msm(points: &[G1Projective], ..) (msm.rs:76-81): the points as the reference holds them in memory, z != 1"""
+    ctx = bp.Context(0)
+    g = O.g1_generator()
+    ks = [0, 1, 2, 3, 5, Q - 1, 123456789, 0] + [random.Random(5).randrange(Q) for _ in range(30)]     # identity first, last-but-30 and inside a group
+    pts = [O.g1_mul(g, O.fr_from_int(k)) for k in ks]
+    assert any(bytes(p.tobytes()[96:144]) != bytes(O.g1_generator().tobytes()[96:144]) for p in pts[2:])      # z != 1: really projective
+    h = ctx.srs_load_projective144(b"".join(p.tobytes() for p in pts))
+    assert ctx.srs_export(h) == b"".join(M.enc96(M.ec_mul(k)) for k in ks)
+    sc = O.splitmix_scalars(len(ks), 3)
+    assert ctx.msm(h, sc) == M.enc96(M.ec_mul(sum(k * s for k, s in zip(ks, O.fr_array_to_ints(sc))) % Q))
+    many = bp.Context([0, 0])
+    hm = many.srs_load_projective144(b"".join(p.tobytes() for p in pts))
+    assert many.srs_export(hm) == ctx.srs_export(h) and many.msm(hm, sc) == ctx.msm(h, sc)
