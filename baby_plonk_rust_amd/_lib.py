@@ -42,6 +42,7 @@ SIGNATURES = {
     "bp_srs_generate_progression": (_int, [_vp, _sz, _vp, _vp, _pp(_u64)]),
     "bp_srs_len": (_int, [_vp, _u64, _pp(_sz)]),
     "bp_srs_export": (_int, [_vp, _u64, _sz, _sz, _vp]),
+    "bp_srs_export_projective144": (_int, [_vp, _u64, _sz, _sz, _vp]),
     "bp_srs_free": (_int, [_vp, _u64]),
     "bp_srs_precompute": (_int, [_vp, _u64, _u32]),
     "bp_srs_table_info": (_int, [_vp, _u64, _pp(_u32), _pp(_u32), _pp(_u64)]),

@@ -105,7 +105,8 @@ class Context:
 
     def srs_load_projective144(self, points144):
         """n x 144 bytes: the in-memory image of G1Projective (x | y | z Montgomery limbs), normalised on the GPU"""
-        buf = np.ascontiguousarray(np.frombuffer(bytes(points144), dtype=np.uint8))
+        buf = points144 if isinstance(points144, np.ndarray) else np.frombuffer(bytes(points144), dtype=np.uint8)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
         n, h = len(buf) // 144, C.c_uint64()
         self.check(self._lib.bp_srs_load_projective144(self._h, buf.ctypes.data, n, C.byref(h)), "bp_srs_load_projective144")
         return h.value
@@ -133,6 +134,13 @@ class Context:
         out = np.zeros(96 * n, dtype=np.uint8)
         self.check(self._lib.bp_srs_export(self._h, handle, first, n, out.ctypes.data), "bp_srs_export")
         return bytes(out)
+
+    def srs_export_projective144(self, handle, first=0, n=None):
+        """the points as G1Projective memory images (144 bytes each, z = 1): what a Rust Vec<G1Projective> holds"""
+        n = self.srs_len(handle) - first if n is None else n
+        out = np.zeros(144 * n, dtype=np.uint8)
+        self.check(self._lib.bp_srs_export_projective144(self._h, handle, first, n, out.ctypes.data), "bp_srs_export_projective144")
+        return out
 
     def srs_free(self, handle):
         self.check(self._lib.bp_srs_free(self._h, handle), "bp_srs_free")
@@ -170,7 +178,7 @@ class Context:
         if device_ptr is not None:
             rc = self._lib.bp_msm_g1_blob_device(self._h, handle, first, device_ptr, n, fmt, 1, d_blob_ptr)
         else:
-            s = _fr_array(scalars)
+            s = _fr_array(scalars) if fmt == FR_MONT else np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
             rc = self._lib.bp_msm_g1_blob_device(self._h, handle, first, s.ctypes.data, len(s), fmt, 0, d_blob_ptr)
         self.check(rc, "bp_msm_g1_blob_device")
 

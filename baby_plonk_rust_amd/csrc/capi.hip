@@ -470,6 +470,35 @@ int bp_srs_export(bp_ctx* ctx, uint64_t srs_handle, size_t first, size_t n, uint
   return BP_OK;
 }
 
+int bp_srs_export_projective144(bp_ctx* ctx, uint64_t srs_handle, size_t first, size_t n, uint8_t* points144) {
+  if (!ctx || (n && !points144)) return BP_ERR_INVALID_ARG;
+  SrsEntry* lead;
+  BP_TRY(srs_find(ctx, srs_handle, &lead));
+  if (first > lead->n_global || n > lead->n_global - first) return fail(ctx, BP_ERR_INVALID_ARG, "SRS range out of bounds", hipSuccess, __FILE__, __LINE__);
+  const std::vector<bp_ctx*> sh = shards_of(ctx);
+  const fp_t one = Fp::one();
+  for (size_t r = 0; r < sh.size(); r++) {
+    bp_ctx* m = sh[r];
+    SrsEntry* e;
+    BP_TRY(lift(ctx, m, srs_find(m, member_handle(*lead, srs_handle, r), &e)));
+    const size_t lo = std::max(first, e->first), hi = std::min(first + n, e->first + e->n);
+    if (lo >= hi) continue;
+    DeviceGuard guard(m->device);
+    std::vector<g1_affine> aff(hi - lo);
+    BP_HIP(ctx, hipMemcpyAsync(aff.data(), e->d_points + (lo - e->first), (hi - lo) * sizeof(g1_affine), hipMemcpyDeviceToHost, m->stream));
+    BP_HIP(ctx, hipStreamSynchronize(m->stream));
+    for (size_t i = 0; i < hi - lo; i++) {                   // G1Projective::from(&G1Affine) (g1.rs:176-190): z = 1, or 0 for the identity
+      g1_proj p;
+      p.x = aff[i].x;
+      p.y = aff[i].y;
+      p.z = g1_affine_is_identity(aff[i]) ? Fp::zero() : one;
+      if (g1_affine_is_identity(aff[i])) p = g1_identity();
+      memcpy(points144 + (lo - first + i) * 144, &p, 144);
+    }
+  }
+  return BP_OK;
+}
+
 int bp_srs_free(bp_ctx* ctx, uint64_t srs_handle) {
   if (!ctx) return BP_ERR_INVALID_ARG;
   SrsEntry* lead;

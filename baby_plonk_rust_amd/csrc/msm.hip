@@ -238,12 +238,12 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
     hipLaunchKernelGGL(msm_planes_block, dim3(blocks_per_window, Wr), dim3(256), 512 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
                        l1, block_out);
     hipLaunchKernelGGL(msm_planes_window, dim3(l1 + 1, Wr), dim3(128), 256 * sizeof(proj28_slot), st, block_out, l1, l2, window_sum,
-                       long_count + 1, reinterpret_cast<uint32_t*>(window_sum + n_planes));
+                       long_count + 1, offsets + total, reinterpret_cast<uint32_t*>(window_sum + n_planes));
   } else {
     hipLaunchKernelGGL(msm_reduce, dim3(blocks_per_window, Wr), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
                        block_out);
     hipLaunchKernelGGL(msm_window_finish, dim3(Wr), dim3(256), 256 * sizeof(proj28_slot), st, block_out, blocks_per_window, window_sum,
-                       long_count + 1, reinterpret_cast<uint32_t*>(window_sum + n_planes));
+                       long_count + 1, offsets + total, reinterpret_cast<uint32_t*>(window_sum + n_planes));
   }
   BP_HIP(ctx, hipGetLastError());
   if (d_blob) {
@@ -257,7 +257,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
     hipLaunchKernelGGL(msm_write_blob, dim3(1), dim3(256), 0, st, window_sum, hdr, (uint8_t*)d_blob);
     BP_HIP(ctx, hipGetLastError());
   } else {
-    BP_HIP(ctx, hipMemcpyAsync(h_windows, window_sum, (size_t)n_planes * sizeof(proj28_slot) + 4, hipMemcpyDeviceToHost, st));    // sums + status
+    BP_HIP(ctx, hipMemcpyAsync(h_windows, window_sum, (size_t)n_planes * sizeof(proj28_slot) + 8, hipMemcpyDeviceToHost, st));    // sums + status + entry count
   }
   BP_HIP(ctx, hipEventRecord(ctx->ev[3], st));
   out->empty = false;
@@ -265,7 +265,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   out->c = plan.c;
   out->Wr = Wr;
   out->n_planes = n_planes;
-  out->adds = max_entries;      // upper bound: zero digits are skipped (about n*W/2^c of them)
+  out->adds = max_entries;      // upper bound (blob mode keeps it); msm_finish replaces it by the exact count of non-zero digits
   out->h_windows = h_windows;
   return BP_OK;
 }
@@ -292,8 +292,9 @@ int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out) {
   }
   const proj28_slot* h_windows = static_cast<const proj28_slot*>(pend.h_windows);
   const uint32_t n_planes = pend.n_planes;
-  if (*reinterpret_cast<const uint32_t*>(h_windows + n_planes))
-    return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q in a canonical-bytes input", hipSuccess, __FILE__, __LINE__);
+  const uint32_t* tail = reinterpret_cast<const uint32_t*>(h_windows + n_planes);
+  if (tail[0]) return fail(ctx, BP_ERR_BAD_SCALAR, "scalar >= q in a canonical-bytes input", hipSuccess, __FILE__, __LINE__);
+  ctx->msm_adds = tail[1];             // entries of the bucket-sorted list = non-zero digits = bucket additions performed
   std::vector<g1_proj> windows(n_planes);
   for (uint32_t w = 0; w < n_planes; w++) windows[w] = slot_to_proj(&h_windows[w]);
   if (pend.tables) host_plane_horner(*host_out, windows.data(), pend.Wr, pend.c);

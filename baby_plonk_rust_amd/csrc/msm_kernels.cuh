@@ -408,8 +408,8 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
 // bp_msm_g1_blob_device: the window sums / bit planes of one rank's MSM as a self-describing record in HBM, so the ranks'
 // records can be all-gathered on the device and combined after a single device-to-host copy (bp_msm_blobs_combine).
 struct MsmBlobHeader {
-  uint32_t magic, c, Wr, n_planes, tables, status;
-  uint32_t pad[10];
+  uint32_t magic, c, Wr, n_planes, tables, status, entries;
+  uint32_t pad[9];
 };
 static_assert(sizeof(MsmBlobHeader) == 64, "blob header");
 constexpr uint32_t MSM_BLOB_MAGIC = 0x424d5042u;      // "BPMB"
@@ -418,7 +418,11 @@ __global__ void __launch_bounds__(256) msm_write_blob(const proj28_slot* __restr
   const uint4* src = reinterpret_cast<const uint4*>(window_sum);
   for (uint32_t i = threadIdx.x; i < hdr.n_planes * 11u; i += blockDim.x) dst[i] = src[i];
   if (threadIdx.x == 0) {
-    if (hdr.n_planes) hdr.status = *reinterpret_cast<const uint32_t*>(window_sum + hdr.n_planes);     // scalar >= q seen by msm_digits
+    if (hdr.n_planes) {
+      const uint32_t* tail = reinterpret_cast<const uint32_t*>(window_sum + hdr.n_planes);
+      hdr.status = tail[0];             // scalar >= q seen by msm_digits
+      hdr.entries = tail[1];
+    }
     *reinterpret_cast<MsmBlobHeader*>(blob) = hdr;
   }
 }
@@ -563,9 +567,9 @@ msm_reduce(const uint32_t* __restrict__ offsets, MsmPlan plan, const proj28_slot
 // (the last kernel of an MSM also moves the scalar-status word behind the sums, so that one copy brings everything to the host)
 __global__ void __launch_bounds__(256, 2) msm_window_finish(const proj28_slot* __restrict__ block_out, uint32_t blocks_per_window,
                                                              proj28_slot* __restrict__ window_sum, const uint32_t* __restrict__ status_in,
-                                                             uint32_t* __restrict__ status_out) {
+                                                             const uint32_t* __restrict__ entries_in, uint32_t* __restrict__ status_out) {
   const uint32_t w = blockIdx.x;
-  if (w == 0 && threadIdx.x == 0) *status_out = *status_in;
+  if (w == 0 && threadIdx.x == 0) { status_out[0] = *status_in; status_out[1] = *entries_in; }    // [1]: non-zero digits = bucket additions done
   g1_proj28 v = g1_identity28();
   for (uint32_t j = threadIdx.x; j < blocks_per_window; j += blockDim.x) {       // > 256 shares: fold first
     g1_proj28 q = load_proj28(&block_out[(size_t)w * blocks_per_window + j]);
@@ -636,10 +640,10 @@ msm_planes_block(const uint32_t* __restrict__ offsets, MsmPlan plan, const proj2
 // out[w * (l1 + l2 + 1) + {0: A, 1 + j: T_j}]
 __global__ void __launch_bounds__(128, 1)
 msm_planes_window(const proj28_slot* __restrict__ in, uint32_t l1, uint32_t l2, proj28_slot* __restrict__ out,
-                  const uint32_t* __restrict__ status_in, uint32_t* __restrict__ status_out) {
+                  const uint32_t* __restrict__ status_in, const uint32_t* __restrict__ entries_in, uint32_t* __restrict__ status_out) {
   proj28_slot* buf = reinterpret_cast<proj28_slot*>(msm_lds_tree);
   const uint32_t v = blockIdx.x, w = blockIdx.y, nblk = 1u << l2, c = l1 + l2 + 1;
-  if (v == 0 && w == 0 && threadIdx.x == 0) *status_out = *status_in;       // rides to the host behind the sums
+  if (v == 0 && w == 0 && threadIdx.x == 0) { status_out[0] = *status_in; status_out[1] = *entries_in; }      // ride to the host behind the sums
   if (threadIdx.x < nblk) buf[threadIdx.x] = in[((size_t)w * nblk + threadIdx.x) * (l1 + 1) + v];
   __syncthreads();
   const proj28_slot* root = planes_tree(buf, buf + 128, l2, v == 0);

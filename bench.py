@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the hot path: G1 MSM scalar-muls/s (+ Fr NTT elements/s) on MI355X.
+"""bench.py -- headline benchmark of the hot path: G1 MSM scalar-muls/s (+ Fr NTT elements/s, proofs/s) on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
-one 2^log_n-point G1 MSM per rank against that rank's resident SRS shard (point-range sharding),
-followed -- only when N > 1 -- by the single RCCL all-gather of the 144-byte projective partials and the
-7-addition combine.  Weak scaling: every rank owns 2^log_n points, the job computes one N * 2^log_n-point MSM.
-The Fr NTT (independent columns, one 2^ntt_log_n vector per rank, no collective) is timed the same way in a
-second region and reported in the "ntt" object of the same JSON line.
+N > 1 needs N ranks, one per GPU.  Launched by `python -m torch.distributed.run ... bench.py --gpus N ...` every process is a
+rank (RANK / LOCAL_RANK / WORLD_SIZE in the environment).  Launched bare (`python bench.py --gpus N`, WORLD_SIZE unset) the
+parent starts that same torch.distributed.run command as a child process BEFORE it makes any GPU call, relays rank 0's JSON
+line and exits with the child's code; it refuses loudly when fewer than N GPUs are visible.
 
-Workload at N = 1: BASELINE.json configs[2], the 2^20-point MSM the metric is quoted on (+ a 2^20 NTT).
-The SRS is what Setup holds for the life of a prover (src/setup.rs:7-10): resident in HBM together with its
-fixed-base window tables, built once by bp_srs_precompute before the timed region (build time and size are
-reported).  The same MSM without tables (raw points only, the uncached bucket_msm seam) is timed beside it
-in "msm_without_tables"; --no-tables makes that the headline instead.
-Inputs: points P_i = (a + i d) G generated on the GPU, scalars = SplitMix64 ->
-from_bytes_wide generated on the GPU; nothing is read from disk.  The CPU oracle is used for the
-`cpu_baseline` leg only (rank 0, N = 1, bounded sample).
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM.  Legs, each timed
+with W warm-up steps and exactly K steps between barrier + synchronize, max over ranks:
+  value / weak scaling   one 2^log_n-point G1 MSM per rank against that rank's resident SRS shard (point-range sharding,
+                         SURVEY.md 8e) + for N > 1 the single RCCL all-gather of the ranks' partial-sum records and the
+                         combine: the job computes one N * 2^log_n-point MSM.  BASELINE configs[2] at N = 1.
+  strong_scaling         BASELINE configs[3]: ONE 2^24-point MSM, 2^24 / N points per rank, same exchange; its result hash
+                         is the same for every N.
+  ntt / sizes            2^20 Fr NTT per rank (independent columns, no collective); at N = 1 also the metric's other sizes
+                         (2^16 = configs[1], 2^24) with their own roofline objects.
+  seams (N = 1)          msm_host_scalars: pageable host scalars in (what Setup::commit(&Polynomial) hands over, PCIe
+                         inclusive); msm_uncached_seam: upload 2^log_n points + multiply + free (bucket_msm(&[G1Projective])).
+  prove                  BASELINE configs[4]: bp_prove on a synthetic 2^20-gate circuit; independent proofs per GPU
+                         (throughput) and, for N > 1, ONE proof on a context spanning all N GPUs (latency, row e3).
+The SRS is what Setup holds for the life of a prover (src/setup.rs:7-10): resident in HBM together with its fixed-base
+window tables, built once before the timed region (build time and size reported); the same MSM on raw points is timed
+beside it (`msm_without_tables`), --no-tables makes that the headline.
+Inputs: points P_i = (a + i d) G and scalars SplitMix64 -> from_bytes_wide, both generated on the
+GPU.  The CPU oracle is used for the `cpu_baseline` leg only (rank 0, N = 1, bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,37 +39,117 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
-import baby_plonk_rust_amd as bp
-from baby_plonk_rust_amd import dist as bpd
-
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-# The dominant kernel is integer-issue bound: second ceiling from this repo's own measurements --
-# tools/ubench_int.hip (profiles/r01_ubench_int_issue_rates.txt): v_mad_u64_u32 issues at 57 lanes/clk/CU, like a carry add
-VALU_PEAK_LANE_INSTR_S = 57.0 * 256 * 2.4e9
-ACC_INSTR_PER_ADD = 5000         # VALU instructions per iteration of msm_accumulate's loop (hipcc -S: 5006, of which 3729 v_mad_u64_u32)
+# msm_accumulate is integer-issue bound.  Issue rates measured by tools/ubench_int.hip on this part
+# (profiles/r01_ubench_int_issue_rates.txt), lanes per clock per CU: v_mad_u64_u32 and the other quarter-rate integer ops
+# 57, plain 32-bit VALU ops 90; 256 CUs, 2.4 GHz peak engine clock.
+RATE_QUARTER, RATE_FULL, N_CU, CLOCK_HZ = 57.0, 90.0, 256, 2.4e9
 MSM_BYTES_PER_UNIT = 128         # 32 B scalar + 96 B affine point per scalar-mul
 NTT_BYTES_PER_UNIT = 64          # 32 B read + 32 B write per element
 GOLDEN = 0x9E3779B97F4A7C15
 A0, D0 = 0x1F2E3D4C5B6A79881122334455667788, 0x0102030405060708090A0B0C0D0E0F10
+MASK64 = 2**64 - 1
 
 
-def measured_traffic(key):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_hbm_traffic.json), or None when the
-    running configuration is not the profiled one"""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=20, help="weak-scaling MSM points per GPU = 2^log_n")
+    ap.add_argument("--ntt-log-n", type=int, default=20, help="NTT length per GPU = 2^ntt_log_n")
+    ap.add_argument("--strong-log-n", type=int, default=24, help="strong-scaling leg: ONE 2^strong_log_n-point MSM over all GPUs (0 = skip)")
+    ap.add_argument("--strong-steps", type=int, default=0, help="steps of the strong-scaling leg (0 = min(steps, 10))")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=18)
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-seams", action="store_true")
+    ap.add_argument("--prove-log-n", type=int, default=20, help="gates of the synthetic circuit of the proofs/s leg = 2^prove_log_n (0 = skip)")
+    ap.add_argument("--prove-reps", type=int, default=3)
+    ap.add_argument("--prove-streams", type=int, default=2, help="concurrent provers per GPU in the proofs/s throughput figure")
+    ap.add_argument("--other-sizes", type=int, nargs="*", default=[16, 24], help="log2 sizes also measured at N = 1 (MSM with tables + NTT)")
+    ap.add_argument("--no-tables", action="store_true", help="headline = MSM on the raw SRS, no fixed-base window tables")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                                                      "the N > 1 control flow on a box with fewer GPUs than ranks)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become the launcher.  Nothing here touches the GPU
+    (torch.cuda.device_count() does not initialise it), the ranks are fresh child processes."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and n_dev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d needs %d ranks with one GPU each, but %d GPU%s visible\n"
+                         % (args.gpus, args.gpus, n_dev, " is" if n_dev == 1 else "s are"))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=ROOT)
+    line = None
+    for out in child.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if rc != 0 or line is None:
+        sys.stderr.write("bench.py: the %d-rank run failed (exit code %d%s)\n" % (args.gpus, rc, "" if line else ", no result line"))
+        return rc or 1
+    print(line, flush=True)
+    return 0
+
+
+def profile_lookup(name, key):
+    """numbers that need a separate profiler pass (PMC counters, static instruction mix) come from committed files under
+    profiles/; None when the running configuration is not the profiled one"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-            return json.load(f)[key]["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f).get(key)
     except Exception:
         return None
+
+
+def msm_roofline(n, acc_s, adds, window_bits, tables, traffic_key=None):
+    """HBM roofline (the contract's) and the integer-issue roofline (the one that binds) of msm_accumulate for one launch"""
+    achieved = MSM_BYTES_PER_UNIT * n / acc_s / 1e9
+    traffic = profile_lookup("r02_hbm_traffic.json", traffic_key) if traffic_key else None
+    hbm = {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic["hbm_bytes_per_launch"] if traffic else None, "traffic_source": traffic.get("source") if traffic else None,
+           "kernel_ms": acc_s * 1e3, "algorithmic_bytes_per_launch": MSM_BYTES_PER_UNIT * n,
+           "note": "integer-issue bound by design (11 Fp products + 8 reductions per bucket addition); see roofline_valu_issue"}
+    mix = profile_lookup("r02_msm_accumulate_instr_mix.json", "msm_accumulate<2>")
+    issue = None
+    if mix and adds:
+        # lane-cycles of one loop iteration at the measured issue rates, times the additions actually performed
+        per_add_s = (mix["quarter_rate"] / RATE_QUARTER + mix["full_rate"] / RATE_FULL) / (N_CU * CLOCK_HZ)
+        ideal_s = adds * per_add_s
+        issue = {"bound": "valu_issue", "kernel": "msm_accumulate", "achieved": adds / acc_s, "peak": 1.0 / per_add_s, "unit": "bucket additions/s",
+                 "frac": ideal_s / acc_s, "additions_per_launch": adds,
+                 "valu_per_addition": {"quarter_rate": mix["quarter_rate"], "full_rate": mix["full_rate"], "v_mad_u64_u32": mix.get("v_mad_u64_u32")},
+                 "note": "additions counted by the kernel pipeline (non-zero digits) x static instruction classes of the loop body "
+                         "(tools/instr_mix.py on the shipped code object) at the issue rates tools/ubench_int.hip measured "
+                         "(quarter-rate 57, full-rate 90 lanes/clk/CU, 256 CU, 2.4 GHz), over the measured kernel time"}
+    return hbm, issue
+
+
+def ntt_roofline(nn, ntt_s, passes, traffic_key=None):
+    achieved = NTT_BYTES_PER_UNIT * nn / ntt_s / 1e9
+    traffic = profile_lookup("r02_hbm_traffic.json", traffic_key) if traffic_key else None
+    return {"bound": "hbm", "kernel": "ntt_pass_* (all %d passes of one transform)" % passes, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+            "traffic_source": traffic.get("source") if traffic else None, "kernel_ms": ntt_s * 1e3,
+            "algorithmic_bytes_per_launch": NTT_BYTES_PER_UNIT * nn}
 
 
 def cpu_baseline(sample_log_n, threads_all):
     """reference-faithful CPU path (oracle restatement of src/msm.rs: c = 4, 64 windows, projective adds),
     single thread like the reference, on a bounded sample of the same synthetic workload"""
+    import numpy as np
     from oracle import oracle as O
     n = 1 << sample_log_n
     aff = O.points_progression(n, A0, D0)
@@ -84,7 +174,9 @@ def cpu_baseline(sample_log_n, threads_all):
     t6 = time.perf_counter()
     return {
         "value": n / (t1 - t0), "unit": "scalar-muls/s", "cores": 1, "kind": "port",
-        "sample": "2^%d-point bucket_msm(b=256,c=4) restated from src/msm.rs, same synthetic inputs, %.1f s" % (sample_log_n, t1 - t0),
+        "sample": "2^%d-point bucket_msm(b=256,c=4) restated from src/msm.rs, same synthetic inputs, %.1f s; the algorithm is "
+                  "exactly linear in the point count (64 windows x (N bucket additions + 45 bucket-reduction operations)), so "
+                  "the rate holds for 2^20 and 2^24 (2^20 would take %.0f s on one core)" % (sample_log_n, t1 - t0, (t1 - t0) * (1 << (20 - sample_log_n))),
         "all_cores": {"value": n / (t2 - t1), "cores": threads_all, "note": "same algorithm, 64 windows over OpenMP threads"},
         "ntt": {"value": (1 << ntt_log) / (t4 - t3), "unit": "elements/s", "cores": 1,
                 "sample": "2^%d radix-2 NTT (output-identical O(n log n) twin of utils.rs:63-81), %.2f s" % (ntt_log, t4 - t3),
@@ -95,37 +187,33 @@ def cpu_baseline(sample_log_n, threads_all):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-n", type=int, default=20, help="MSM points per GPU = 2^log_n")
-    ap.add_argument("--ntt-log-n", type=int, default=20, help="NTT length per GPU = 2^ntt_log_n")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=18)
-    ap.add_argument("--skip-cpu", action="store_true")
-    ap.add_argument("--prove-log-n", type=int, default=20, help="gates of the synthetic circuit of the proofs/s leg = 2^prove_log_n (0 = skip)")
-    ap.add_argument("--prove-reps", type=int, default=3)
-    ap.add_argument("--prove-streams", type=int, default=2, help="concurrent provers per GPU in the proofs/s throughput figure")
-    ap.add_argument("--other-sizes", type=int, nargs="*", default=[16, 24], help="log2 sizes also measured at N = 1 (MSM with tables + NTT, 3 runs each)")
-    ap.add_argument("--no-tables", action="store_true", help="headline = MSM on the raw SRS, no fixed-base window tables")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
-                                                      "the N > 1 control flow on a box with fewer GPUs than ranks)")
-    args = ap.parse_args()
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import hashlib
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import baby_plonk_rust_amd as bp
+    from baby_plonk_rust_amd import dist as bpd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
     n_dev = torch.cuda.device_count()
     if args.backend == "nccl" and world > n_dev:
         raise SystemExit("bench.py: %d ranks but %d GPUs (one process per GPU)" % (world, n_dev))
     dev_index = local_rank % max(n_dev, 1)            # == local_rank except in a gloo rehearsal
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    ctl = None                                        # host-side group for object gathers and long waits
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+            ctl = dist.new_group(backend="gloo")
         else:
             dist.init_process_group(args.backend)
 
@@ -134,111 +222,186 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(vals):
+        if world == 1:
+            return [float(v) for v in vals]
+        t = torch.tensor(vals, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    def gather_objects(obj):
+        if world == 1:
+            return [obj]
+        out = [None] * world
+        dist.all_gather_object(out, obj, group=ctl)
+        return out
+
     ctx = bp.Context(dev_index)
-    n = 1 << args.log_n
-    # this rank's point range [rank*n, (rank+1)*n) of the global progression, resident in HBM
-    srs = ctx.srs_generate_progression(n, A0 + rank * n * D0, D0)
-    scal = torch.empty(n * 4, dtype=torch.int64, device=dev)
-    ctx.synthetic_scalars_device(scal.data_ptr(), n, (0x5EED0000 + args.log_n + GOLDEN * 8 * rank * n) & (2**64 - 1))
+    exchange = bpd.ShardedMsm(ctx)
 
-    def msm_step():
-        # per-rank Pippenger on the resident shard, then (N > 1) the single RCCL all-gather of 144 B per rank
-        # and the N-1 complete additions on every rank (baby_plonk_rust_amd/dist.py)
-        return bpd.msm_sharded(ctx, srs, None, device_ptr=scal.data_ptr(), n=n)
-
-    def timed_msm():
-        for _ in range(args.warmup):
-            res = msm_step()
+    def timed_msm(srs, d_scal, n, steps, warmup):
+        """W + K steps of: per-rank Pippenger on the resident shard, then (N > 1) the single all-gather of the ranks'
+        records left in HBM + one D2H + combine (baby_plonk_rust_amd/dist.py ShardedMsm)"""
+        def step():
+            if world == 1:
+                return bp.sum_partials(ctx.msm_partial(srs, None, device_ptr=d_scal.data_ptr(), n=n))
+            return exchange(srs, device_ptr=d_scal.data_ptr(), n=n)
+        for _ in range(warmup):
+            res = step()
         barrier()
-        acc, devt = [], []
+        acc, devt, exch = [], [], []
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            res = msm_step()
+        for _ in range(steps):
+            res = step()
             st = ctx.msm_stats()
             acc.append(st["accumulate_ms"])
             devt.append(st["device_ms"])
+            exch.append(exchange.exchange_s * 1e3)
         barrier()
-        return res, time.perf_counter() - t0, acc, devt, ctx.msm_stats()
+        return {"result": res, "elapsed": time.perf_counter() - t0, "acc_ms": float(np.mean(acc)), "dev_ms": float(np.mean(devt)),
+                "exchange_ms": float(np.mean(exch)) if world > 1 else 0.0, "stats": ctx.msm_stats()}
 
-    # secondary leg first: the other table setting, same inputs
+    def timed_ntt(d_vec, log_n, steps, warmup):
+        for _ in range(warmup):
+            ctx.ntt_device(d_vec.data_ptr(), log_n)
+        barrier()
+        ms = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.ntt_device(d_vec.data_ptr(), log_n)
+            ms.append(ctx.ntt_stats()["device_ms"])
+        barrier()
+        return {"elapsed": time.perf_counter() - t0, "dev_ms": float(np.mean(ms)), "passes": ctx.ntt_stats()["passes"]}
+
+    def synthetic(count, seed, first=0):
+        """`count` scalars of the global stream `seed`, starting at element `first` (8 SplitMix64 words per element)"""
+        t = torch.empty(count * 4, dtype=torch.int64, device=dev)
+        ctx.synthetic_scalars_device(t.data_ptr(), count, (seed + GOLDEN * 8 * first) & MASK64)
+        return t
+
+    # ---------------------------------------------------------------- weak-scaling MSM (the headline `value`)
+    n = 1 << args.log_n
+    srs = ctx.srs_generate_progression(n, A0 + rank * n * D0, D0)          # this rank's point range [rank n, (rank + 1) n)
+    scal = synthetic(n, 0x5EED0000 + args.log_n, rank * n)
     table_info, table_build_s = {"window_bits": 0, "windows": 0, "bytes": 0}, 0.0
-    if args.no_tables:
+    if args.no_tables:                  # secondary leg first: the other table setting, same inputs
         t0 = time.perf_counter()
         table_info = ctx.srs_precompute(srs, 0)
         table_build_s = time.perf_counter() - t0
-        other = timed_msm()
+        other = timed_msm(srs, scal, n, args.steps, args.warmup)
         ctx.srs_precompute(srs, bp.SRS_TABLES_OFF)
     else:
-        other = timed_msm()
+        other = timed_msm(srs, scal, n, args.steps, args.warmup)
         t0 = time.perf_counter()
         table_info = ctx.srs_precompute(srs, 0)
         table_build_s = time.perf_counter() - t0
-    result, elapsed, acc_ms, dev_ms, stats = timed_msm()
-    assert other[0] == result, "MSM with and without fixed-base tables disagree"
-    assert stats["tables"] == (not args.no_tables)
+    head = timed_msm(srs, scal, n, args.steps, args.warmup)
+    assert other["result"] == head["result"], "MSM with and without fixed-base tables disagree"
+    assert head["stats"]["tables"] == (not args.no_tables)
 
-    # ---- NTT leg (independent columns, no collective) ----
+    # ---------------------------------------------------------------- seams of the reference (N = 1): host scalars, uncached points
+    seams = {}
+    if world == 1 and not args.skip_seams:
+        host_scal = scal.cpu().numpy().view(np.uint64).reshape(n, 4)       # pageable memory, as a Rust Vec<Scalar> is
+        for _ in range(args.warmup):
+            r = ctx.msm(srs, host_scal)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r = ctx.msm(srs, host_scal)
+        dt = time.perf_counter() - t0
+        assert r == head["result"]
+        seams["msm_host_scalars"] = {
+            "value": n * args.steps / dt, "unit": "scalar-muls/s", "ms_per_step": 1e3 * dt / args.steps, "device_ms": ctx.msm_stats()["device_ms"],
+            "seam": "Setup::commit(&Polynomial) (setup.rs:32-37): %d MiB of pageable host scalars cross PCIe per call, SRS and tables resident"
+                    % (32 * n >> 20)}
+        images = ctx.srs_export_projective144(srs)                         # what Setup.powers_of_x: Vec<G1Projective> holds (g1.rs:442-446)
+        reps = max(2, min(args.steps, 5))
+        best, tot = None, 0.0
+        for i in range(reps + 1):
+            t0 = time.perf_counter()
+            h = ctx.srs_load_projective144(images)
+            r = ctx.msm(h, host_scal)
+            ctx.srs_free(h)
+            dt = time.perf_counter() - t0
+            if i:                                                          # first pass warms the staging workspaces
+                tot += dt
+                best = dt if best is None or dt < best else best
+        assert r == head["result"]
+        seams["msm_uncached_seam"] = {
+            "value": n * reps / tot, "unit": "scalar-muls/s", "ms_per_call": 1e3 * tot / reps, "best_ms": 1e3 * best,
+            "seam": "BucketMSM::bucket_msm(points: &[G1Projective], scalars, 256, 4) (msm.rs:76-81) taken literally: upload %d MiB of "
+                    "projective points + %d MiB of scalars from pageable memory, normalise on the GPU (bp_srs_load_projective144), "
+                    "multiply without tables, free" % (144 * n >> 20, 32 * n >> 20)}
+        del images, host_scal
+
+    # ---------------------------------------------------------------- NTT leg (independent columns, no collective)
     nn = 1 << args.ntt_log_n
-    vec = torch.empty(nn * 4, dtype=torch.int64, device=dev)
-    ctx.synthetic_scalars_device(vec.data_ptr(), nn, (0xF40000 + args.ntt_log_n + GOLDEN * 8 * rank * nn) & (2**64 - 1))
-    for _ in range(args.warmup):
-        ctx.ntt_device(vec.data_ptr(), args.ntt_log_n)
-    barrier()
-    ntt_ms = []
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.ntt_device(vec.data_ptr(), args.ntt_log_n)
-        ntt_ms.append(ctx.ntt_stats()["device_ms"])
-    barrier()
-    ntt_elapsed = time.perf_counter() - t1
-    ntt_passes = ctx.ntt_stats()["passes"]
+    vec = synthetic(nn, 0xF40000 + args.ntt_log_n, rank * nn)
+    ntt = timed_ntt(vec, args.ntt_log_n, args.steps, args.warmup)
 
-    # ---- the metric's other sizes (BASELINE: "at 2^20 / 2^24", 2^16 = configs[1]); single GPU only, best of 3 runs ----
+    # ---------------------------------------------------------------- the metric's other sizes, N = 1 (2^16 = configs[1]; 2^24 rides on the strong leg)
     sizes = {}
+
+    def release():
+        nonlocal srs, scal, vec
+        if srs is not None:
+            ctx.srs_free(srs)
+        srs = scal = vec = None
+        torch.cuda.empty_cache()
+
     if world == 1:
         for lg in args.other_sizes:
-            if lg == args.log_n or lg < 10 or lg > 26:
+            if lg == args.log_n or lg == args.strong_log_n or lg < 10 or lg > 26:
                 continue
             m = 1 << lg
-            ctx.srs_free(srs)
-            del scal, vec
-            torch.cuda.empty_cache()
+            release()
             srs = ctx.srs_generate_progression(m, A0, D0)
             if not args.no_tables:
                 ctx.srs_precompute(srs, 0)
-            scal = torch.empty(m * 4, dtype=torch.int64, device=dev)
-            ctx.synthetic_scalars_device(scal.data_ptr(), m, (0x5EED0000 + lg) & (2**64 - 1))
-            vec = torch.empty(m * 4, dtype=torch.int64, device=dev)
-            ctx.synthetic_scalars_device(vec.data_ptr(), m, (0xF40000 + lg) & (2**64 - 1))
-            best_msm, best_ntt = None, None
-            for _ in range(4):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                ctx.msm_partial(srs, None, device_ptr=scal.data_ptr(), n=m)
-                dt = time.perf_counter() - t0
-                best_msm = dt if best_msm is None or dt < best_msm else best_msm
-                ctx.ntt_device(vec.data_ptr(), lg)
-                dn = ctx.ntt_stats()["device_ms"] * 1e-3
-                best_ntt = dn if best_ntt is None or dn < best_ntt else best_ntt
-            st = ctx.msm_stats()
-            sizes["2^%d" % lg] = {"msm_scalar_muls_per_s": m / best_msm, "msm_ms": 1e3 * best_msm, "msm_accumulate_ms": st["accumulate_ms"],
-                                  "window_bits": st["window_bits"], "tables": st["tables"],
-                                  "ntt_elements_per_s": m / best_ntt, "ntt_device_ms": 1e3 * best_ntt, "ntt_passes": ctx.ntt_stats()["passes"]}
+            scal = synthetic(m, 0x5EED0000 + lg)
+            vec = synthetic(m, 0xF40000 + lg)
+            k = args.steps if lg <= 22 else max(2, min(args.steps, 5))
+            r = timed_msm(srs, scal, m, k, args.warmup)
+            t = timed_ntt(vec, lg, k, args.warmup)
+            hbm, issue = msm_roofline(m, r["acc_ms"] * 1e-3, r["stats"]["mixed_adds"], r["stats"]["window_bits"], r["stats"]["tables"])
+            sizes["2^%d" % lg] = {"steps": k, "msm": {"value": m * k / r["elapsed"], "unit": "scalar-muls/s", "ms_per_step": 1e3 * r["elapsed"] / k,
+                                                        "device_ms": r["dev_ms"], "window_bits": r["stats"]["window_bits"], "tables": r["stats"]["tables"],
+                                                        "roofline": hbm, "roofline_valu_issue": issue},
+                                  "ntt": {"value": m * k / t["elapsed"], "unit": "elements/s", "ms_per_step": 1e3 * t["elapsed"] / k, "passes": t["passes"],
+                                          "roofline": ntt_roofline(m, t["dev_ms"] * 1e-3, t["passes"])}}
 
-    # ---- prover leg (BASELINE configs[4]): independent proofs per GPU (replicas, no collective) ----
+    # ---------------------------------------------------------------- strong scaling = BASELINE configs[3]: ONE 2^24-point MSM over all ranks
+    strong = None
+    if args.strong_log_n:
+        release()
+        total = 1 << args.strong_log_n
+        lo, hi = bpd.shard_range(total, rank, world)
+        m = hi - lo
+        t0 = time.perf_counter()
+        srs = ctx.srs_generate_progression(m, A0 + lo * D0, D0)
+        t_gen = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        s_info = ctx.srs_precompute(srs, bp.SRS_TABLES_OFF if args.no_tables else 0)
+        t_tab = time.perf_counter() - t0
+        scal = synthetic(m, 0x5EED0000 + args.strong_log_n, lo)
+        k = args.strong_steps or max(2, min(args.steps, 10))
+        r = timed_msm(srs, scal, m, k, 2)
+        strong = {"r": r, "k": k, "m": m, "total": total, "table_info": s_info, "gen_s": t_gen, "table_s": t_tab}
+        if world == 1 and args.strong_log_n <= 26:
+            vec = synthetic(total, 0xF40000 + args.strong_log_n)
+            strong["ntt"] = timed_ntt(vec, args.strong_log_n, k, 2)
+
+    # ---------------------------------------------------------------- prover leg (BASELINE configs[4])
     prove = None
     if args.prove_log_n:
-        import hashlib
         import random
+        import threading
         from baby_plonk_rust_amd.synthetic import Q as FR_Q, chained_multiplications
         pn = 1 << args.prove_log_n
-        ctx.srs_free(srs)
-        del scal, vec
-        torch.cuda.empty_cache()
+        release()
         t0 = time.perf_counter()
         cols, pk = chained_multiplications(pn, 1000 + rank)
         t_circuit_host = time.perf_counter() - t0
-        import threading
         t0 = time.perf_counter()
         provers = []
         for j in range(max(1, args.prove_streams)):              # each concurrent prover owns a context (= HIP stream), SRS tables, circuit
@@ -251,14 +414,14 @@ def main():
         ptrs = [w.data_ptr() for w in wit]
         blobs = [p.prove_device(ptrs[0], ptrs[1], ptrs[2], None, blinders) for p in provers]      # warm-up (workspaces, NTT tables)
         assert all(b == blobs[0] for b in blobs)
-        # latency: one prover, proofs back to back
-        barrier()
+        barrier()                                                # latency: one prover, proofs back to back
         t0 = time.perf_counter()
         for _ in range(args.prove_reps):
             blob = provers[0].prove_device(ptrs[0], ptrs[1], ptrs[2], None, blinders)
         barrier()
         single_elapsed = time.perf_counter() - t0
         round_ms = provers[0].last_stats()["round_ms"]
+
         # throughput: all provers of this GPU at once (one host thread each; the library calls release the GIL), so one
         # proof's latency-bound tails (bucket reduction, scans, host transcript) overlap another proof's bulk kernels
         def run(p):
@@ -272,73 +435,113 @@ def main():
         for th in threads:
             th.join()
         barrier()
-        prove_elapsed = time.perf_counter() - t0
-        prove = {"elapsed": prove_elapsed, "single_elapsed": single_elapsed, "round_ms": round_ms, "sha": hashlib.sha256(blob).hexdigest()[:16],
-                 "setup_s": t_setup, "circuit_host_s": t_circuit_host, "streams": len(provers)}
+        prove = {"elapsed": time.perf_counter() - t0, "single_elapsed": single_elapsed, "round_ms": round_ms, "sha": hashlib.sha256(blob).hexdigest()[:16],
+                 "setup_s": t_setup, "circuit_host_s": t_circuit_host, "streams": len(provers), "group": None}
+        # one proof on ONE context over all N GPUs (bp_init_multi): the nine commitments of prover.rs are sharded by point range,
+        # everything else runs on GPU 0.  Rank 0 drives it; the other ranks have freed their memory and wait on the host.
+        if world > 1 and args.backend == "nccl":
+            del provers, wit
+            torch.cuda.empty_cache()
+            dist.barrier(group=ctl)
+            if rank == 0:
+                try:
+                    gctx = bp.Context(list(range(world)))
+                    gsetup = bp.Setup.generate_srs(pn + 6, 0x1234567 + args.prove_log_n, gctx, tables=not args.no_tables)
+                    gprover = bp.Prover(gsetup, bp.Circuit(pk, gctx))
+                    gwit = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
+                    gp = [w.data_ptr() for w in gwit]
+                    gblob = gprover.prove_device(gp[0], gp[1], gp[2], None, blinders)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(args.prove_reps):
+                        gblob = gprover.prove_device(gp[0], gp[1], gp[2], None, blinders)
+                    g_elapsed = time.perf_counter() - t0
+                    prove["group"] = {"n_gpus": world, "latency_ms_per_proof": 1e3 * g_elapsed / args.prove_reps, "round_ms": gprover.last_stats()["round_ms"],
+                                      "same_proof_bytes_as_one_gpu": gblob == blob,
+                                      "how": "one bp_init_multi context in rank 0's process: SRS and the nine MSMs of a proof sharded by point "
+                                             "range over the %d GPUs (peer copies of the scalar slices, partial sums added on the host), "
+                                             "polynomial rounds on GPU 0" % world}
+                    gctx.close()
+                except Exception as e:                            # never lose the line over the optional leg
+                    prove["group"] = {"n_gpus": world, "error": repr(e)[:300]}
+            dist.barrier(group=ctl)
 
-    other_elapsed = other[1]
-    if world > 1:
-        t = torch.tensor([elapsed, ntt_elapsed, other_elapsed, prove["elapsed"] if prove else 0.0, prove["single_elapsed"] if prove else 0.0],
-                         dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, ntt_elapsed, other_elapsed = float(t[0]), float(t[1]), float(t[2])
-        if prove:
-            prove["elapsed"], prove["single_elapsed"] = float(t[3]), float(t[4])
+    # ---------------------------------------------------------------- reduce over ranks, print the line
+    times = [head["elapsed"], ntt["elapsed"], other["elapsed"], prove["elapsed"] if prove else 0.0, prove["single_elapsed"] if prove else 0.0,
+             strong["r"]["elapsed"] if strong else 0.0]
+    elapsed, ntt_elapsed, other_elapsed, prove_elapsed, prove_single, strong_elapsed = max_over_ranks(times)
+    per_rank = gather_objects({"rank": rank, "device": dev_index, "weak_accumulate_ms": head["acc_ms"], "weak_device_ms": head["dev_ms"],
+                               "weak_exchange_ms": head["exchange_ms"],
+                               "strong_points": strong["m"] if strong else 0, "strong_accumulate_ms": strong["r"]["acc_ms"] if strong else 0.0,
+                               "strong_device_ms": strong["r"]["dev_ms"] if strong else 0.0,
+                               "strong_exchange_ms": strong["r"]["exchange_ms"] if strong else 0.0})
 
     if rank == 0:
+        stats = head["stats"]
         units = world * n * args.steps
-        value = units / elapsed
-        acc = float(np.mean(acc_ms)) * 1e-3
-        achieved = MSM_BYTES_PER_UNIT * n / acc / 1e9
-        ntt_t = float(np.mean(ntt_ms)) * 1e-3
-        ntt_achieved = NTT_BYTES_PER_UNIT * nn / ntt_t / 1e9
+        cfg_key = "2p%d_c%d%s" % (args.log_n, stats["window_bits"], "_tables" if stats["tables"] else "")
+        hbm, issue = msm_roofline(n, head["acc_ms"] * 1e-3, stats["mixed_adds"], stats["window_bits"], stats["tables"], "msm_accumulate_" + cfg_key)
         line = {
             "metric": "g1_msm_scalar_muls_per_s",
             "baseline_metric": "G1 MSM scalar-muls/s + Fr NTT elements/s at 2^20/2^24; proof bit-exact",
-            "value": value, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": units / elapsed, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 limbs (381-bit Fp Montgomery, 255-bit Fr)", "data": "synthetic",
-            "config": {"workload": "2^%d-point BLS12-381 G1 MSM per GPU (global 2^%d x %d points, point-range shards, "
-                                   "RCCL all-gather of 144-B partials), SRS %s; + 2^%d Fr NTT per GPU; BASELINE configs[2] at N=1"
+            "config": {"workload": "2^%d-point BLS12-381 G1 MSM per GPU (global 2^%d x %d points, point-range shards, one RCCL all-gather "
+                                   "of the ranks' partial-sum records), SRS %s; + 2^%d Fr NTT per GPU; BASELINE configs[2] at N=1"
                                    % (args.log_n, args.log_n, world,
-                                      "raw points only" if args.no_tables else "resident with its fixed-base window tables (Setup)",
-                                      args.ntt_log_n),
+                                      "raw points only" if args.no_tables else "resident with its fixed-base window tables (Setup)", args.ntt_log_n),
                        "msm_points_per_gpu": n, "window_bits": stats["window_bits"], "ntt_len_per_gpu": nn,
                        "srs_tables": {"used": stats["tables"], "window_bits": table_info["window_bits"], "windows": table_info["windows"],
                                       "bytes_per_gpu": table_info["bytes"], "build_s": table_build_s},
-                       "parallelism": "point-range x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("msm_accumulate_2p20_c16" + ("" if args.no_tables else "_tables"))
-                         if (args.log_n == 20 and stats["window_bits"] == 16) else None,
-                         "kernel_ms": acc * 1e3, "algorithmic_bytes_per_launch": MSM_BYTES_PER_UNIT * n,
-                         "note": "integer-ALU bound by design (11 Fp mul per bucket add); see DESIGN.md"},
-            "roofline_valu_issue": {"bound": "valu_issue (integer multiply-add)", "kernel": "msm_accumulate",
-                                    "achieved": stats["mixed_adds"] * ACC_INSTR_PER_ADD / acc, "peak": VALU_PEAK_LANE_INSTR_S,
-                                    "unit": "lane-instructions/s", "frac": stats["mixed_adds"] * ACC_INSTR_PER_ADD / acc / VALU_PEAK_LANE_INSTR_S,
-                                    "note": "mixed additions per launch x static instruction count of the loop body / measured kernel time, against "
-                                            "the measured v_mad_u64_u32 issue rate (57 lanes/clk/CU x 256 CU x 2.4 GHz)"},
-            "msm_device_ms": float(np.mean(dev_ms)),
+                       "parallelism": "point-range x%d" % world, "ranks": world, "backend": args.backend if world > 1 else None},
+            "roofline": hbm,
+            "roofline_valu_issue": issue,
+            "msm_device_ms": head["dev_ms"],
+            "exchange_ms": head["exchange_ms"],
             ("msm_with_tables" if args.no_tables else "msm_without_tables"): {
                 "value": units / other_elapsed, "unit": "scalar-muls/s", "ms_per_step": 1e3 * other_elapsed / args.steps,
-                "device_ms": float(np.mean(other[3])), "accumulate_ms": float(np.mean(other[2])), "window_bits": other[4]["window_bits"]},
+                "device_ms": other["dev_ms"], "accumulate_ms": other["acc_ms"], "window_bits": other["stats"]["window_bits"]},
             "ntt": {"metric": "fr_ntt_elements_per_s", "value": world * nn * args.steps / ntt_elapsed, "unit": "elements/s",
-                    "ms_per_step": 1e3 * ntt_elapsed / args.steps, "passes": ntt_passes,
-                    "roofline": {"bound": "hbm", "kernel": "ntt_pass_* (all passes of one transform)", "achieved": ntt_achieved,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_achieved / HBM_PEAK_GBS,
-                                 "traffic": measured_traffic("ntt_2p20_two_passes") if (args.ntt_log_n == 20 and ntt_passes == 2) else None,
-                                 "kernel_ms": ntt_t * 1e3, "algorithmic_bytes_per_launch": NTT_BYTES_PER_UNIT * nn}},
-            "result_sha": __import__("hashlib").sha256(result).hexdigest()[:16],
+                    "ms_per_step": 1e3 * ntt_elapsed / args.steps, "passes": ntt["passes"],
+                    "roofline": ntt_roofline(nn, ntt["dev_ms"] * 1e-3, ntt["passes"], "ntt_2p%d" % args.ntt_log_n)},
+            "result_sha": hashlib.sha256(head["result"]).hexdigest()[:16],
+            "per_rank": per_rank,
         }
+        line.update(seams)
         if sizes:
             line["other_sizes"] = sizes
+        if strong:
+            r, k = strong["r"], strong["k"]
+            s_hbm, s_issue = msm_roofline(strong["m"], r["acc_ms"] * 1e-3, r["stats"]["mixed_adds"], r["stats"]["window_bits"], r["stats"]["tables"],
+                                          "msm_accumulate_2p%d_c%d%s" % (args.strong_log_n, r["stats"]["window_bits"], "_tables" if r["stats"]["tables"] else "")
+                                          if world == 1 else None)
+            line["strong_scaling"] = {
+                "metric": "g1_msm_scalar_muls_per_s", "value": strong["total"] * k / strong_elapsed, "unit": "scalar-muls/s", "scaling": "strong",
+                "n_gpus": world, "rccl_ranks": world if args.backend == "nccl" else 0, "steps": k, "warmup": 2, "ms_per_step": 1e3 * strong_elapsed / k,
+                "workload": "ONE 2^%d-point G1 MSM (BASELINE configs[3]), %d points per rank, SRS shards resident with tables; per step: "
+                            "per-rank Pippenger, one all-gather of %d-byte records in HBM, one D2H, host combine"
+                            % (args.strong_log_n, strong["m"], bp._lib.MSM_BLOB_BYTES),
+                "points_per_rank": strong["m"], "window_bits": r["stats"]["window_bits"], "tables": r["stats"]["tables"],
+                "accumulate_ms_per_rank": [p["strong_accumulate_ms"] for p in per_rank],
+                "device_ms_per_rank": [p["strong_device_ms"] for p in per_rank],
+                "exchange_ms_per_rank": [p["strong_exchange_ms"] for p in per_rank],
+                "srs_generate_s": strong["gen_s"], "table_build_s": strong["table_s"], "table_bytes_per_gpu": strong["table_info"]["bytes"],
+                "result_sha": hashlib.sha256(r["result"]).hexdigest()[:16],
+                "roofline": s_hbm, "roofline_valu_issue": s_issue}
+            if "ntt" in strong:
+                t = strong["ntt"]
+                line["strong_scaling"]["ntt"] = {"value": strong["total"] * k / t["elapsed"], "unit": "elements/s", "ms_per_step": 1e3 * t["elapsed"] / k,
+                                                 "passes": t["passes"],
+                                                 "roofline": ntt_roofline(strong["total"], t["dev_ms"] * 1e-3, t["passes"], "ntt_2p%d" % args.strong_log_n)}
         if prove:
-            line["prove"] = {"metric": "plonk_proofs_per_s", "value": world * prove["streams"] * args.prove_reps / prove["elapsed"], "unit": "proofs/s",
+            line["prove"] = {"metric": "plonk_proofs_per_s", "value": world * prove["streams"] * args.prove_reps / prove_elapsed, "unit": "proofs/s",
                              "gates": 1 << args.prove_log_n, "concurrent_provers_per_gpu": prove["streams"],
-                             "latency_ms_per_proof_single_prover": 1e3 * prove["single_elapsed"] / args.prove_reps,
-                             "proofs_per_s_single_prover_per_gpu": args.prove_reps / prove["single_elapsed"],
+                             "latency_ms_per_proof_single_prover": 1e3 * prove_single / args.prove_reps,
+                             "proofs_per_s_single_prover_per_gpu": args.prove_reps / prove_single,
                              "round_ms": prove["round_ms"], "proofs_timed_per_gpu": prove["streams"] * args.prove_reps,
                              "parallelism": "independent proofs x%d" % world,
+                             "one_proof_over_all_gpus": prove["group"],
                              "workload": "bp_prove: prover.rs rounds 1-5 + host transcript on a synthetic 2^%d-gate circuit (chained "
                                          "multiplications), witness and circuit resident in HBM, 624-byte proof out; BASELINE configs[4]"
                                          % args.prove_log_n,
@@ -348,6 +551,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, min(64, os.cpu_count() or 1))
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier(group=ctl) if ctl is not None else dist.barrier()
         dist.destroy_process_group()
 
 

@@ -95,6 +95,8 @@ int  bp_srs_generate_progression(bp_ctx* ctx, size_t n, const uint8_t a32[32], c
 int  bp_srs_len(bp_ctx* ctx, uint64_t srs_handle, size_t* n);
 /* Read points [first, first+n) back in the 96-byte encoding (G1Affine::to_uncompressed). */
 int  bp_srs_export(bp_ctx* ctx, uint64_t srs_handle, size_t first, size_t n, uint8_t* points96);
+/* The same points as G1Projective memory images (z = 1, the identity as (0 : 1 : 0)): G1Projective::from(&G1Affine), g1.rs:176-190. */
+int  bp_srs_export_projective144(bp_ctx* ctx, uint64_t srs_handle, size_t first, size_t n, uint8_t* points144);
 int  bp_srs_free(bp_ctx* ctx, uint64_t srs_handle);
 /* Fixed-base window tables for an SRS that serves many commitments (Setup lives as long as the prover,
  * src/setup.rs:7-10): T[w][i] = 2^(window_bits * w) * P_i for every window w, affine, resident in HBM

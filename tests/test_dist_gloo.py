@@ -68,3 +68,18 @@ def test_shard_range_partition():
             assert max(sizes) - min(sizes) <= 1
     assert [bpd.column_owner(j, 4) for j in range(6)] == [0, 1, 2, 3, 0, 1]
     assert sorted(sum((bpd.my_columns(23, r, 8) for r in range(8)), [])) == list(range(23))
+
+
+def test_bench_refuses_to_fake_ranks_without_gpus():
+    """`python bench.py --gpus N` must start N ranks or fail loudly -- never run one rank and call it N.
+    In this container no GPU is visible, so any N > 1 is refused before anything is launched."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         timeout=300, cwd=root, env=env)
+    assert out.returncode == 2 and "--gpus 2" in out.stderr and not out.stdout.strip()

@@ -56,14 +56,37 @@ def test_two_ranks_point_range_shards_on_one_gpu():
     assert all(got == want for _, got in res)
 
 
-def test_bench_two_rank_rehearsal():
-    port = _free_port()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "14",
-           "--ntt-log-n", "14", "--prove-log-n", "10", "--prove-reps", "2", "--backend", "gloo", "--skip-cpu"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the two ranks itself (before touching the GPU) and
+    relays rank 0's line.  gloo backend = a rehearsal of the N > 1 control flow on a 1-GPU box: barriers, max-over-ranks timing,
+    the records' all-gather, both scaling legs, the rank-0 JSON line."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "14", "--ntt-log-n", "14",
+           "--strong-log-n", "15", "--prove-log-n", "10", "--prove-reps", "2", "--backend", "gloo", "--skip-cpu"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # exactly one result line reaches the caller
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["ntt"]["value"] > 0
-    assert line["config"]["msm_points_per_gpu"] == 1 << 14
+    assert line["config"]["msm_points_per_gpu"] == 1 << 14 and len(line["per_rank"]) == 2
+    st = line["strong_scaling"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["points_per_rank"] == 1 << 14 and st["value"] > 0
+    assert len(st["accumulate_ms_per_rank"]) == 2 and all(v > 0 for v in st["accumulate_ms_per_rank"])
     assert line["prove"]["gates"] == 1 << 10 and line["prove"]["value"] > 0 and line["prove"]["parallelism"] == "independent proofs x2"
+    # the strong-scaling problem is the same for every N: one rank must get the same bytes
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "14", "--ntt-log-n", "14",
+                          "--strong-log-n", "15", "--prove-log-n", "0", "--skip-cpu", "--skip-seams", "--other-sizes"], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT, env=env)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    line1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert line1["n_gpus"] == 1 and line1["strong_scaling"]["result_sha"] == st["result_sha"]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], capture_output=True,
+                         text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 2 and "--gpus %d" % (n + 1) in out.stderr and not out.stdout.strip()

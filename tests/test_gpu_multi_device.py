@@ -170,6 +170,11 @@ def test_projective_image_seam():
     assert ctx.srs_export(h) == b"".join(M.enc96(M.ec_mul(k)) for k in ks)
     sc = O.splitmix_scalars(len(ks), 3)
     assert ctx.msm(h, sc) == M.enc96(M.ec_mul(sum(k * s for k, s in zip(ks, O.fr_array_to_ints(sc))) % Q))
+    # export in the same form (z = 1; identity = (0 : 1 : 0)) and load it back
+    img = ctx.srs_export_projective144(h)
+    assert bp.sum_partials(img[144 * 4: 144 * 5].tobytes()) == M.enc96(M.ec_mul(5)) and bp.sum_partials(img[:144].tobytes()) == M.enc96(None)
+    assert ctx.srs_export(ctx.srs_load_projective144(img)) == ctx.srs_export(h)
     many = bp.Context([0, 0])
     hm = many.srs_load_projective144(b"".join(p.tobytes() for p in pts))
+    assert (many.srs_export_projective144(hm) == img).all()
     assert many.srs_export(hm) == ctx.srs_export(h) and many.msm(hm, sc) == ctx.msm(h, sc)
