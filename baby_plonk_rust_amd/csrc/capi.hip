@@ -1068,13 +1068,10 @@ int bp_poly_div_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b,
     *n_out = nq;
     return BP_OK;
   }
-  std::vector<fr_t> h(nq);
-  BP_HIP(ctx, hipMemcpyAsync(h.data(), q, nq * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+  size_t m = nq;
+  BP_TRY(fr_compact_nonzero_run(ctx, q, &m));
+  if (m) BP_HIP(ctx, hipMemcpyAsync(d_out, q, m * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  size_t m = 0;
-  for (size_t i = 0; i < nq; i++)
-    if (!big_is_zero(h[i])) h[m++] = h[i];
-  if (m) BP_HIP(ctx, hipMemcpy(d_out, h.data(), m * sizeof(fr_t), hipMemcpyHostToDevice));
   *n_out = m;
   return BP_OK;
 }

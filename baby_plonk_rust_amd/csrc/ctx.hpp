@@ -151,6 +151,7 @@ int poly_eval_run(bp_ctx* ctx, const fr_t* d_coeffs, size_t n, const fr_t& x, fr
 int poly_div_run(bp_ctx* ctx, fr_t* d_a, size_t na, const fr_t* d_b, size_t nb, const fr_t& b0, const fr_t& b_lead, bool binomial,
                  fr_t* d_q, size_t nq);
 int fr_nonzero_stats_run(bp_ctx* ctx, const fr_t* d_a, size_t n, size_t lo, size_t hi, size_t* eff_len, size_t* nonzero_in_range);
+int fr_compact_nonzero_run(bp_ctx* ctx, fr_t* d_q, size_t* n);
 int fr_scale_powers_run(bp_ctx* ctx, const fr_t* d_a, size_t n, const fr_t& w, fr_t* d_out);
 int fr_synthetic_run(bp_ctx* ctx, fr_t* d_out, size_t n, uint64_t seed);
 int fr_scan_mul_run(bp_ctx* ctx, const fr_t* d_in, size_t n, int reverse, int inclusive, fr_t* d_out, fr_t* d_total);

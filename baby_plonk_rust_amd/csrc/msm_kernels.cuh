@@ -378,9 +378,12 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
   uint32_t g_end = offsets[g + 1];
   uint32_t run_start = p0;
   g1_proj28 acc = g1_identity28();
-  // software pipeline: the gather of entry p+1 is in flight while entry p is added
-  uint32_t e_next = sorted[p0];
-  g1_affine28 q_next = load_affine28(&points[e_next & 0x7fffffffu]);
+  // software pipeline, two deep: while entry p is added, the gather of entry p+1 is in flight AND the index of entry p+2 is
+  // being fetched -- the gather's address is then in a register when the next iteration starts (with a one-deep pipeline
+  // every iteration stalled on `sorted[p+1]` before it could issue the gather: a full memory latency per addition)
+  uint32_t e_cur = sorted[p0];
+  uint32_t e_ahead = p0 + 1 < p1 ? sorted[p0 + 1] : 0u;
+  g1_affine28 q_next = load_affine28(&points[e_cur & 0x7fffffffu]);
   for (uint32_t p = p0; p < p1; p++) {
     if (p >= g_end) {                            // leave bucket g: flush its run [run_start, p)
       const bool complete = run_start == offsets[g];    // it ended at g_end by construction
@@ -389,12 +392,11 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
       run_start = p;
       do { g++; g_end = offsets[g + 1]; } while (p >= g_end);    // skip empty buckets
     }
-    const uint32_t e = e_next;
+    const uint32_t e = e_cur;
     const g1_affine28 q = q_next;
-    if (p + 1 < p1) {
-      e_next = sorted[p + 1];
-      q_next = load_affine28(&points[e_next & 0x7fffffffu]);
-    }
+    if (p + 1 < p1) q_next = load_affine28(&points[e_ahead & 0x7fffffffu]);
+    e_cur = e_ahead;
+    if (p + 2 < p1) e_ahead = sorted[p + 2];
     uint32_t nz = 0;
 #pragma unroll
     for (int j = 0; j < N28; j++) nz |= q.x.l[j] | q.y.l[j];

@@ -80,6 +80,28 @@ int fr_nonzero_stats_run(bp_ctx* ctx, const fr_t* d_a, size_t n, size_t lo, size
   if (nonzero_in_range) *nonzero_in_range = (size_t)h[1];
   return BP_OK;
 }
+// d_q[0..*n) -> its non-zero elements in order, in place (through a workspace); *n = how many remain.  All on the device.
+int fr_compact_nonzero_run(bp_ctx* ctx, fr_t* d_q, size_t* n) {
+  if (*n == 0) return BP_OK;
+  if (*n >= ((size_t)1 << 32)) return fail(ctx, BP_ERR_TOO_LARGE, "compaction longer than 2^32", hipSuccess, __FILE__, __LINE__);
+  const uint32_t n_tiles = (uint32_t)((*n + COMPACT_TILE - 1) / COMPACT_TILE);
+  uint32_t* tiles;
+  fr_t* tmp;
+  unsigned long long* d_total;
+  BP_TRY(ws_get(ctx, "poly.compact_tiles", (size_t)n_tiles * 4, (void**)&tiles));
+  BP_TRY(ws_get(ctx, "poly.compact_tmp", *n * sizeof(fr_t), (void**)&tmp));
+  BP_TRY(ws_get(ctx, "poly.nzstats", 16, (void**)&d_total));
+  hipLaunchKernelGGL(fr_compact_count, dim3(n_tiles), dim3(256), 0, ctx->stream, d_q, *n, tiles);
+  hipLaunchKernelGGL(fr_compact_scan, dim3(1), dim3(256), 0, ctx->stream, tiles, n_tiles, d_total);
+  hipLaunchKernelGGL(fr_compact_scatter, dim3(n_tiles), dim3(256), 0, ctx->stream, d_q, *n, tiles, tmp);
+  BP_HIP(ctx, hipGetLastError());
+  unsigned long long m = 0;
+  BP_HIP(ctx, hipMemcpyAsync(&m, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (m) BP_HIP(ctx, hipMemcpyAsync(d_q, tmp, (size_t)m * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
+  *n = (size_t)m;
+  return BP_OK;
+}
 int fr_scale_powers_run(bp_ctx* ctx, const fr_t* d_a, size_t n, const fr_t& w, fr_t* d_out) {
   if (n == 0) return BP_OK;
   hipLaunchKernelGGL(fr_scale_powers, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_a, n, w, d_out);

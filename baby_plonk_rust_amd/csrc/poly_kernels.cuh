@@ -317,6 +317,71 @@ __global__ void __launch_bounds__(256) fr_nonzero_stats(const fr_t* __restrict__
     if (cnt) atomicAdd(&out[1], cnt);
   }
 }
+// ---- stable compaction of the non-zero elements (the reference's Div squeezes zero quotient coefficients out,
+// polynomial.rs:371-376): count per tile, scan the tile counts, scatter.  Tile = 256 lanes x COMPACT_PER_LANE elements.
+constexpr uint32_t COMPACT_PER_LANE = 8, COMPACT_TILE = 256 * COMPACT_PER_LANE;
+__device__ __forceinline__ uint32_t compact_block_scan(uint32_t v, uint32_t* lds4, uint32_t& total) {       // exclusive scan over 256 lanes
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(incl, d, 64);
+    if (lane >= (uint32_t)d) incl += t;
+  }
+  if (lane == 63) lds4[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const uint32_t x = lds4[w];
+    if ((uint32_t)w < wave) base += x;
+    tot += x;
+  }
+  __syncthreads();
+  total = tot;
+  return base + incl - v;
+}
+__global__ void __launch_bounds__(256) fr_compact_count(const fr_t* __restrict__ a, size_t n, uint32_t* __restrict__ tile_count) {
+  __shared__ uint32_t lds4[4];
+  const size_t base = (size_t)blockIdx.x * COMPACT_TILE + (size_t)threadIdx.x * COMPACT_PER_LANE;
+  uint32_t c = 0;
+  for (uint32_t j = 0; j < COMPACT_PER_LANE; j++)
+    if (base + j < n && !big_is_zero(load_fr(&a[base + j]))) c++;
+  uint32_t tot;
+  (void)compact_block_scan(c, lds4, tot);
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = tot;
+}
+// exclusive scan of the tile counts in place, one workgroup (any number of tiles); total -> *total_out
+__global__ void __launch_bounds__(256) fr_compact_scan(uint32_t* __restrict__ tile_count, uint32_t n_tiles, unsigned long long* __restrict__ total_out) {
+  __shared__ uint32_t lds4[4];
+  uint32_t running = 0;
+  for (uint32_t b = 0; b < n_tiles; b += 256) {
+    const uint32_t i = b + threadIdx.x, v = i < n_tiles ? tile_count[i] : 0;
+    uint32_t tot, ex = compact_block_scan(v, lds4, tot);
+    if (i < n_tiles) tile_count[i] = running + ex;
+    running += tot;
+  }
+  if (threadIdx.x == 0) *total_out = running;
+}
+__global__ void __launch_bounds__(256) fr_compact_scatter(const fr_t* __restrict__ a, size_t n, const uint32_t* __restrict__ tile_offset,
+                                                           fr_t* __restrict__ out) {
+  __shared__ uint32_t lds4[4];
+  const size_t base = (size_t)blockIdx.x * COMPACT_TILE + (size_t)threadIdx.x * COMPACT_PER_LANE;
+  fr_t v[COMPACT_PER_LANE];
+  uint32_t c = 0, keep = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < COMPACT_PER_LANE; j++) {
+    if (base + j < n) {
+      v[j] = load_fr(&a[base + j]);
+      if (!big_is_zero(v[j])) { keep |= 1u << j; c++; }
+    }
+  }
+  uint32_t tot, pos = tile_offset[blockIdx.x] + compact_block_scan(c, lds4, tot);
+#pragma unroll
+  for (uint32_t j = 0; j < COMPACT_PER_LANE; j++)
+    if (keep & (1u << j)) store_fr(&out[pos++], v[j]);
+}
+
 // out[i] = a[i] * w^i   (p(x) -> p(w x); prover.rs:661-674 monomial_z_to_z_omega)
 __global__ void __launch_bounds__(256) fr_scale_powers(const fr_t* __restrict__ a, size_t n, fr_t w, fr_t* __restrict__ out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -132,15 +132,7 @@ int squeeze_zeros(bp_ctx* ctx, fr_t* d_q, size_t* n) {
   size_t eff, nonzero;
   BP_TRY(fr_nonzero_stats_run(ctx, d_q, *n, 0, *n, &eff, &nonzero));
   if (nonzero == *n) return BP_OK;
-  std::vector<fr_t> h(*n);
-  BP_HIP(ctx, hipMemcpyAsync(h.data(), d_q, *n * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  size_t m = 0;
-  for (size_t i = 0; i < *n; i++)
-    if (!big_is_zero(h[i])) h[m++] = h[i];
-  if (m) BP_HIP(ctx, hipMemcpy(d_q, h.data(), m * sizeof(fr_t), hipMemcpyHostToDevice));
-  *n = m;
-  return BP_OK;
+  return fr_compact_nonzero_run(ctx, d_q, n);      // scan + scatter on the device: no proof path blocks on a host copy
 }
 
 // (numerator of na coefficients) / (x - point) -> d_q, *nq coefficients, by the reference's Div semantics

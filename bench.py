@@ -210,7 +210,8 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     ctl = None                                        # host-side group for object gathers and long waits
-    if world > 1:
+    use_dist = "WORLD_SIZE" in os.environ             # under a launcher even a single rank goes through the collectives
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
             ctl = dist.new_group(backend="gloo")
@@ -218,19 +219,19 @@ def main():
             dist.init_process_group(args.backend)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(vals):
-        if world == 1:
+        if not use_dist:
             return [float(v) for v in vals]
         t = torch.tensor(vals, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(v) for v in t]
 
     def gather_objects(obj):
-        if world == 1:
+        if not use_dist:
             return [obj]
         out = [None] * world
         dist.all_gather_object(out, obj, group=ctl)
@@ -243,7 +244,7 @@ def main():
         """W + K steps of: per-rank Pippenger on the resident shard, then (N > 1) the single all-gather of the ranks'
         records left in HBM + one D2H + combine (baby_plonk_rust_amd/dist.py ShardedMsm)"""
         def step():
-            if world == 1:
+            if not use_dist:
                 return bp.sum_partials(ctx.msm_partial(srs, None, device_ptr=d_scal.data_ptr(), n=n))
             return exchange(srs, device_ptr=d_scal.data_ptr(), n=n)
         for _ in range(warmup):
@@ -259,7 +260,7 @@ def main():
             exch.append(exchange.exchange_s * 1e3)
         barrier()
         return {"result": res, "elapsed": time.perf_counter() - t0, "acc_ms": float(np.mean(acc)), "dev_ms": float(np.mean(devt)),
-                "exchange_ms": float(np.mean(exch)) if world > 1 else 0.0, "stats": ctx.msm_stats()}
+                "exchange_ms": float(np.mean(exch)) if use_dist else 0.0, "stats": ctx.msm_stats()}
 
     def timed_ntt(d_vec, log_n, steps, warmup):
         for _ in range(warmup):
@@ -494,7 +495,7 @@ def main():
                        "msm_points_per_gpu": n, "window_bits": stats["window_bits"], "ntt_len_per_gpu": nn,
                        "srs_tables": {"used": stats["tables"], "window_bits": table_info["window_bits"], "windows": table_info["windows"],
                                       "bytes_per_gpu": table_info["bytes"], "build_s": table_build_s},
-                       "parallelism": "point-range x%d" % world, "ranks": world, "backend": args.backend if world > 1 else None},
+                       "parallelism": "point-range x%d" % world, "ranks": world, "backend": args.backend if use_dist else None},
             "roofline": hbm,
             "roofline_valu_issue": issue,
             "msm_device_ms": head["dev_ms"],
@@ -518,7 +519,7 @@ def main():
                                           if world == 1 else None)
             line["strong_scaling"] = {
                 "metric": "g1_msm_scalar_muls_per_s", "value": strong["total"] * k / strong_elapsed, "unit": "scalar-muls/s", "scaling": "strong",
-                "n_gpus": world, "rccl_ranks": world if args.backend == "nccl" else 0, "steps": k, "warmup": 2, "ms_per_step": 1e3 * strong_elapsed / k,
+                "n_gpus": world, "rccl_ranks": world if (use_dist and args.backend == "nccl") else 0, "steps": k, "warmup": 2, "ms_per_step": 1e3 * strong_elapsed / k,
                 "workload": "ONE 2^%d-point G1 MSM (BASELINE configs[3]), %d points per rank, SRS shards resident with tables; per step: "
                             "per-rank Pippenger, one all-gather of %d-byte records in HBM, one D2H, host combine"
                             % (args.strong_log_n, strong["m"], bp._lib.MSM_BLOB_BYTES),
@@ -550,7 +551,7 @@ def main():
         if world == 1 and not args.skip_cpu:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, min(64, os.cpu_count() or 1))
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier(group=ctl) if ctl is not None else dist.barrier()
         dist.destroy_process_group()
 

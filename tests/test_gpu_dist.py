@@ -90,3 +90,23 @@ def test_bench_refuses_more_ranks_than_gpus():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], capture_output=True,
                          text=True, timeout=300, cwd=ROOT, env=env)
     assert out.returncode == 2 and "--gpus %d" % (n + 1) in out.stderr and not out.stdout.strip()
+
+
+def test_bench_under_launcher_with_rccl_single_rank():
+    """one rank under torch.distributed.run with the RCCL backend: the exchange path of N > 1 (records all-gathered on the device by
+    RCCL, one D2H, combine; gloo side group for host gathers) really runs, with a world of one -- what a 1-GPU box can execute"""
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--log-n", "16", "--ntt-log-n", "16", "--strong-log-n", "17",
+           "--prove-log-n", "0", "--skip-cpu", "--skip-seams", "--other-sizes"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["backend"] == "nccl" and line["strong_scaling"]["rccl_ranks"] == 1
+    assert line["exchange_ms"] > 0 and line["strong_scaling"]["exchange_ms_per_rank"][0] > 0
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    one = subprocess.run([sys.executable] + cmd[10:], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    line1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert line1["result_sha"] == line["result_sha"] and line1["strong_scaling"]["result_sha"] == line["strong_scaling"]["result_sha"]
+    assert line1["config"]["backend"] is None

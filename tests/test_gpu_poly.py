@@ -158,3 +158,43 @@ def test_canonical_byte_format_paths(ctx):
     # a non-canonical scalar argument is rejected
     bad = np.frombuffer((Q + 1).to_bytes(32, "little"), dtype=np.uint8).copy()
     assert lib.bp_poly_evaluate(h, A.ctypes.data, 7, MONO, bad.ctypes.data, bp.FR_BYTES_LE, r.ctypes.data) == -4
+
+
+def test_division_2p16_against_the_committed_oracle_hashes():
+    """Polynomial / Polynomial (polynomial.rs:314-380) on 2^16 + 11 coefficients by x^n - 1 (n = 2^14, the round-3 shape) and by
+    x - zeta (the round-5 shape): sha256 of the quotient limbs recorded by the CPU oracle (tests/golden/make_large_vectors.py);
+    host-pointer and HBM-resident entry points"""
+    import hashlib
+    import json
+    import os
+    from tests import prover_rounds as PR
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "large_vectors.json")))["division"]
+    n, zeta = rec["n"], int(rec["zeta"], 16)
+    a = O.splitmix_scalars((1 << 16) + 11, 0xD1F1)
+    zh = PR.sparse(n + 1, {0: Q - 1, n: 1})
+    lin = PR.sparse(2, {0: Q - zeta, 1: 1})
+    for divisor, key in ((zh, "by_xn_minus_1"), (lin, "by_x_minus_zeta")):
+        q = bp.Polynomial(a, bp.BASIS_MONOMIAL) / bp.Polynomial(divisor, bp.BASIS_MONOMIAL)
+        assert len(q) == rec[key]["len"] and hashlib.sha256(q.values.tobytes()).hexdigest() == rec[key]["sha256"], key
+        qd = bp.DevicePolynomial(a, bp.BASIS_MONOMIAL) / bp.DevicePolynomial(divisor, bp.BASIS_MONOMIAL)
+        assert hashlib.sha256(np.ascontiguousarray(qd.values).tobytes()).hexdigest() == rec[key]["sha256"], key
+
+
+def test_device_division_squeezes_zero_coefficients_at_size():
+    """the reference's Div drops zero quotient coefficients (polynomial.rs:371-376); on HBM-resident operands the compaction is a
+    device scan + scatter (no host round trip): a quotient of 70 001 coefficients with zeros at the ends, across tile edges and in
+    a long run comes back with exactly those removed, in order"""
+    nq, zeta = 70001, 0x5A5A5A5A1234567 % Q
+    q = O.splitmix_scalars(nq, 0xC0FFEE)
+    zero_at = [0, 1, 2047, 2048, 2049, 4096, 40000, nq - 2] + list(range(10000, 10300))
+    q[zero_at] = 0
+    assert not (q[nq - 1] == 0).all()
+    lin = np.stack([bp.scalar_from_int(Q - zeta), bp.scalar_from_int(1)])
+    qd, bd = bp.DevicePolynomial(q, bp.BASIS_MONOMIAL), bp.DevicePolynomial(lin, bp.BASIS_MONOMIAL)
+    a = qd * bd                                             # exact product: a / (x - zeta) == q
+    got = (a / bd).values
+    keep = np.ones(nq, dtype=bool)
+    keep[zero_at] = False
+    assert got.shape == (int(keep.sum()), 4) and (got == q[keep]).all()
+    host = bp.Polynomial(a.values, bp.BASIS_MONOMIAL) / bp.Polynomial(lin, bp.BASIS_MONOMIAL)
+    assert (host.values == got).all()
