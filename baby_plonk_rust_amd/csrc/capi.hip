@@ -544,8 +544,8 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
       c = lg > 8 ? lg - 4 : 4;        // reduction tree has c - 1 levels -- measured optimum 2^10: 6, 2^12: 8
     }
   }
-  if (c != BP_SRS_TABLES_OFF && (c < 4 || c > 16))
-    return fail(ctx, BP_ERR_INVALID_ARG, "window_bits must be 0 (auto), 1 (off) or 4..16", hipSuccess, __FILE__, __LINE__);
+  if (c != BP_SRS_TABLES_OFF && (c < 4 || c > 24))
+    return fail(ctx, BP_ERR_INVALID_ARG, "window_bits must be 0 (auto), 1 (off) or 4..24", hipSuccess, __FILE__, __LINE__);
   const std::vector<bp_ctx*> sh = shards_of(ctx);
   const std::vector<uint64_t> hs = lead->member_handle;
   for (size_t r = 0; r < sh.size(); r++) BP_TRY(lift(ctx, sh[r], srs_precompute_one(sh[r], hs.empty() ? srs_handle : hs[r], c)));

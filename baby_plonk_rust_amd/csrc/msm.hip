@@ -19,8 +19,9 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
   return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
-// Window width: minimise W * (n + 2 * 2^(c-1)) (bucket adds + reduction adds), bounded by the int16 digit
-// array and by the 128 KiB LDS histogram (c <= 16).
+// Window width: minimise W * (n + 2 * 2^(c-1)) (bucket adds + reduction adds).  Per-window bucket sets (any point set) are
+// bounded by the 128 KiB LDS histogram of one window (c <= 16); with fixed-base tables wider windows go through the
+// partitioned sort (plan.parts > 1), up to MSM_MAX_TABLE_C.
 // table_c != 0: the SRS carries fixed-base window tables built for that width (row length table_stride)
 static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_stride) {
   memset(&plan, 0, sizeof plan);
@@ -29,9 +30,9 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   if (c < 4) c = 4;
   if (c > MSM_MAX_C) c = MSM_MAX_C;
   c = env_u32("BP_MSM_C", c);
-  if (table_c) c = table_c;
+  if (c > (uint32_t)MSM_MAX_C) c = MSM_MAX_C;          // per-window bucket sets: one LDS histogram per window
+  if (table_c) c = table_c;                          // tables: up to MSM_MAX_TABLE_C through the partitioned sort
   if (c < 2) c = 2;
-  if (c > MSM_MAX_C) c = MSM_MAX_C;
   // digits d_w = ((k + bias) >> c*w & mask) - 2^(c-1) with bias = sum_w 2^(c-1) 2^(cw); needs k + bias < 2^(cW)
   // for every k < q.  Take W = ceil(256 / c) and check the bound with the real q; add a window if it fails.
   static const uint32_t q_minus_1[8] = {0x00000000u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
@@ -75,6 +76,17 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   plan.total = table_c ? plan.B : W * plan.B;
   plan.wbuckets = table_c ? 0 : plan.B;
   plan.wpoints = table_c ? (uint32_t)table_stride : 0;
+  plan.hist = plan.B < (1u << MSM_HIST_LOG) ? plan.B : 1u << MSM_HIST_LOG;
+  plan.parts = plan.B / plan.hist;
+  plan.wide = c > 16;
+  // record kernels: ~32 Ki records per workgroup, at least ~256 workgroups in all
+  {
+    uint64_t per_run = n / plan.parts + 1;
+    uint32_t rs = (uint32_t)(per_run >> 15), lo_rs = 256 / (W * plan.parts) + 1;
+    if (rs < lo_rs) rs = lo_rs;
+    while (rs > 1 && per_run / rs < 1024) rs >>= 1;
+    plan.rslices = env_u32("BP_MSM_RSLICES", rs);
+  }
   const uint64_t entries = (uint64_t)W * n;
   uint32_t chunk = 4;
   // tables: B buckets hold all W * n entries, so chunks grow with n to keep ~8 partial runs per bucket for the fix-up
@@ -179,10 +191,10 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   const uint32_t blocks_per_window = table_c ? 1u << l2 : ((B + plan.seg - 1) / plan.seg + 255) / 256;
   const uint32_t per_block = table_c ? l1 + 1 : 1, per_window = table_c ? plan.c : 1;     // slots
 
-  int16_t* digits;
+  void* digits;
   uint32_t *counts, *offsets, *cursors, *sorted;
   proj28_slot *bucket_sum, *partial, *block_out, *window_sum;
-  BP_TRY(ws_get(ctx, "msm.digits", max_entries * sizeof(int16_t), (void**)&digits));
+  BP_TRY(ws_get(ctx, "msm.digits", max_entries * (plan.wide ? sizeof(int32_t) : sizeof(int16_t)), &digits));
   BP_TRY(ws_get(ctx, "msm.counts", (size_t)total * 4 + 8, (void**)&counts));       // + [0] long-bucket counter, [1] scalar status: one memset
   BP_TRY(ws_get(ctx, "msm.offsets", ((size_t)total + 1) * 4, (void**)&offsets));
   BP_TRY(ws_get(ctx, "msm.cursors", (size_t)total * 4, (void**)&cursors));
@@ -205,19 +217,48 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   uint8_t* h_base;
   BP_TRY(pinned_get(ctx, MSM_SLOTS * slot_bytes, (void**)&h_base));
   proj28_slot* h_windows = reinterpret_cast<proj28_slot*>(h_base + (size_t)slot * slot_bytes);
+  // wide windows: partition workspaces
+  const uint32_t n_runs = W * plan.parts;
+  uint32_t *part_cnt = nullptr, *part_off = nullptr, *part_cur = nullptr, *rec_idx = nullptr;
+  uint16_t* rec_lo = nullptr;
+  if (plan.parts > 1) {
+    BP_TRY(ws_get(ctx, "msm.part_cnt", (size_t)n_runs * 4, (void**)&part_cnt));
+    BP_TRY(ws_get(ctx, "msm.part_off", ((size_t)n_runs + 1) * 4, (void**)&part_off));
+    BP_TRY(ws_get(ctx, "msm.part_cur", (size_t)n_runs * 4, (void**)&part_cur));
+    BP_TRY(ws_get(ctx, "msm.rec_idx", max_entries * 4, (void**)&rec_idx));
+    BP_TRY(ws_get(ctx, "msm.rec_lo", max_entries * 2, (void**)&rec_lo));
+  }
 
   hipStream_t st = ctx->stream;
   BP_HIP(ctx, hipEventRecord(ctx->ev[0], st));
   BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4 + 8, st));
   hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits, long_count + 1);
-  const size_t hist_bytes = (size_t)B * 4;
-  const unsigned hist_threads = B >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
-  hipLaunchKernelGGL(msm_count, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, digits, plan, counts);
+  const size_t hist_bytes = (size_t)plan.hist * 4;
+  const unsigned hist_threads = plan.hist >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
   const uint32_t n_tiles = (total + SCAN_TILE - 1) / SCAN_TILE;      // <= 4096 (total <= 2^24)
-  hipLaunchKernelGGL(scan_tile_sums, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums);
-  hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(256), 0, st, tile_sums, n_tiles, offsets + total);
-  hipLaunchKernelGGL(scan_apply, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums, offsets, cursors);
-  hipLaunchKernelGGL(msm_scatter, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, digits, plan, cursors, sorted);
+  if (plan.parts == 1) {
+    hipLaunchKernelGGL(msm_count, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, (const int16_t*)digits, plan, counts);
+    hipLaunchKernelGGL(scan_tile_sums, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums);
+    hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(256), 0, st, tile_sums, n_tiles, offsets + total);
+    hipLaunchKernelGGL(scan_apply, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums, offsets, cursors);
+    hipLaunchKernelGGL(msm_scatter, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, (const int16_t*)digits, plan, cursors, sorted);
+  } else {
+    // partition every window's digits by the high bucket bits, then the counting sort per (window, part) run
+    const dim3 pgrid((unsigned)((n + PART_SLICE - 1) / PART_SLICE), W);
+    const uint32_t run_tiles = (n_runs + SCAN_TILE - 1) / SCAN_TILE;
+    BP_HIP(ctx, hipMemsetAsync(part_cnt, 0, (size_t)n_runs * 4, st));
+    hipLaunchKernelGGL(msm_part_count, pgrid, dim3(1024), 0, st, (const int32_t*)digits, plan, part_cnt);
+    hipLaunchKernelGGL(scan_tile_sums, dim3(run_tiles), dim3(256), 0, st, part_cnt, n_runs, tile_sums);
+    hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(256), 0, st, tile_sums, run_tiles, part_off + n_runs);
+    hipLaunchKernelGGL(scan_apply, dim3(run_tiles), dim3(256), 0, st, part_cnt, n_runs, tile_sums, part_off, part_cur);
+    hipLaunchKernelGGL(msm_part_scatter, pgrid, dim3(1024), 0, st, (const int32_t*)digits, plan, part_cur, rec_idx, rec_lo);
+    const dim3 rgrid(plan.rslices, n_runs);
+    hipLaunchKernelGGL(msm_count_rec, rgrid, dim3(1024), hist_bytes, st, rec_lo, part_off, plan, counts);
+    hipLaunchKernelGGL(scan_tile_sums, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums);
+    hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(256), 0, st, tile_sums, n_tiles, offsets + total);
+    hipLaunchKernelGGL(scan_apply, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums, offsets, cursors);
+    hipLaunchKernelGGL(msm_scatter_rec, rgrid, dim3(1024), hist_bytes, st, rec_idx, rec_lo, part_off, plan, cursors, sorted);
+  }
   BP_HIP(ctx, hipEventRecord(ctx->ev[1], st));
   const dim3 acc_grid((unsigned)((n_chunks + 255) / 256));
   switch (env_u32("BP_MSM_ACC_WAVES", 2)) {
@@ -237,8 +278,26 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   if (table_c) {
     hipLaunchKernelGGL(msm_planes_block, dim3(blocks_per_window, Wr), dim3(256), 512 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
                        l1, block_out);
-    hipLaunchKernelGGL(msm_planes_window, dim3(l1 + 1, Wr), dim3(128), 256 * sizeof(proj28_slot), st, block_out, l1, l2, window_sum,
-                       long_count + 1, offsets + total, reinterpret_cast<uint32_t*>(window_sum + n_planes));
+    // merge steps of at most 7 levels each until one node (A and the c - 1 planes) is left; c <= 16 needs one
+    uint32_t k = l1, r = l2;
+    const proj28_slot* in = block_out;
+    proj28_slot* tmp[2] = {nullptr, nullptr};
+    if (r > 7) {
+      BP_TRY(ws_get(ctx, "msm.planes_tmp0", ((size_t)1 << (r - 7)) * (k + 8) * sizeof(proj28_slot), (void**)&tmp[0]));
+      if (r > 14) BP_TRY(ws_get(ctx, "msm.planes_tmp1", ((size_t)1 << (r - 14)) * (k + 15) * sizeof(proj28_slot), (void**)&tmp[1]));
+    }
+    int flip = 0;
+    do {
+      const uint32_t m = r < 7 ? r : 7, nodes = 1u << (r - m);
+      const bool last = r == m;
+      proj28_slot* out_nodes = last ? window_sum : tmp[flip];
+      hipLaunchKernelGGL(msm_planes_window, dim3(k + 1, nodes), dim3(128), 256 * sizeof(proj28_slot), st, in, k, m, out_nodes, long_count + 1,
+                         offsets + total, last ? reinterpret_cast<uint32_t*>(window_sum + n_planes) : (uint32_t*)nullptr);
+      in = out_nodes;
+      flip ^= 1;
+      k += m;
+      r -= m;
+    } while (r > 0);
   } else {
     hipLaunchKernelGGL(msm_reduce, dim3(blocks_per_window, Wr), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
                        block_out);

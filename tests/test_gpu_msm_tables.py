@@ -181,3 +181,40 @@ def test_full_size_2p24_closed_form_both_paths(ctx):
     parts = b"".join(ctx.msm_partial(h, None, first=r * per, device_ptr=t.data_ptr() + 32 * r * per, n=per) for r in range(8))
     assert bp.sum_partials(parts) == want
     ctx.srs_free(h)
+
+
+@pytest.mark.parametrize("c,log_n", [(17, 14), (18, 15), (19, 16), (20, 17), (21, 18), (22, 19), (24, 21)])
+def test_windows_wider_than_16_bits(ctx, c, log_n):
+    """fixed-base tables with c > 16: one window's 2^(c-1) buckets exceed the LDS histogram, so the digits are partitioned by
+    the high bucket bits first (msm_part_*), sorted per (window, part), and the bit-plane tree takes extra merge steps.
+    Same bytes as the closed form and as the c <= 16 paths; every table row probed on its own; skewed and edge scalars."""
+    n, a, d = (1 << log_n) + 13, Q - 98765, 0x0F1E2D3C4B5A6978
+    h = ctx.srs_generate_progression(n, a, d)
+    sc = O.splitmix_scalars(n, 0x5EED0000 + c)
+    want = M.enc96(M.ec_mul(oracle_dot(sc, a, d)))
+    assert ctx.msm(h, sc) == want and not ctx.msm_stats()["tables"]
+    info = ctx.srs_precompute(h, c)
+    assert info["window_bits"] == c and info["windows"] == {17: 15, 18: 15, 19: 14, 20: 13, 21: 13, 22: 12, 24: 11}[c]
+    assert ctx.msm(h, sc) == want
+    st = ctx.msm_stats()
+    assert st["tables"] and st["window_bits"] == c and 0 < st["mixed_adds"] <= info["windows"] * n
+    # a prefix and an offset range (zip truncation / shards) through the same tables
+    assert bp.sum_partials(ctx.msm_partial(h, sc[: n // 2 + 3])) == M.enc96(M.ec_mul(oracle_dot(sc[: n // 2 + 3], a, d)))
+    assert bp.sum_partials(ctx.msm_partial(h, sc[: n - 101], first=101)) == M.enc96(M.ec_mul(oracle_dot(sc[: n - 101], a + 101 * d, d)))
+    # every row of the tables alone
+    for w in range(info["windows"]):
+        if c * w >= 255:
+            break
+        one_hot = np.zeros((n, 4), dtype=np.uint64)
+        j = (977 * (w + 1)) % n
+        one_hot[j] = bp.scalar_from_int(1 << (c * w))
+        assert ctx.msm(h, one_hot) == M.enc96(M.ec_mul(((a + j * d) << (c * w)) % Q)), w
+    # edge scalars: q - 1 (top digit, sign carries through every window), 1, 0, all equal (one bucket per window, the long fix-up)
+    for val in (Q - 1, 1, 0, 0x123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF % Q):
+        same = np.tile(bp.scalar_from_int(val), (n, 1))
+        k = val * ((n * a + d * (n * (n - 1) // 2)) % Q) % Q
+        assert ctx.msm(h, same) == M.enc96(M.ec_mul(k)), hex(val)
+    small = bp.scalars_from_ints([(i * 7919) % 65536 for i in range(n)]) if n <= (1 << 16) + 13 else None
+    if small is not None:                                       # 16-bit witness-like values: only the low windows are populated
+        assert ctx.msm(h, small) == M.enc96(M.ec_mul(oracle_dot(small, a, d)))
+    ctx.srs_free(h)
