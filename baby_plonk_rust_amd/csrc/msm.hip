@@ -88,9 +88,14 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
     plan.rslices = env_u32("BP_MSM_RSLICES", rs);
   }
   const uint64_t entries = (uint64_t)W * n;
-  uint32_t chunk = 4;
-  // tables: B buckets hold all W * n entries, so chunks grow with n to keep ~8 partial runs per bucket for the fix-up
-  while (chunk < (table_c ? 1024u : 64u) && entries / chunk > 262144) chunk <<= 1;
+  // entries per lane: the kernel runs 2 waves per SIMD = 131072 lanes at a time and every lane does the same work, so the
+  // lane count should land just under a whole number of such rounds -- 262144 lanes = two rounds.  (A power-of-two chunk
+  // wasted up to a third of the second round whenever windows * n was not a power of two: 13 or 15 windows.)
+  // tables: B buckets hold all W * n entries, so chunks grow with n; per-window buckets are short, cap the chunk at 64.
+  uint32_t chunk = (uint32_t)((entries + 262143) / 262144);
+  const uint32_t chunk_cap = table_c ? 1024u : 64u;
+  if (chunk < 4) chunk = 4;
+  if (chunk > chunk_cap) chunk = chunk_cap;
   plan.chunk = env_u32("BP_MSM_CHUNK", chunk);
   // count/scatter workgroups per window: each flushes its whole LDS histogram with global atomics, so fewer, fatter
   // slices are cheaper (~32 Ki points each) as long as >= 256 workgroups remain to fill the CUs (measured: 2^16, 2^20, 2^24)

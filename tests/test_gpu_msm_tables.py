@@ -98,7 +98,9 @@ def test_degenerate_srs_with_tables(ctx):
     assert ctx.msm(hh, frs([99, 99])) == M.enc96(None)       # P and -P cancel in every table row
     assert ctx.msm(hh, frs([Q - 1, 3])) == M.enc96(M.ec_mul((5 * (Q - 1) - 15) % Q))
     with pytest.raises(bp.BpError):
-        ctx.srs_precompute(hh, 17)
+        ctx.srs_precompute(hh, 25)                            # widths are 4..24
+    with pytest.raises(bp.BpError):
+        ctx.srs_precompute(hh, 3)
     with pytest.raises(bp.BpError):
         ctx.srs_precompute(987654321, 0)
     ctx.srs_free(hh)
@@ -194,7 +196,7 @@ def test_windows_wider_than_16_bits(ctx, c, log_n):
     want = M.enc96(M.ec_mul(oracle_dot(sc, a, d)))
     assert ctx.msm(h, sc) == want and not ctx.msm_stats()["tables"]
     info = ctx.srs_precompute(h, c)
-    assert info["window_bits"] == c and info["windows"] == {17: 15, 18: 15, 19: 14, 20: 13, 21: 13, 22: 12, 24: 11}[c]
+    assert info["window_bits"] == c and info["windows"] == {17: 16, 18: 15, 19: 14, 20: 13, 21: 13, 22: 12, 24: 11}[c]
     assert ctx.msm(h, sc) == want
     st = ctx.msm_stats()
     assert st["tables"] and st["window_bits"] == c and 0 < st["mixed_adds"] <= info["windows"] * n
