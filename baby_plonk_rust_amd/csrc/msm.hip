@@ -81,10 +81,12 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   plan.wide = c > 16;
   // record kernels: ~32 Ki records per workgroup, at least ~256 workgroups in all
   {
-    uint64_t per_run = n / plan.parts + 1;
-    uint32_t rs = (uint32_t)(per_run >> 15), lo_rs = 256 / (W * plan.parts) + 1;
-    if (rs < lo_rs) rs = lo_rs;
-    while (rs > 1 && per_run / rs < 1024) rs >>= 1;
+    // every workgroup flushes and reserves its whole 2^15-bucket histogram with global atomics, so few, fat workgroups:
+    // about 1024 in all, none below ~128 Ki records unless the runs are shorter than that
+    const uint64_t per_run = n / plan.parts + 1;
+    uint32_t rs = 1024 / (W * plan.parts), by_len = (uint32_t)(per_run >> 17);
+    if (rs > by_len) rs = by_len;
+    if (rs < 1) rs = 1;
     plan.rslices = env_u32("BP_MSM_RSLICES", rs);
   }
   const uint64_t entries = (uint64_t)W * n;
@@ -160,7 +162,8 @@ static g1_proj slot_to_proj(const proj28_slot* slot) {
 // dynamic-LDS limits are per function AND per device: set them for every context at creation (bp_init), after hipSetDevice
 int msm_init_device(bp_ctx* ctx) {
   // a full-window histogram at c = 16 needs 128 KiB of dynamic LDS, the plane tree 88 KiB
-  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_planes_block, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_planes_block<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_planes_block<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_count, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return BP_OK;
@@ -192,7 +195,8 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   const uint64_t max_entries = (uint64_t)W * n;
   const uint64_t n_chunks = (max_entries + plan.chunk - 1) / plan.chunk;
   // bucket reduction: running sums per window, or (tables: one bucket set) the bit-plane tree in two stages of l1 + l2 levels
-  const uint32_t l1 = plan.c - 1 < PLANES_BLOCK_LOG ? plan.c - 1 : PLANES_BLOCK_LOG, l2 = plan.c - 1 - l1;
+  const uint32_t planes_log = env_u32("BP_MSM_PLANES_LOG", plan.c > 16 ? 7 : PLANES_BLOCK_LOG) == 7 ? 7 : PLANES_BLOCK_LOG;
+  const uint32_t l1 = plan.c - 1 < planes_log ? plan.c - 1 : planes_log, l2 = plan.c - 1 - l1;
   const uint32_t blocks_per_window = table_c ? 1u << l2 : ((B + plan.seg - 1) / plan.seg + 255) / 256;
   const uint32_t per_block = table_c ? l1 + 1 : 1, per_window = table_c ? plan.c : 1;     // slots
 
@@ -281,8 +285,12 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   hipLaunchKernelGGL(msm_fixup_long, dim3(1024), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
                      long_count, long_list, long_cap);
   if (table_c) {
-    hipLaunchKernelGGL(msm_planes_block, dim3(blocks_per_window, Wr), dim3(256), 512 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
-                       l1, block_out);
+    if (planes_log == 7)
+      hipLaunchKernelGGL((msm_planes_block<128, 2>), dim3(blocks_per_window, Wr), dim3(128), 256 * sizeof(proj28_slot), st, offsets, plan,
+                         bucket_sum, l1, block_out);
+    else
+      hipLaunchKernelGGL((msm_planes_block<256, 1>), dim3(blocks_per_window, Wr), dim3(256), 512 * sizeof(proj28_slot), st, offsets, plan,
+                         bucket_sum, l1, block_out);
     // merge steps of at most 7 levels each until one node (A and the c - 1 planes) is left; c <= 16 needs one
     uint32_t k = l1, r = l2;
     const proj28_slot* in = block_out;

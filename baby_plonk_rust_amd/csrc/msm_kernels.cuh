@@ -761,8 +761,11 @@ __device__ __forceinline__ proj28_slot* planes_tree(proj28_slot* cur, proj28_slo
   return cur;
 }
 
-// grid (B >> l1, windows), 2^l1 <= 256 lanes used.  out[(w * gridDim.x + block) * (l1 + 1) + v]
-__global__ void __launch_bounds__(256, 1)
+// grid (B >> l1, windows), 2^l1 lanes used, LDS = two arrays of 2^l1 slots.  out[(w * gridDim.x + block) * (l1 + 1) + v]
+// Two builds: 256 lanes / 2^8 buckets / one wave per SIMD (c <= 16: few blocks, the dependent chain is what counts), and
+// 128 lanes / 2^7 buckets / two waves per SIMD (wide windows: thousands of blocks, three to four of them share a CU).
+template <int THREADS, int WAVES>
+__global__ void __launch_bounds__(THREADS, WAVES)
 msm_planes_block(const uint32_t* __restrict__ offsets, MsmPlan plan, const proj28_slot* __restrict__ bucket_sum, uint32_t l1,
                  proj28_slot* __restrict__ out) {
   proj28_slot* buf = reinterpret_cast<proj28_slot*>(msm_lds_tree);
@@ -773,7 +776,7 @@ msm_planes_block(const uint32_t* __restrict__ offsets, MsmPlan plan, const proj2
     store_proj28(&buf[threadIdx.x], s);
   }
   __syncthreads();
-  const proj28_slot* root = planes_tree(buf, buf + 256, l1, true);
+  const proj28_slot* root = planes_tree(buf, buf + nb, l1, true);
   if (threadIdx.x <= l1) out[((size_t)w * gridDim.x + blockIdx.x) * (l1 + 1) + threadIdx.x] = root[threadIdx.x];
 }
 
