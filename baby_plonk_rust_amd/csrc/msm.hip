@@ -81,12 +81,13 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   plan.wide = c > 16;
   // record kernels: ~32 Ki records per workgroup, at least ~256 workgroups in all
   {
-    // every workgroup flushes and reserves its whole 2^15-bucket histogram with global atomics, so few, fat workgroups:
-    // about 1024 in all, none below ~128 Ki records unless the runs are shorter than that
+    // ~32 Ki records per workgroup, at least ~256 workgroups in all.  (Measured: one fat workgroup per run -- 262 144 records
+    // each at 2^24, c = 22 -- is 4-5x SLOWER per record: the 256 resident workgroups then stream from addresses exactly
+    // 2^19 records apart in lock step and camp on the same HBM channels.)
     const uint64_t per_run = n / plan.parts + 1;
-    uint32_t rs = 1024 / (W * plan.parts), by_len = (uint32_t)(per_run >> 17);
-    if (rs > by_len) rs = by_len;
-    if (rs < 1) rs = 1;
+    uint32_t rs = (uint32_t)(per_run >> 15), lo_rs = 256 / (W * plan.parts) + 1;
+    if (rs < lo_rs) rs = lo_rs;
+    while (rs > 1 && per_run / rs < 1024) rs >>= 1;
     plan.rslices = env_u32("BP_MSM_RSLICES", rs);
   }
   const uint64_t entries = (uint64_t)W * n;
