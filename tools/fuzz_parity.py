@@ -24,6 +24,7 @@ ap.add_argument("--seed", type=int, default=1)
 args = ap.parse_args()
 rnd = random.Random(args.seed)
 ctx = bp.default_context()
+group = bp.Context([0, 0, 0])          # the same library calls through a three-shard context (bp_init_multi) on this one card
 t_end = time.time() + args.seconds
 counts = {"msm": 0, "ntt": 0, "poly": 0}
 
@@ -48,28 +49,32 @@ def scalars(n, kind):
 while time.time() < t_end:
     which = rnd.choice(["msm", "msm", "ntt", "poly"])
     if which == "msm":
-        n = rnd.choice([rnd.randrange(1, 40), rnd.randrange(1, 3000), rnd.randrange(1, 70000)])
+        n = rnd.choice([rnd.randrange(1, 40), rnd.randrange(1, 3000), rnd.randrange(1, 70000), rnd.randrange(60000, 300000)])
         a, d = rnd.randrange(Q), rnd.randrange(Q)
         srs_len = n + rnd.choice([0, 0, 3, 100])
+        c = ctx if rnd.random() < 0.7 else group
+        ctx_single, ctx = ctx, c
         h = ctx.srs_generate_progression(srs_len, a, d)
         mode = rnd.choice(["plain", "tables", "tables"])
         c_plain = rnd.choice([None, 4, 7, 10, 13, 16])
-        if mode == "tables":
-            ctx.srs_precompute(h, rnd.choice([0, 0, 4, 6, 9, 12, 15, 16]))
+        if mode == "tables":        # widths above 16 take the partitioned sort (only when 8 n >= 2^width, else the plain path answers)
+            ctx.srs_precompute(h, rnd.choice([0, 0, 4, 6, 9, 12, 15, 16, 17, 18, 19, 20]))
         os.environ.pop("BP_MSM_C", None)
         if c_plain:
             os.environ["BP_MSM_C"] = str(c_plain)
-        os.environ["BP_MSM_CHUNK"] = str(rnd.choice([4, 8, 16, 32, 64]))
+        if rnd.random() < 0.6:
+            os.environ["BP_MSM_CHUNK"] = str(rnd.choice([4, 5, 8, 13, 16, 32, 61, 64]))
         kind = rnd.choice(["random", "small", "equal", "sparse", "edges"])
         sc = scalars(n, kind)
         first = rnd.randrange(0, srs_len - n + 1) if rnd.random() < 0.3 else 0
         got = bp.sum_partials(ctx.msm_partial(h, sc, first=first))
         want = M.enc96(M.ec_mul(oracle_dot(sc, (a + first * d) % Q, d)))
         if got != want:
-            print("MSM MISMATCH", dict(n=n, srs_len=srs_len, mode=mode, c_plain=c_plain, chunk=os.environ["BP_MSM_CHUNK"], kind=kind, first=first,
-                                        table=ctx.srs_table_info(h), a=a, d=d, seed=args.seed))
+            print("MSM MISMATCH", dict(n=n, srs_len=srs_len, mode=mode, c_plain=c_plain, chunk=os.environ.get("BP_MSM_CHUNK"), kind=kind, first=first,
+                                        table=ctx.srs_table_info(h), a=a, d=d, seed=args.seed, shards=ctx.n_shards()))
             sys.exit(1)
         ctx.srs_free(h)
+        ctx = ctx_single
         os.environ.pop("BP_MSM_C", None)
         os.environ.pop("BP_MSM_CHUNK", None)
     elif which == "ntt":
