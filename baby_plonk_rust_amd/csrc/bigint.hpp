@@ -1,4 +1,4 @@
-// bigint.cuh -- fixed-width multi-limb arithmetic on 32-bit limbs for gfx950.
+// bigint.hpp -- fixed-width multi-limb arithmetic on 32-bit limbs for gfx950.
 //
 // Representation: little-endian 32-bit limbs.  A field element is the SAME bit pattern as the
 // reference's 64-bit-limb Montgomery value (lib/bls12_381/src/scalar.rs:16-22, fp.rs:11-15)

@@ -8,8 +8,8 @@
 #include <vector>
 
 #include "../../include/bp_msm_ntt.h"
-#include "g1.cuh"
-#include "g1_28.cuh"
+#include "g1.hpp"
+#include "g1_28.hpp"
 
 namespace bp {
 
@@ -45,7 +45,7 @@ struct CircuitEntry {
 };
 
 struct tw29_t;
-struct NttTables {       // per (log_n, inverse); entries are 48-byte 29-bit-limb twiddle records (fr29.cuh)
+struct NttTables {       // per (log_n, inverse); entries are 48-byte 29-bit-limb twiddle records (fr29.hpp)
   tw29_t* lo = nullptr;        // w_N^j, j < 2^h
   tw29_t* hi = nullptr;        // w_N^(j << h), j < 2^(k-h)
   tw29_t* hi_scaled = nullptr; // hi * N^-1 (inverse transforms, first pass)
@@ -131,7 +131,7 @@ struct MsmPending {
   uint64_t adds = 0;
   const void* h_windows = nullptr;      // pinned: n_planes accumulator slots + the status word
 };
-// d_blob != nullptr: the result stays in HBM as a BP_MSM_BLOB_BYTES record (msm_kernels.cuh) instead of the pinned slot
+// d_blob != nullptr: the result stays in HBM as a BP_MSM_BLOB_BYTES record (msm_kernels.hpp) instead of the pinned slot
 int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
                int slot, void* d_blob, MsmPending* out);
 int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out);

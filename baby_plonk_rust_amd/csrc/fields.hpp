@@ -1,9 +1,9 @@
-// fields.cuh -- the two BLS12-381 prime fields as parameter packs for bigint.cuh.
+// fields.hpp -- the two BLS12-381 prime fields as parameter packs for bigint.hpp.
 //   Fr : scalar field, 8 x 32-bit limbs,  Montgomery R = 2^256  (lib/bls12_381/src/scalar.rs:83-221)
 //   Fp : base field,  12 x 32-bit limbs,  Montgomery R = 2^384  (lib/bls12_381/src/fp.rs:70-110)
 // The 32-bit limb tables are the reference's 64-bit constants split in halves.
 #pragma once
-#include "bigint.cuh"
+#include "bigint.hpp"
 
 namespace bp {
 

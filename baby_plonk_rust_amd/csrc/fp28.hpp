@@ -1,4 +1,4 @@
-// fp28.cuh -- BLS12-381 base field in an UNSATURATED radix for the MSM hot loop: 14 limbs x 28 bits in
+// fp28.hpp -- BLS12-381 base field in an UNSATURATED radix for the MSM hot loop: 14 limbs x 28 bits in
 // u32 registers, Montgomery radix R' = 2^392.
 //
 // Why (measured on MI355X, profiles/r01_ubench_int_issue_rates.txt): v_mad_u64_u32 issues at the same rate
@@ -14,7 +14,7 @@
 // no u64 column overflow in mul, subtrahend covered limb-by-limb by the added multiple of p).  A kernel that
 // compiles cannot overflow.
 #pragma once
-#include "fields.cuh"
+#include "fields.hpp"
 
 namespace bp {
 

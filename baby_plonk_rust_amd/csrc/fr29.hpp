@@ -1,6 +1,6 @@
-// fr29.cuh -- BLS12-381 scalar field in an unsaturated radix for the NTT butterflies: 9 limbs x 29 bits.
+// fr29.hpp -- BLS12-381 scalar field in an unsaturated radix for the NTT butterflies: 9 limbs x 29 bits.
 //
-// Same reasoning as fp28.cuh (v_mad_u64_u32 issues like an add, so carries cost as much as products): with
+// Same reasoning as fp28.hpp (v_mad_u64_u32 issues like an add, so carries cost as much as products): with
 // 29-bit limbs a column of 9 + 9 products fits a 64-bit accumulator, one v_mad_u64_u32 per product from plain
 // C, no carry instructions.
 //
@@ -15,7 +15,7 @@
 //   diff: u - v + 4q (limb-wise, 4q in a spread form that dominates v's limbs), then * w -> < 2q, normalised
 //         Montgomery output bound: (6q * q) / 2^261 + q < 2q since 2^261 / q > 2^6.
 #pragma once
-#include "fields.cuh"
+#include "fields.hpp"
 
 namespace bp {
 

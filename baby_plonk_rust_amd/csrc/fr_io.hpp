@@ -1,6 +1,6 @@
-// fr_io.cuh -- 16-byte-vector global loads/stores of Fr elements (32 B = 2 x dwordx4 per lane).
+// fr_io.hpp -- 16-byte-vector global loads/stores of Fr elements (32 B = 2 x dwordx4 per lane).
 #pragma once
-#include "fields.cuh"
+#include "fields.hpp"
 
 namespace bp {
 

@@ -1,4 +1,4 @@
-// g1.cuh -- BLS12-381 G1 on y^2 = x^3 + 4 with the complete homogeneous-projective formulas of
+// g1.hpp -- BLS12-381 G1 on y^2 = x^3 + 4 with the complete homogeneous-projective formulas of
 // Renes-Costello-Batina (eprint 2015/1060), the same formulas the reference uses
 // (lib/bls12_381/src/g1.rs:638-752).  Complete formulas are branch-free: identity inputs, P+P and
 // P+(-P) need no special cases, which is what a 64-lane wavefront wants (SURVEY.md section 7,
@@ -8,7 +8,7 @@
 // stored as x = y = 0 (not on the curve, so unambiguous).  Projective = x | y | z, 144 B, identical
 // to the reference's G1Projective memory image (g1.rs:442-446).
 #pragma once
-#include "fields.cuh"
+#include "fields.hpp"
 
 namespace bp {
 

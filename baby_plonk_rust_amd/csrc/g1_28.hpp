@@ -1,9 +1,9 @@
-// g1_28.cuh -- the bucket-accumulation group law on the unsaturated field of fp28.cuh.
+// g1_28.hpp -- the bucket-accumulation group law on the unsaturated field of fp28.hpp.
 // Same complete mixed addition as the reference (Renes-Costello-Batina Algorithm 8, g1.rs:715-752), with
 // lazy limbs; every intermediate's limb and value bounds are checked at compile time by the F28 types.
 #pragma once
-#include "fp28.cuh"
-#include "g1.cuh"
+#include "fp28.hpp"
+#include "g1.hpp"
 
 namespace bp {
 

@@ -1,11 +1,11 @@
-// msm.hip -- host driver of the G1 MSM pipeline (kernels in msm_kernels.cuh).
+// msm.hip -- host driver of the G1 MSM pipeline (kernels in msm_kernels.hpp).
 #include <stdlib.h>
 #include <string.h>
 
 #include <vector>
 
 #include "ctx.hpp"
-#include "msm_kernels.cuh"
+#include "msm_kernels.hpp"
 
 namespace bp {
 

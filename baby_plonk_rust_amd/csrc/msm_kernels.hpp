@@ -1,4 +1,4 @@
-// msm_kernels.cuh -- G1 multi-scalar multiplication on gfx950: sum_i s_i * P_i.
+// msm_kernels.hpp -- G1 multi-scalar multiplication on gfx950: sum_i s_i * P_i.
 // Replaces BucketMSM::bucket_msm (src/msm.rs:76-118) behind Setup::commit (src/setup.rs:32-37).
 //
 // The reference walks 64 four-bit windows with 15 buckets each and ~60 projective adds per point.
@@ -15,7 +15,7 @@
 //   5. msm_accumulate   the hot loop.  The bucket-sorted index list is cut into equal chunks, one per
 //                       lane, regardless of bucket boundaries: every lane performs the same number of
 //                       complete mixed additions (gathered 112-B points of the unsaturated SRS copy, 14 x 28-bit
-//                       lazy limbs of fp28.cuh, accumulator in VGPRs),
+//                       lazy limbs of fp28.hpp, accumulator in VGPRs),
 //                       so wave utilisation does not depend on the scalar distribution.  Runs that
 //                       cover a whole bucket are stored as the bucket sum; runs cut by a chunk edge go
 //                       to a per-lane partial slot.
@@ -26,11 +26,11 @@
 //   host epilogue       Horner over the W window sums / the bit planes (c doublings per window, msm.rs:107-115)
 //                       + one affine normalisation.
 //
-// Group law: complete RCB formulas (g1.cuh) -- branch-free, so P+P / P+(-P) / identity need no
+// Group law: complete RCB formulas (g1.hpp) -- branch-free, so P+P / P+(-P) / identity need no
 // divergent special cases.
 #pragma once
-#include "g1.cuh"
-#include "g1_28.cuh"
+#include "g1.hpp"
+#include "g1_28.hpp"
 
 namespace bp {
 
@@ -413,7 +413,7 @@ __device__ __forceinline__ g1_proj28 load_proj28(const proj28_slot* __restrict__
   for (int j = 0; j < N28; j++) { p.x.l[j] = w[j]; p.y.l[j] = w[N28 + j]; p.z.l[j] = w[2 * N28 + j]; }
   return p;
 }
-// Cooperative complete addition (g1_28.cuh): the COOP consecutive lanes of a group pass the same two points; the six
+// Cooperative complete addition (g1_28.hpp): the COOP consecutive lanes of a group pass the same two points; the six
 // products and the three output coordinates travel between the lanes by shuffles; every lane returns the full sum.
 // ~1 600 instructions deep instead of ~6 600, at twice the work -- it pays only where fewer additions than lanes / 8 are
 // pending (the upper levels of block_tree_sum28), not in the bulk loop.

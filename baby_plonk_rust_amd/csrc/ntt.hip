@@ -1,8 +1,8 @@
-// ntt.hip -- host driver of the Fr NTT (kernels in ntt_kernels.cuh) and of the element-wise Fr kernels.
+// ntt.hip -- host driver of the Fr NTT (kernels in ntt_kernels.hpp) and of the element-wise Fr kernels.
 #include <string.h>
 
 #include "ctx.hpp"
-#include "ntt_kernels.cuh"
+#include "ntt_kernels.hpp"
 
 namespace bp {
 

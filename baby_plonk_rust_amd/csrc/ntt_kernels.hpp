@@ -1,4 +1,4 @@
-// ntt_kernels.cuh -- Fr number-theoretic transform on gfx950.
+// ntt_kernels.hpp -- Fr number-theoretic transform on gfx950.
 // Replaces ntt_381 / i_ntt_381 (src/utils.rs:63-81, 106-129): out[x] = sum_y in[y] * w^(x*y),
 // w = ROOT_OF_UNITY^(2^32/N) (inverse: ROOT_OF_UNITY_INV, then * N^-1); natural order in and out.
 // The reference evaluates that sum literally (O(N^2), one 256-bit pow per term); every value is a
@@ -12,11 +12,11 @@
 //   pass P     : length-2^(l_P) transforms over contiguous rows; the result goes to the digit-reversed
 //                position e_1 + 2^(l_1) e_2 + ..., i.e. natural order, written in coalesced runs.
 //   A tile is 2^l x C elements (C = 8 adjacent columns = 256-B global runs) staged in LDS limb-major
-//   (9 x 29-bit limbs per element, fr29.cuh: one v_mad_u64_u32 per partial product, lazy butterflies).
+//   (9 x 29-bit limbs per element, fr29.hpp: one v_mad_u64_u32 per partial product, lazy butterflies).
 //   HBM traffic: P reads + P writes of the vector (P = 1 up to 2^10, 2 up to 2^20, 3 beyond).
 #pragma once
-#include "fr_io.cuh"
-#include "fr29.cuh"
+#include "fr_io.hpp"
+#include "fr29.hpp"
 
 namespace bp {
 
@@ -35,7 +35,7 @@ struct NttPlan {
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? __brev(x) >> (32 - bits) : 0; }
 
-// Twiddle tables live in HBM as 48-byte records: 9 x 29-bit limbs of w * 2^261 (fr29.cuh) + 3 pad words.
+// Twiddle tables live in HBM as 48-byte records: 9 x 29-bit limbs of w * 2^261 (fr29.hpp) + 3 pad words.
 struct tw29_t { uint4 q[3]; };
 __device__ __forceinline__ fr29 load_tw29(const tw29_t* __restrict__ p) {
   uint4 a = p->q[0], b = p->q[1], c = p->q[2];

@@ -1,10 +1,10 @@
-// poly.hip -- host drivers of the polynomial kernels (poly_kernels.cuh).
+// poly.hip -- host drivers of the polynomial kernels (poly_kernels.hpp).
 #include <string.h>
 
 #include <algorithm>
 
 #include "ctx.hpp"
-#include "poly_kernels.cuh"
+#include "poly_kernels.hpp"
 
 namespace bp {
 

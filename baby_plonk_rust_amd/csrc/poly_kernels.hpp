@@ -1,9 +1,9 @@
-// poly_kernels.cuh -- device kernels behind the Polynomial operators of src/polynomial.rs:
+// poly_kernels.hpp -- device kernels behind the Polynomial operators of src/polynomial.rs:
 //   evaluation at a point (coeffs_evaluate :34-45), division by a binomial b0 + bm x^m (the only
 //   divisors the prover uses: Z_H = x^n - 1 at prover.rs:450 and x - zeta / x - zeta*omega at :623-638),
-//   and a general long division for everything else.  Element-wise ops live in ntt_kernels.cuh.
+//   and a general long division for everything else.  Element-wise ops live in ntt_kernels.hpp.
 #pragma once
-#include "fr_io.cuh"
+#include "fr_io.hpp"
 
 namespace bp {
 

@@ -5,7 +5,7 @@
 // The reference builds every round out of value-semantics `Polynomial` operators (each product = three O(n^2) DFTs,
 // each division a long division).  Every committed or evaluated polynomial is uniquely determined by the witness, the
 // circuit, the blinders and the challenges, so this file computes the same polynomials by the cheapest exact route:
-//   round 1/2  b(x) (x^n - 1) + iNTT(values) written directly (fr_blind); grand product by scans (poly_kernels.cuh);
+//   round 1/2  b(x) (x^n - 1) + iNTT(values) written directly (fr_blind); grand product by scans (poly_kernels.hpp);
 //   round 3    the quotient t = (gate + alpha perm + alpha^2 first_row) / (x^n - 1) point-wise on the coset g <w_4n>
 //              (5 coset NTTs of the witness polynomials + 1 inverse; the circuit's 9 coset columns are cached);
 //   round 5    the opening numerator as one fused linear combination, division by x - zeta as a scan (poly.hip).
@@ -20,7 +20,7 @@
 #include <vector>
 
 #include "ctx.hpp"
-#include "prover_kernels.cuh"
+#include "prover_kernels.hpp"
 #include "transcript.hpp"
 
 namespace bp {

@@ -1,9 +1,9 @@
-// prover_kernels.cuh -- element-wise kernels of the native prover (prover.hip): the polynomial identities of
+// prover_kernels.hpp -- element-wise kernels of the native prover (prover.hip): the polynomial identities of
 // src/prover.rs rounds 1-5 evaluated without the reference's chain of O(n)-allocation Polynomial temporaries.
 // All values are Montgomery Fr (scalar.rs:22), all kernels HBM-streaming.
 #pragma once
-#include "fields.cuh"
-#include "fr_io.cuh"
+#include "fields.hpp"
+#include "fr_io.hpp"
 
 namespace bp {
 

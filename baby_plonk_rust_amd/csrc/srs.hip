@@ -1,6 +1,6 @@
-// srs.hip -- host drivers of the SRS kernels (srs_kernels.cuh).
+// srs.hip -- host drivers of the SRS kernels (srs_kernels.hpp).
 #include "ctx.hpp"
-#include "srs_kernels.cuh"
+#include "srs_kernels.hpp"
 
 namespace bp {
 

@@ -1,10 +1,10 @@
-// srs_kernels.cuh -- SRS ingest / export / generation on the GPU.
+// srs_kernels.hpp -- SRS ingest / export / generation on the GPU.
 //   srs_decode96   : 96-byte zkcrypto uncompressed encoding (g1.rs:246-322) -> device Montgomery affine
 //   srs_encode96   : the inverse (G1Affine::to_uncompressed)
 //   srs_generate   : P_i = s_i * G with s_i = tau^i (Setup::generate_srs, setup.rs:12-31) or
 //                    s_i = a + i*d (synthetic benchmark points)
 #pragma once
-#include "g1.cuh"
+#include "g1.hpp"
 
 namespace bp {
 

@@ -440,13 +440,14 @@ def main():
                  "setup_s": t_setup, "circuit_host_s": t_circuit_host, "streams": len(provers), "group": None}
         # one proof on ONE context over all N GPUs (bp_init_multi): the nine commitments of prover.rs are sharded by point range,
         # everything else runs on GPU 0.  Rank 0 drives it; the other ranks have freed their memory and wait on the host.
-        if world > 1 and args.backend == "nccl":
+        if world > 1:
             del provers, wit
             torch.cuda.empty_cache()
             dist.barrier(group=ctl)
             if rank == 0:
                 try:
-                    gctx = bp.Context(list(range(world)))
+                    # one shard per GPU; a gloo rehearsal (ranks sharing a card) lists that card once per rank
+                    gctx = bp.Context(list(range(world)) if args.backend == "nccl" else [dev_index] * world)
                     gsetup = bp.Setup.generate_srs(pn + 6, 0x1234567 + args.prove_log_n, gctx, tables=not args.no_tables)
                     gprover = bp.Prover(gsetup, bp.Circuit(pk, gctx))
                     gwit = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]

@@ -1,8 +1,8 @@
 // hostcheck.hip -- TEST-ONLY host build of the product's __host__ __device__ arithmetic headers
-// (baby_plonk_rust_amd/csrc/{bigint,fields,g1}.cuh) so their logic can be checked against the
+// (baby_plonk_rust_amd/csrc/{bigint,fields,g1}.hpp) so their logic can be checked against the
 // oracle on a machine without a GPU.  Never linked into the product library.
 #define BP_HOST_USE_DEVICE_ALGO 1   /* run the 32-bit column multiplier (the device algorithm) on the CPU */
-#include "../../baby_plonk_rust_amd/csrc/g1.cuh"
+#include "../../baby_plonk_rust_amd/csrc/g1.hpp"
 #include <string.h>
 using namespace bp;
 
@@ -26,8 +26,8 @@ void hc_g1_mul_small(uint32_t* r, const uint32_t* a, uint32_t k, int nbits) { g1
 void hc_g1_to_affine(uint32_t* r, const uint32_t* a) { g1_proj x; memcpy(&x, a, 144); g1_affine z = g1_to_affine(x); memcpy(r, &z, 96); }
 }
 
-// ---- unsaturated 14 x 28 field (fp28.cuh / g1_28.cuh) ----
-#include "../../baby_plonk_rust_amd/csrc/g1_28.cuh"
+// ---- unsaturated 14 x 28 field (fp28.hpp / g1_28.hpp) ----
+#include "../../baby_plonk_rust_amd/csrc/g1_28.hpp"
 extern "C" {
 // r (saturated Montgomery) = a * b through the 28-bit path: convert in, mul28, convert out
 void hc_fp28_mul(uint32_t* r, const uint32_t* a, const uint32_t* b) {
@@ -84,8 +84,8 @@ int hc_g1_28_is_identity(const uint32_t* a_in) { g1_proj a; memcpy(&a, a_in, 144
 void hc_g1_28_identity(uint32_t* r) { g1_proj out = g1_proj_from_28(g1_identity28()); memcpy(r, &out, 144); }
 }
 
-// ---- unsaturated 9 x 29 scalar field (fr29.cuh) ----
-#include "../../baby_plonk_rust_amd/csrc/fr29.cuh"
+// ---- unsaturated 9 x 29 scalar field (fr29.hpp) ----
+#include "../../baby_plonk_rust_amd/csrc/fr29.hpp"
 extern "C" {
 // (u, v) in the reference's Montgomery form, w in Montgomery form; outputs canonical Montgomery: u+v, (u-v)*w after `reps` chained butterflies
 void hc_fr29_butterfly(uint32_t* ru, uint32_t* rv, const uint32_t* u_in, const uint32_t* v_in, const uint32_t* w_in, int reps) {

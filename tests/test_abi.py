@@ -41,7 +41,7 @@ def test_no_gpu_means_loud_failure_not_fallback():
 def test_product_does_not_import_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "baby_plonk_rust_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".hpp", ".hpp", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 for needle in ("import oracle", "from oracle", "oracle/", "liboracle", "bp_oracle", "oracle."):
                     assert needle not in src, (needle, os.path.join(dirpath, f))
@@ -90,7 +90,7 @@ def test_host_point_compression_against_the_reference_fixture():
 
 
 def _slot(point_int):
-    """an accumulator slot as the MSM kernels leave it (msm_kernels.cuh proj28_slot): x | y | z, 14 limbs of 28 bits each of
+    """an accumulator slot as the MSM kernels leave it (msm_kernels.hpp proj28_slot): x | y | z, 14 limbs of 28 bits each of
     v * 2^392 mod p, + 2 pad words; built with Python integers only"""
     P = M.P
     x, y, z = (point_int[0], point_int[1], 1) if point_int is not None else (0, 1, 0)

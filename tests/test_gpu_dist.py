@@ -74,6 +74,8 @@ def test_bench_self_launches_two_ranks():
     assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["points_per_rank"] == 1 << 14 and st["value"] > 0
     assert len(st["accumulate_ms_per_rank"]) == 2 and all(v > 0 for v in st["accumulate_ms_per_rank"])
     assert line["prove"]["gates"] == 1 << 10 and line["prove"]["value"] > 0 and line["prove"]["parallelism"] == "independent proofs x2"
+    grp = line["prove"]["one_proof_over_all_gpus"]          # one proof on a context spanning all ranks' GPUs (here: two shards on one card)
+    assert grp["n_gpus"] == 2 and grp.get("same_proof_bytes_as_one_gpu") is True and grp["latency_ms_per_proof"] > 0, grp
     # the strong-scaling problem is the same for every N: one rank must get the same bytes
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "14", "--ntt-log-n", "14",
                           "--strong-log-n", "15", "--prove-log-n", "0", "--skip-cpu", "--skip-seams", "--other-sizes"], capture_output=True, text=True,

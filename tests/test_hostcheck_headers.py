@@ -1,4 +1,4 @@
-"""CPU check of the product's __host__ __device__ arithmetic headers (bigint/fields/g1 .cuh): the same
+"""CPU check of the product's __host__ __device__ arithmetic headers (bigint/fields/g1 .hpp): the same
 templates the kernels instantiate are compiled for the host (tests/hostcheck) with the device's 32-bit
 column multiplier selected, and compared with the oracle.  Catches logic errors before any GPU time."""
 import ctypes as C
@@ -99,7 +99,7 @@ def test_g1_ops(hc):
 
 
 def test_fp28_unsaturated_field(hc):
-    """fp28.cuh: 14 x 28-bit lazy limbs, R' = 2^392 -- multiply and domain conversions vs the oracle"""
+    """fp28.hpp: 14 x 28-bit lazy limbs, R' = 2^392 -- multiply and domain conversions vs the oracle"""
     rnd = random.Random(14)
     vals = [0, 1, P - 1, P - 2, (P - 1) // 2, 2**380, 2**381 - 1] + [rnd.randrange(P) for _ in range(80)]
     for i in range(len(vals) - 1):
@@ -109,7 +109,7 @@ def test_fp28_unsaturated_field(hc):
 
 
 def test_g1_28_mixed_add(hc):
-    """g1_28.cuh: complete mixed addition on lazy limbs, incl. identity / doubling / inverse cases and long chains"""
+    """g1_28.hpp: complete mixed addition on lazy limbs, incl. identity / doubling / inverse cases and long chains"""
     rnd = random.Random(15)
     g = O.g1_generator()
 
@@ -143,7 +143,7 @@ def test_g1_28_mixed_add(hc):
 
 
 def test_g1_28_add_double_mul_small(hc):
-    """g1_28.cuh: complete projective add / double / small multiples on lazy limbs (used by fix-up and reduce)"""
+    """g1_28.hpp: complete projective add / double / small multiples on lazy limbs (used by fix-up and reduce)"""
     rnd = random.Random(16)
     g = O.g1_generator()
     pts = [g, O.g1_identity(), O.g1_double(g)] + [O.g1_mul(g, O.fr_from_int(rnd.randrange(Q))) for _ in range(4)]
@@ -180,7 +180,7 @@ def test_g1_28_add_double_mul_small(hc):
 
 
 def test_fr29_lazy_butterflies(hc):
-    """fr29.cuh: 9 x 29-bit limbs, data kept in the reference's 2^256 Montgomery domain, twiddles in 2^261"""
+    """fr29.hpp: 9 x 29-bit limbs, data kept in the reference's 2^256 Montgomery domain, twiddles in 2^261"""
     rnd = random.Random(17)
     fn = hc.hc_fr29_butterfly
     fn.restype, fn.argtypes = None, [C.c_void_p] * 5 + [C.c_int]
