@@ -175,7 +175,11 @@ def test_full_size_2p24_closed_form_both_paths(ctx):
     want = M.enc96(M.ec_mul(O.dot_progression(sc, a, d)))
     plain = bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n))
     assert plain == want and not ctx.msm_stats()["tables"]
-    info = ctx.srs_precompute(h)
+    info = ctx.srs_precompute(h)                                     # auto width: 20 bits = 13 windows from 2^23 points (partitioned sort)
+    assert info["window_bits"] == 20 and info["windows"] == 13 and info["bytes"] == 13 * n * 112
+    assert bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n)) == want and ctx.msm_stats()["tables"]
+    assert ctx.msm_stats()["window_bits"] == 20
+    info = ctx.srs_precompute(h, 16)                                 # and the one-histogram-per-window width at the same size
     assert info["window_bits"] == 16 and info["bytes"] == 16 * n * 112
     assert bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n)) == want and ctx.msm_stats()["tables"]
     # point-range shards as 8 GPUs would hold them (2^21 points each), combined on the host
