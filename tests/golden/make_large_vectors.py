@@ -9,7 +9,8 @@ the radix-2 twin of the reference DFT, Polynomial operators with the reference's
 recipe that regenerates the inputs; likewise one 2^16-coefficient Polynomial division by x^n - 1 and by x - zeta.
 The reference itself is Rust and cannot run here; nothing of it is copied, the fixture is data.
 
-    python tests/golden/make_large_vectors.py          (about five minutes on 8 cores)
+    python tests/golden/make_large_vectors.py          (2^12, 2^14, 2^16 gates + the divisions: three minutes on 8 cores)
+    python tests/golden/make_large_vectors.py 18 19    (adds 2^18 and 2^19 gates -- 4n = 2^20 and 2^21, the three-pass NTT: ~40 minutes)
 """
 import hashlib
 import json
@@ -74,8 +75,16 @@ def large_division():
 
 
 if __name__ == "__main__":
-    out = {"_made_by": "tests/golden/make_large_vectors.py (CPU oracle restatement of src/prover.rs / src/polynomial.rs)",
-           "proofs": [large_proof(k) for k in (12, 14, 16)], "division": large_division()}
-    with open(os.path.join(HERE, "large_vectors.json"), "w") as f:
+    path = os.path.join(HERE, "large_vectors.json")
+    if len(sys.argv) > 1:            # python make_large_vectors.py 18 19  -> add (or refresh) proofs of these sizes, keep the rest
+        out = json.load(open(path))
+        have = {p["log_n"]: p for p in out["proofs"]}
+        for k in map(int, sys.argv[1:]):
+            have[k] = large_proof(k)
+        out["proofs"] = [have[k] for k in sorted(have)]
+    else:
+        out = {"_made_by": "tests/golden/make_large_vectors.py (CPU oracle restatement of src/prover.rs / src/polynomial.rs)",
+               "proofs": [large_proof(k) for k in (12, 14, 16)], "division": large_division()}
+    with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote large_vectors.json")
