@@ -271,6 +271,8 @@ void bp_destroy(bp_ctx* ctx) {
     bp_destroy(ctx->members[r]);
   }
   ctx->members.clear();
+  for (bp_ctx* lane : ctx->lanes) bp_destroy(lane);
+  ctx->lanes.clear();
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->ws)
@@ -652,6 +654,56 @@ static int msm_all_shards(bp_ctx* ctx, uint64_t srs_handle, size_t first, const 
   *out = acc;
   return BP_OK;
 }
+
+}  // extern "C"
+
+namespace bp {
+constexpr int MAX_LANES = 3;
+int commit_many(bp_ctx* ctx, uint64_t srs_handle, const fr_t* const* d_coeffs, const size_t* n, int k, g1_proj* out) {
+  if (k <= 0) return BP_OK;
+  SrsEntry* e;
+  BP_TRY(srs_find(ctx, srs_handle, &e));
+  if (is_group(ctx) || k == 1) {            // a group context already keeps every GPU busy with one commitment's shards
+    for (int j = 0; j < k; j++) BP_TRY(msm_all_shards(ctx, srs_handle, 0, d_coeffs[j], n[j], BP_FR_MONT, 1, &out[j]));
+    return BP_OK;
+  }
+  DeviceGuard guard(ctx->device);
+  while ((int)ctx->lanes.size() < MAX_LANES - 1 && (int)ctx->lanes.size() < k - 1) {
+    bp_ctx* lane = nullptr;
+    int rc = ctx_create(&lane, ctx->device);
+    if (rc != BP_OK) return fail(ctx, rc, "commit lane", hipSuccess, __FILE__, __LINE__);
+    ctx->lanes.push_back(lane);
+  }
+  for (int base = 0; base < k; base += MAX_LANES) {
+    const int cnt = std::min(MAX_LANES, k - base);
+    BP_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));          // the coefficient vectors were produced on ctx->stream
+    MsmPending pend[MAX_LANES];
+    bool used[MAX_LANES] = {false, false, false};
+    int rc = BP_OK;
+    for (int j = 0; j < cnt && rc == BP_OK; j++) {
+      bp_ctx* lane = j == 0 ? ctx : ctx->lanes[j - 1];
+      if (lane != ctx) {
+        hipError_t he = hipStreamWaitEvent(lane->stream, ctx->ev[4], 0);
+        if (he != hipSuccess) { rc = fail(ctx, BP_ERR_HIP, "commit lane wait", he, __FILE__, __LINE__); break; }
+      }
+      const size_t cnt_j = std::min(n[base + j], e->n);              // zip() truncation, msm.rs:29
+      rc = lift(ctx, lane, msm_shard_launch(lane, e, 0, d_coeffs[base + j], cnt_j, BP_FR_MONT, 1, ctx->device, nullptr, 0, nullptr, &pend[j]));
+      used[j] = rc == BP_OK;
+    }
+    for (int j = 0; j < cnt; j++) {                                 // every launched lane is waited for, also after a failure elsewhere
+      if (!used[j]) continue;
+      bp_ctx* lane = j == 0 ? ctx : ctx->lanes[j - 1];
+      const int rc1 = lift(ctx, lane, msm_finish(lane, pend[j], &out[base + j]));
+      if (rc == BP_OK) rc = rc1;
+      if (lane != ctx && rc1 == BP_OK && lane->msm_accumulate_ms > ctx->msm_accumulate_ms) ctx->msm_accumulate_ms = lane->msm_accumulate_ms;
+    }
+    if (rc != BP_OK) return rc;
+  }
+  return BP_OK;
+}
+}  // namespace bp
+
+extern "C" {
 
 int bp_msm_g1_partial(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
                       int scalars_on_device, uint8_t out144[144]) {
@@ -1235,7 +1287,12 @@ int bp_circuit_commitments(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_ha
   auto it = ctx->circuits.find(circuit_handle);
   if (it == ctx->circuits.end()) return fail(ctx, BP_ERR_INVALID_ARG, "unknown circuit handle", hipSuccess, __FILE__, __LINE__);
   const size_t n = (size_t)1 << it->second.log_n;
-  for (int k = 0; k < 8; k++) BP_TRY(bp_commit_device(ctx, srs_handle, it->second.coef + (size_t)k * n, n, BP_BASIS_MONOMIAL, out768 + 96 * k));
+  const fr_t* polys[8];
+  size_t lens[8];
+  g1_proj cm[8];
+  for (int k = 0; k < 8; k++) { polys[k] = it->second.coef + (size_t)k * n; lens[k] = n; }
+  BP_TRY(commit_many(ctx, srs_handle, polys, lens, 8, cm));
+  for (int k = 0; k < 8; k++) host_encode96(out768 + 96 * k, cm[k]);
   return BP_OK;
 }
 int bp_prove(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_handle, const void* a, const void* b, const void* c, const void* public_input,

@@ -62,6 +62,10 @@ struct bp_ctx {
   // Every member is a full single-device context (own stream, workspaces, NTT tables) driven by the leader's host thread.
   std::vector<bp_ctx*> members;
   bp_ctx* leader = nullptr;                        // set on members[1..]
+  // Extra single-device contexts on THIS device (own stream + workspaces, created on first use): independent commitments of
+  // one caller -- the three of prover rounds 1 and 3, the two of round 5, the verifier's eight -- run on them concurrently,
+  // so one MSM's latency-bound tail (bucket tree, fix-up, scans) overlaps another's bulk kernel.
+  std::vector<bp_ctx*> lanes;
   hipStream_t stream = nullptr;
   bool own_stream = true;
   std::string last_error;
@@ -139,6 +143,9 @@ int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out);
 int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
             g1_proj* host_out);
 int msm_init_device(bp_ctx* ctx);
+// k independent commitments sum_i coeffs_j[i] * SRS[i] (Setup::commit, setup.rs:32-37) of HBM-resident Montgomery coefficient
+// vectors, all in flight together; out[j] in the order given
+int commit_many(bp_ctx* ctx, uint64_t srs_handle, const fr_t* const* d_coeffs, const size_t* n, int k, g1_proj* out);
 int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points28, size_t n, uint32_t c, g1_affine28** d_table,
                    uint32_t* windows);
 int srs_to28_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28** d_out);

@@ -243,7 +243,11 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
     hipLaunchKernelGGL(fr_blind, dim3(blocks_n), dim3(256), 0, st, coefs + (size_t)j * n, n, blind[2 * j + 1], blind[2 * j], Fr::zero(), 2u,
                        poly_abc[j]);
   BP_HIP(ctx, hipGetLastError());
-  for (int j = 0; j < 3; j++) BP_TRY(commit(ctx, srs, poly_abc[j], n + 2, &cm[j]));
+  {                                       // three independent commitments in flight together (commit_many)
+    const fr_t* polys[3] = {poly_abc[0], poly_abc[1], poly_abc[2]};
+    const size_t lens[3] = {n + 2, n + 2, n + 2};
+    BP_TRY(commit_many(ctx, srs, polys, lens, 3, &cm[0]));
+  }
   tr.point("a_1", cm[0]); tr.point("b_1", cm[1]); tr.point("c_1", cm[2]);
   const fr_t beta = tr.challenge("beta"), gamma = tr.challenge("gamma");
   const double t_r1 = now_ms();
@@ -299,9 +303,11 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   hipLaunchKernelGGL(fr_poke_add, dim3(1), dim3(1), 0, st, t_mid, fneg(blind[9]));                  // ... - b10
   hipLaunchKernelGGL(fr_poke_add, dim3(1), dim3(1), 0, st, t_hi, fneg(blind[10]));                  // - b11
   BP_HIP(ctx, hipGetLastError());
-  BP_TRY(commit(ctx, srs, t_lo, n + 1, &cm[4]));
-  BP_TRY(commit(ctx, srs, t_mid, n + 1, &cm[5]));
-  BP_TRY(commit(ctx, srs, t_hi, hi_len, &cm[6]));
+  {
+    const fr_t* polys[3] = {t_lo, t_mid, t_hi};
+    const size_t lens[3] = {n + 1, n + 1, hi_len};
+    BP_TRY(commit_many(ctx, srs, polys, lens, 3, &cm[4]));
+  }
   tr.point("t_lo_1", cm[4]); tr.point("t_mid_1", cm[5]); tr.point("t_hi_1", cm[6]);
   const fr_t zeta = tr.challenge("zeta");
   const double t_r3 = now_ms();
@@ -378,8 +384,11 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   hipLaunchKernelGGL(fr_poke_add, dim3(1), dim3(1), 0, st, num, fneg(zw_bar));
   BP_HIP(ctx, hipGetLastError());
   BP_TRY(divide_by_linear(ctx, num, n + 3, fmul(zeta, omega), w_zeta_omega, &wzo_len));
-  BP_TRY(commit(ctx, srs, w_zeta, wz_len, &cm[7]));
-  BP_TRY(commit(ctx, srs, w_zeta_omega, wzo_len, &cm[8]));
+  {
+    const fr_t* polys[2] = {w_zeta, w_zeta_omega};
+    const size_t lens[2] = {wz_len, wzo_len};
+    BP_TRY(commit_many(ctx, srs, polys, lens, 2, &cm[7]));
+  }
   const double t_r5 = now_ms();
 
   // ---- Proof (verifier.rs:23-40 field order): 9 compressed points, then the 6 evaluations as 32-byte little-endian
