@@ -1,4 +1,5 @@
 // ntt.hip -- host driver of the Fr NTT (kernels in ntt_kernels.hpp) and of the element-wise Fr kernels.
+#include <stdlib.h>
 #include <string.h>
 
 #include "ctx.hpp"
@@ -33,21 +34,32 @@ int ntt_init_tables(bp_ctx* ctx) {
   return BP_OK;
 }
 
-// one butterfly per lane per stage: 2^(l-1) * 8 columns lanes, capped at 1024 (a 2^8 x 8 tile owns most of the CU's LDS)
-static unsigned pass_threads(uint32_t l) {
-  unsigned t = (1u << (l - 1)) << ntt_tile_cols_log(l);
+// one butterfly per lane per stage: 2^(l-1) * columns lanes, capped at 1024
+static unsigned pass_threads(uint32_t l, uint32_t cl) {
+  unsigned t = (1u << (l - 1)) << cl;
   return t > 1024 ? 1024 : (t < 64 ? 64 : t);
+}
+static uint32_t env_ntt(const char* name, uint32_t dflt) {
+  const char* v = getenv(name);
+  return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
 static void make_ntt_plan(NttPlan& plan, uint32_t k) {
   memset(&plan, 0, sizeof plan);
   plan.k = k;
   plan.P = k <= NTT_SMALL_MAX_LOG ? 1 : (k <= 2 * NTT_MAX_PASS_LOG ? 2 : 3);
+  if (plan.P == 2 && k >= env_ntt("BP_NTT_THREE_PASS_FROM", 99)) plan.P = 3;
   uint32_t rem = k;
   for (uint32_t i = 0; i < plan.P; i++) {          // balanced widths, larger ones first
     uint32_t left = plan.P - i;
     plan.l[i] = (rem + left - 1) / left;
     rem -= plan.l[i];
+    plan.cl[i] = ntt_tile_cols_log(plan.l[i]);
+    if (plan.l[i] <= 7) plan.cl[i] = env_ntt("BP_NTT_COLS_LOG_L7", plan.cl[i]);
+    if (plan.l[i] == 8) plan.cl[i] = env_ntt("BP_NTT_COLS_LOG_L8", plan.cl[i]);
+    if (plan.l[i] == 9) plan.cl[i] = env_ntt("BP_NTT_COLS_LOG_L9", plan.cl[i]);
+    if (plan.l[i] == 10) plan.cl[i] = env_ntt("BP_NTT_COLS_LOG_L10", plan.cl[i]);
+    if (plan.cl[i] > 3) plan.cl[i] = 3;
   }
   plan.h = (k + 1) / 2;
 }
@@ -107,23 +119,23 @@ int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, si
     // ping-pong: pass 1 data -> tmp, middle passes in tmp, last pass tmp -> data
     fr_t* tmp;
     BP_TRY(ws_get(ctx, "ntt.tmp", batch * N * sizeof(fr_t), (void**)&tmp));
-    auto tile_lds = [](uint32_t l) {
-      const uint32_t C = 1u << ntt_tile_cols_log(l), tstride = ((1u << l) * (C + 1) + 1) & ~1u;
+    auto tile_lds = [](uint32_t l, uint32_t cl) {
+      const uint32_t C = 1u << cl, tstride = ((1u << l) * (C + 1) + 1) & ~1u;
       return ((size_t)tstride + (1u << l)) * N29 * 4 + 16;
     };
     uint32_t s = k;
     for (uint32_t i = 0; i + 1 < plan.P; i++) {
-      const uint32_t l = plan.l[i];
+      const uint32_t l = plan.l[i], cl = plan.cl[i];
       s -= l;
-      const size_t lds = tile_lds(l);
+      const size_t lds = tile_lds(l, cl);
       const tw29_t* hi = (inverse && i == 0) ? tab->hi_scaled : tab->hi;   // N^-1 rides on the first twiddle
-      hipLaunchKernelGGL(ntt_pass_strided, dim3((unsigned)(N >> (l + ntt_tile_cols_log(l))), (unsigned)batch), dim3(pass_threads(l)), lds, st,
-                         i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp, tmp, i == 0 ? stride : N, N, k, l, s, small, tab->lo, hi,
+      hipLaunchKernelGGL(ntt_pass_strided, dim3((unsigned)(N >> (l + cl)), (unsigned)batch), dim3(pass_threads(l, cl)), lds, st,
+                         i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp, tmp, i == 0 ? stride : N, N, k, l, s, cl, small, tab->lo, hi,
                          tab->h);
     }
-    const uint32_t l = plan.l[plan.P - 1];
-    const size_t lds = tile_lds(l);
-    hipLaunchKernelGGL(ntt_pass_last, dim3((unsigned)(N >> (l + ntt_tile_cols_log(l))), (unsigned)batch), dim3(pass_threads(l)), lds, st,
+    const uint32_t l = plan.l[plan.P - 1], cl = plan.cl[plan.P - 1];
+    const size_t lds = tile_lds(l, cl);
+    hipLaunchKernelGGL(ntt_pass_last, dim3((unsigned)(N >> (l + cl)), (unsigned)batch), dim3(pass_threads(l, cl)), lds, st,
                        (const fr_t*)tmp, d_data, N, stride, plan, small);
   }
   BP_HIP(ctx, hipGetLastError());

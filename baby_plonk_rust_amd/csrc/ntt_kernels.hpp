@@ -22,14 +22,18 @@ namespace bp {
 
 constexpr int NTT_MAX_PASS_LOG = 10;    // per-pass transform length up to 2^10
 constexpr int NTT_SMALL_MAX_LOG = 10;   // single-workgroup transform up to 2^10
-// tile columns C = 2^cl shrink as the per-pass length grows so that a tile (2^l x (C+1) x 36 B) plus its stage twiddles
-// stays inside the 160 KiB of LDS: l <= 8 -> C = 8 (256-B global runs), l = 9 -> C = 4, l = 10 -> C = 2 (64-B runs)
-__host__ __device__ constexpr uint32_t ntt_tile_cols_log(uint32_t l) { return l <= 8 ? 3u : (l == 9 ? 2u : 1u); }
+// tile columns C = 2^cl shrink as the per-pass length grows so that TWO tiles (2^l x (C+1) x 36 B each, plus stage twiddles)
+// fit the 160 KiB of LDS wherever possible: with one 1 024-lane workgroup per CU nothing overlaps a tile's global loads and
+// stores, with two the other one computes meanwhile (measured, profiles/r02_ntt_tile_width_ab.txt: l = 8: C = 8 -> 4 is -8 %
+// at 2^22 and 2^24; l = 9: C = 4 -> 2 is -25 % at 2^18).  l <= 7 -> C = 8 (256-B global runs), l = 8 -> 4, l = 9 -> 2,
+// l = 10 -> 2 (one tile per CU: a single column would halve the run to 32 B and measured +32 %)
+__host__ __device__ constexpr uint32_t ntt_tile_cols_log(uint32_t l) { return l <= 7 ? 3u : (l == 8 ? 2u : 1u); }
 
 struct NttPlan {
   uint32_t k;            // log2 N
   uint32_t P;            // passes
   uint32_t l[4];         // digit widths
+  uint32_t cl[4];        // log2 of the tile's column count per pass (ntt_tile_cols_log unless overridden)
   uint32_t h;            // low table has 2^h entries, high table 2^(k-h)
 };
 
@@ -174,10 +178,10 @@ __device__ __forceinline__ fr29 twiddle_lookup(const tw29_t* __restrict__ lo, co
 //   l      digit width, s = bits below the digit, mlog = l + s, k = log2 N
 //   element (hi, d, r): address hi * 2^mlog + d * 2^s + r; tile = all d x C consecutive r.
 __global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride,
-                                                         uint32_t k, uint32_t l, uint32_t s,
+                                                         uint32_t k, uint32_t l, uint32_t s, uint32_t cl,
                                                          const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo,
                                                          const tw29_t* __restrict__ tw_hi, uint32_t h) {
-  const uint32_t cl = ntt_tile_cols_log(l), C = 1u << cl, CP = C + 1;
+  const uint32_t C = 1u << cl, CP = C + 1;
   const uint32_t L = 1u << l, mlog = l + s, tstride = (L * CP + 1) & ~1u;      // even: the limb-pair arrays stay 8-byte aligned
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
@@ -209,7 +213,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* 
 __global__ void __launch_bounds__(1024) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
                                                       size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
   const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l;
-  const uint32_t cl = ntt_tile_cols_log(l), C = 1u << cl, CP = C + 1, tstride = (L * CP + 1) & ~1u;
+  const uint32_t cl = plan.cl[P - 1], C = 1u << cl, CP = C + 1, tstride = (L * CP + 1) & ~1u;
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
   const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
