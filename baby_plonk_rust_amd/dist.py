@@ -63,7 +63,8 @@ class ShardedMsm:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.gpu = torch.device("cuda", ctx.device)
         self.mine = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu)
-        self.on_gpu = self.world > 1 and dist.get_backend(group) == "nccl"
+        self.collective = dist.is_initialized()          # under a launcher even a single rank goes through the collective
+        self.on_gpu = self.collective and dist.get_backend(group) == "nccl"
         self.gathered = torch.empty(self.world * _lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu if self.on_gpu else "cpu")
         self.exchange_s = 0.0
         torch.cuda.synchronize(self.gpu)
@@ -72,7 +73,7 @@ class ShardedMsm:
         import time
         self.ctx.msm_blob_device(srs_handle_local, self.mine.data_ptr(), scalars_local, first=first, device_ptr=device_ptr, n=n)
         t0 = time.perf_counter()
-        if self.world == 1:
+        if not self.collective:
             host = self.mine.cpu()
         elif self.on_gpu:
             dist.all_gather_into_tensor(self.gathered, self.mine, group=self.group)       # the path's single collective
