@@ -167,6 +167,10 @@ int msm_init_device(bp_ctx* ctx) {
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_planes_block<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_count, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_count_rec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_scatter_rec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return BP_OK;
 }
 
@@ -241,11 +245,66 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
 
   hipStream_t st = ctx->stream;
   BP_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-  BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4 + 8, st));
-  hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits, long_count + 1);
   const size_t hist_bytes = (size_t)plan.hist * 4;
   const unsigned hist_threads = plan.hist >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
   const uint32_t n_tiles = (total + SCAN_TILE - 1) / SCAN_TILE;      // <= 4096 (total <= 2^24)
+  // Bucket sort: the partitioned (radix) sort from ~2 Mi entries -- every store coalesced or L2-merged -- the one-histogram
+  // counting sort below that (fewer launches).  BP_MSM_SORT: 0 = histogram sort (c <= 16 only), 1 = radix, 2 = the
+  // per-(window, part) record sort of the first wide-window version (kept for the A/B table).
+  const uint32_t sort_env = env_u32("BP_MSM_SORT", 99);
+  const bool radix = sort_env == 1 || (sort_env != 0 && sort_env != 2 && (plan.parts > 1 || max_entries >= (1ull << 21))) ||
+                     (plan.parts > 1 && sort_env == 0);
+  if (radix) {
+    uint32_t kb = 0;
+    while ((1ull << kb) < total) kb++;
+    uint32_t pb = 0;
+    while (pb < kb && (max_entries >> (pb + 1)) >= 12288) pb++;             // final runs of ~12-24 Ki entries
+    pb = env_u32("BP_MSM_RADIX_BITS", pb);
+    if (pb > kb) pb = kb;
+    if (pb > 16) pb = 16;
+    const uint32_t lv[2] = {pb <= 8 ? pb : pb - pb / 2, pb <= 8 ? 0 : pb / 2}, rbits = kb - pb, n_final = 1u << pb;
+    uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *run_off[3], *cnt, *cur;
+    BP_TRY(ws_get(ctx, "msm.rkeys0", max_entries * 4, (void**)&keys[0]));
+    BP_TRY(ws_get(ctx, "msm.rvals0", max_entries * 4, (void**)&vals[0]));
+    if (pb) {
+      BP_TRY(ws_get(ctx, "msm.rkeys1", max_entries * 4, (void**)&keys[1]));
+      BP_TRY(ws_get(ctx, "msm.rvals1", max_entries * 4, (void**)&vals[1]));
+    }
+    uint32_t* roff;
+    BP_TRY(ws_get(ctx, "msm.run_off", ((size_t)3 * n_final + 16) * 4, (void**)&roff));
+    run_off[0] = roff;                                   // {0, W n}
+    run_off[1] = roff + 4;                               // after level 1: 2^lv[0] + 1 entries
+    run_off[2] = roff + 8 + n_final;                     // after level 2: n_final + 1 entries
+    BP_TRY(ws_get(ctx, "msm.run_cnt", (size_t)n_final * 4, (void**)&cnt));
+    BP_TRY(ws_get(ctx, "msm.run_cur", (size_t)n_final * 4, (void**)&cur));
+    const uint32_t whole[2] = {0u, (uint32_t)max_entries};
+    BP_HIP(ctx, hipMemcpyAsync(run_off[0], whole, sizeof whole, hipMemcpyHostToDevice, st));
+    BP_HIP(ctx, hipMemsetAsync(counts + total, 0, 8, st));
+    hipLaunchKernelGGL(msm_digit_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, keys[0], vals[0], long_count + 1);
+    uint32_t runs = 1, shift = kb, side = 0;
+    for (int level = 0; level < 2 && lv[level]; level++) {
+      const uint32_t bits = lv[level], nd = 1u << bits, n_sub = runs * nd;
+      shift -= bits;
+      uint64_t per_run = max_entries / runs;
+      uint32_t gx = (uint32_t)((per_run + RADIX_SLICE - 1) / RADIX_SLICE) + (runs > 1 ? 1 : 0);
+      if (gx > 4096) gx = 4096;
+      const uint32_t t = (n_sub + SCAN_TILE - 1) / SCAN_TILE;
+      BP_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)n_sub * 4, st));
+      hipLaunchKernelGGL(msm_radix_count, dim3(gx, runs), dim3(1024), 0, st, keys[side], run_off[level], shift, bits, cnt);
+      hipLaunchKernelGGL(scan_tile_sums, dim3(t), dim3(256), 0, st, cnt, n_sub, tile_sums);
+      hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(256), 0, st, tile_sums, t, run_off[level + 1] + n_sub);
+      hipLaunchKernelGGL(scan_apply, dim3(t), dim3(256), 0, st, cnt, n_sub, tile_sums, run_off[level + 1], cur);
+      hipLaunchKernelGGL(msm_radix_scatter, dim3(gx, runs), dim3(1024), RADIX_SLICE * 9, st, keys[side], vals[side], run_off[level], shift, bits,
+                         cur, keys[side ^ 1], vals[side ^ 1]);
+      side ^= 1;
+      runs = n_sub;
+    }
+    const uint32_t level_count = (lv[0] ? 1 : 0) + (lv[1] ? 1 : 0);
+    hipLaunchKernelGGL(msm_radix_final, dim3(runs < 4096 ? runs : 4096), dim3(1024), ((size_t)1 << rbits) * 4, st, keys[side], vals[side],
+                       run_off[level_count], runs, rbits, total, offsets, sorted);
+  } else {
+  BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4 + 8, st));
+  hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits, long_count + 1);
   if (plan.parts == 1) {
     hipLaunchKernelGGL(msm_count, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, (const int16_t*)digits, plan, counts);
     hipLaunchKernelGGL(scan_tile_sums, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums);
@@ -268,6 +327,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
     hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(256), 0, st, tile_sums, n_tiles, offsets + total);
     hipLaunchKernelGGL(scan_apply, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums, offsets, cursors);
     hipLaunchKernelGGL(msm_scatter_rec, rgrid, dim3(1024), hist_bytes, st, rec_idx, rec_lo, part_off, plan, cursors, sorted);
+  }
   }
   BP_HIP(ctx, hipEventRecord(ctx->ev[1], st));
   const dim3 acc_grid((unsigned)((n_chunks + 255) / 256));

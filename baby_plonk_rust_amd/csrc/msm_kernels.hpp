@@ -365,6 +365,165 @@ __global__ void __launch_bounds__(1024) msm_scatter_rec(const uint32_t* __restri
   }
 }
 
+// ---------------------------------------------------------------- 4c. partitioned bucket sort (MSD radix, coalesced)
+// msm_scatter pays for every entry with an isolated 4-byte store: a workgroup's ~32 Ki entries land in ~32 Ki different bucket
+// regions, the lines leave L2 partially written, and HBM sees ~10x the payload (PMC WRITE_SIZE, round 1).  Here the entries are
+// first PARTITIONED by the high bits of their bucket id into runs small enough (~12 Ki entries, ~48 KiB of output) that the
+// final counting sort of a run -- one workgroup, all of the run's buckets -- scatters inside a region L2 holds and merges:
+//   msm_digit_records   scalar -> W (key, value) records: key = bucket id (0xffffffff for a zero digit), value = entry | sign
+//   msm_radix_count     per run and per slice of 8 192 records: LDS histogram of the next `bits` key bits -> sub-run sizes
+//   (scan_*)            exclusive scan of the sub-run sizes = sub-run offsets (sub-runs of run j are consecutive inside run j)
+//   msm_radix_scatter   same slices: rank in LDS, stage the slice sorted by digit, write every sub-run's share lane-adjacent
+//   msm_radix_final     one workgroup per final run: histogram of its 2^rbits buckets, prefix = the buckets' offsets (written
+//                       to `offsets` directly: no global count / scan over buckets), then the entries in bucket order
+// One or two partition levels of <= 8 bits each; the record arrays ping-pong.
+constexpr uint32_t RADIX_SLICE = 8192, RADIX_PER_LANE = RADIX_SLICE / 1024, RADIX_MAX_DIGITS = 256, RADIX_EMPTY = 0xffffffffu;
+
+__global__ void __launch_bounds__(256) msm_digit_records(const fr_t* __restrict__ scalars, int fmt, MsmPlan plan, uint32_t* __restrict__ keys,
+                                                          uint32_t* __restrict__ vals, uint32_t* __restrict__ status) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= plan.n) return;
+  fr_t k = scalars[i];
+  if (fmt == 1) {
+    Fr::from_mont(k, k);
+  } else {
+    fr_t t;
+    if (!big_sub(t, k, Fr::modulus())) atomicOr(status, 1u);
+  }
+  uint32_t kp[10];
+  uint64_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    carry += (uint64_t)(j < 8 ? k.l[j] : 0u) + plan.bias[j];
+    kp[j] = (uint32_t)carry;
+    carry >>= 32;
+  }
+  kp[9] = 0;
+  const uint32_t c = plan.c, mask = (1u << c) - 1u, half = 1u << (c - 1);
+  for (uint32_t w = 0; w < plan.W; w++) {
+    uint32_t o = c * w, word = o >> 5, sh = o & 31;
+    uint64_t two = (uint64_t)kp[word] | ((uint64_t)kp[word + 1] << 32);
+    int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (w + 1 < plan.W ? (int32_t)half : 0);
+    const size_t at = (size_t)w * plan.n + i;
+    keys[at] = d == 0 ? RADIX_EMPTY : w * plan.wbuckets + digit_bucket(d);
+    vals[at] = (i + w * plan.wpoints) | (d < 0 ? 0x80000000u : 0u);
+  }
+}
+
+// run r = records [run_off[r], run_off[r + 1]); the workgroups blockIdx.x, blockIdx.x + gridDim.x, ... take its slices
+__global__ void __launch_bounds__(1024) msm_radix_count(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ run_off, uint32_t shift,
+                                                        uint32_t bits, uint32_t* __restrict__ cnt) {
+  __shared__ uint32_t h[RADIX_MAX_DIGITS];
+  const uint32_t run = blockIdx.y, nd = 1u << bits, lo = run_off[run], hi = run_off[run + 1];
+  if (lo + (uint64_t)blockIdx.x * RADIX_SLICE >= hi) return;
+  if (threadIdx.x < nd) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint64_t base = lo + (uint64_t)blockIdx.x * RADIX_SLICE; base < hi; base += (uint64_t)gridDim.x * RADIX_SLICE) {
+    const uint32_t end = base + RADIX_SLICE < hi ? (uint32_t)base + RADIX_SLICE : hi;
+    for (uint32_t j = (uint32_t)base + threadIdx.x; j < end; j += blockDim.x) {
+      const uint32_t key = keys[j];
+      if (key != RADIX_EMPTY) atomicAdd(&h[(key >> shift) & (nd - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nd && h[threadIdx.x]) atomicAdd(&cnt[run * nd + threadIdx.x], h[threadIdx.x]);
+}
+
+extern __shared__ uint32_t msm_radix_lds[];       // st_key[RADIX_SLICE] | st_val[RADIX_SLICE] | st_d[RADIX_SLICE bytes]
+__global__ void __launch_bounds__(1024) msm_radix_scatter(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                          const uint32_t* __restrict__ run_off, uint32_t shift, uint32_t bits,
+                                                          uint32_t* __restrict__ cursor, uint32_t* __restrict__ keys_out,
+                                                          uint32_t* __restrict__ vals_out) {
+  __shared__ uint32_t h[RADIX_MAX_DIGITS], lbase[RADIX_MAX_DIGITS], gbase[RADIX_MAX_DIGITS], scan16[16];
+  uint32_t* st_key = msm_radix_lds;
+  uint32_t* st_val = st_key + RADIX_SLICE;
+  uint8_t* st_d = reinterpret_cast<uint8_t*>(st_val + RADIX_SLICE);
+  const uint32_t run = blockIdx.y, nd = 1u << bits, lo = run_off[run], hi = run_off[run + 1];
+  for (uint64_t base = lo + (uint64_t)blockIdx.x * RADIX_SLICE; base < hi; base += (uint64_t)gridDim.x * RADIX_SLICE) {   // uniform over the workgroup
+    if (threadIdx.x < nd) h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t key[RADIX_PER_LANE], val[RADIX_PER_LANE], rank[RADIX_PER_LANE];
+#pragma unroll
+    for (uint32_t j = 0; j < RADIX_PER_LANE; j++) {
+      const uint64_t at = base + j * 1024 + threadIdx.x;
+      key[j] = at < hi ? keys[at] : RADIX_EMPTY;
+      if (key[j] != RADIX_EMPTY) {
+        val[j] = vals[at];
+        rank[j] = atomicAdd(&h[(key[j] >> shift) & (nd - 1)], 1u);
+      }
+    }
+    __syncthreads();
+    const uint32_t mine = threadIdx.x < nd ? h[threadIdx.x] : 0u;
+    const uint32_t ex = block_exclusive_scan_1024(mine, scan16);
+    if (threadIdx.x < nd) {
+      lbase[threadIdx.x] = ex;
+      gbase[threadIdx.x] = mine ? atomicAdd(&cursor[run * nd + threadIdx.x], mine) : 0u;
+    }
+    __syncthreads();
+    const uint32_t live = lbase[nd - 1] + h[nd - 1];
+#pragma unroll
+    for (uint32_t j = 0; j < RADIX_PER_LANE; j++) {
+      if (key[j] != RADIX_EMPTY) {
+        const uint32_t d = (key[j] >> shift) & (nd - 1), pos = lbase[d] + rank[j];
+        st_key[pos] = key[j];
+        st_val[pos] = val[j];
+        st_d[pos] = (uint8_t)d;
+      }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < live; j += blockDim.x) {
+      const uint32_t d = st_d[j], g = gbase[d] + (j - lbase[d]);
+      keys_out[g] = st_key[j];
+      vals_out[g] = st_val[j];
+    }
+    __syncthreads();
+  }
+}
+
+// One workgroup per final run (grid-stride).  The run's keys share their high bits; its 2^rbits buckets are
+// [run << rbits, (run + 1) << rbits).  Writes offsets[bucket] for those (only below `total`) and the run's entries in bucket
+// order; the scattered 4-byte stores stay inside the run's own ~48 KiB of `sorted`, which L2 merges into whole lines.
+// keys may still hold RADIX_EMPTY records when no partition level ran (single run): they are skipped.
+__global__ void __launch_bounds__(1024) msm_radix_final(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                        const uint32_t* __restrict__ run_off, uint32_t n_runs, uint32_t rbits, uint32_t total,
+                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t scan16[16];
+  __shared__ uint32_t carry;
+  const uint32_t nb = 1u << rbits, mask = nb - 1;
+  for (uint32_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
+    const uint32_t lo = run_off[run], hi = run_off[run + 1];
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) msm_lds_hist[b] = 0;
+    __syncthreads();
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+      const uint32_t key = keys[j];
+      if (key != RADIX_EMPTY) atomicAdd(&msm_lds_hist[key & mask], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix over the nb bucket sizes, 1024 at a time; the prefix replaces the size in LDS (it becomes the cursor).
+    // Without a partition level the run still holds its zero-digit records: output positions start at `lo` and close up.
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += blockDim.x) {
+      const uint32_t b = b0 + threadIdx.x, v = b < nb ? msm_lds_hist[b] : 0u;
+      const uint32_t ex = block_exclusive_scan_1024(v, scan16) + carry;
+      if (b < nb) {
+        msm_lds_hist[b] = ex;
+        const uint64_t bucket = ((uint64_t)run << rbits) + b;
+        if (bucket < total) offsets[bucket] = lo + ex;
+      }
+      __syncthreads();
+      if (threadIdx.x == blockDim.x - 1) carry = ex + v;
+      __syncthreads();
+    }
+    if (run == n_runs - 1 && threadIdx.x == 0) offsets[total] = lo + carry;
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+      const uint32_t key = keys[j];
+      if (key != RADIX_EMPTY) sorted[lo + atomicAdd(&msm_lds_hist[key & mask], 1u)] = vals[j];
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- 5. accumulate
 __device__ __forceinline__ g1_affine load_affine(const g1_affine* __restrict__ p) {
   g1_affine r;
