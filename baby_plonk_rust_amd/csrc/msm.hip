@@ -169,8 +169,9 @@ int msm_init_device(bp_ctx* ctx) {
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_count_rec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_scatter_rec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_final, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // these two also hold a few KiB of static LDS: the dynamic limit must leave room for it
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_final, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
   return BP_OK;
 }
 
