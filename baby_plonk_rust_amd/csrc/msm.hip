@@ -261,6 +261,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
     uint32_t pb = 0;
     while (pb < kb && (max_entries >> (pb + 1)) >= 12288) pb++;             // final runs of ~12-24 Ki entries
     pb = env_u32("BP_MSM_RADIX_BITS", pb);
+    if (pb + MSM_HIST_LOG < kb) pb = kb - MSM_HIST_LOG;                   // a final run's buckets must fit one LDS histogram
     if (pb > kb) pb = kb;
     if (pb > 16) pb = 16;
     const uint32_t lv[2] = {pb <= 8 ? pb : pb - pb / 2, pb <= 8 ? 0 : pb / 2}, rbits = kb - pb, n_final = 1u << pb;
