@@ -172,6 +172,8 @@ int msm_init_device(bp_ctx* ctx) {
   // these two also hold a few KiB of static LDS: the dynamic limit must leave room for it
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_final, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_long_count, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_long_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
   return BP_OK;
 }
 
@@ -249,12 +251,12 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   const size_t hist_bytes = (size_t)plan.hist * 4;
   const unsigned hist_threads = plan.hist >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
   const uint32_t n_tiles = (total + SCAN_TILE - 1) / SCAN_TILE;      // <= 4096 (total <= 2^24)
-  // Bucket sort: the partitioned (radix) sort from ~2 Mi entries -- every store coalesced or L2-merged -- the one-histogram
-  // counting sort below that (fewer launches).  BP_MSM_SORT: 0 = histogram sort (c <= 16 only), 1 = radix, 2 = the
-  // per-(window, part) record sort of the first wide-window version (kept for the A/B table).
+  // Bucket sort.  c <= 16: the one-histogram counting sort (msm_count / msm_scatter).  Wider windows: the partitioned (radix)
+  // sort -- every store coalesced or L2-merged.  (At c = 16 the two cost the same, 0.34 vs 0.35 ms at 2^20: the radix sort
+  // moves 8-byte records three times.)  BP_MSM_SORT: 1 = radix everywhere, 2 = the per-(window, part) record sort of the
+  // first wide-window version (kept for the A/B table).
   const uint32_t sort_env = env_u32("BP_MSM_SORT", 99);
-  const bool radix = sort_env == 1 || (sort_env != 0 && sort_env != 2 && (plan.parts > 1 || max_entries >= (1ull << 21))) ||
-                     (plan.parts > 1 && sort_env == 0);
+  const bool radix = sort_env == 1 || (plan.parts > 1 && sort_env != 2);
   if (radix) {
     uint32_t kb = 0;
     while ((1ull << kb) < total) kb++;
@@ -281,7 +283,10 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
     BP_TRY(ws_get(ctx, "msm.run_cur", (size_t)n_final * 4, (void**)&cur));
     const uint32_t whole[2] = {0u, (uint32_t)max_entries};
     BP_HIP(ctx, hipMemcpyAsync(run_off[0], whole, sizeof whole, hipMemcpyHostToDevice, st));
-    BP_HIP(ctx, hipMemsetAsync(counts + total, 0, 8, st));
+    uint32_t* rlong;                                     // [0] number of long final runs, [1..] their list
+    BP_TRY(ws_get(ctx, "msm.run_long", ((size_t)n_final + 2) * 4, (void**)&rlong));
+    BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4 + 8, st));     // bucket sizes of long runs + long-bucket counter + scalar status
+    BP_HIP(ctx, hipMemsetAsync(rlong, 0, 4, st));
     hipLaunchKernelGGL(msm_digit_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, keys[0], vals[0], long_count + 1);
     uint32_t runs = 1, shift = kb, side = 0;
     for (int level = 0; level < 2 && lv[level]; level++) {
@@ -302,8 +307,17 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
       runs = n_sub;
     }
     const uint32_t level_count = (lv[0] ? 1 : 0) + (lv[1] ? 1 : 0);
-    hipLaunchKernelGGL(msm_radix_final, dim3(runs < 4096 ? runs : 4096), dim3(1024), ((size_t)1 << rbits) * 4, st, keys[side], vals[side],
-                       run_off[level_count], runs, rbits, total, offsets, sorted);
+    const size_t rhist = ((size_t)1 << rbits) * 4;
+    hipLaunchKernelGGL(msm_radix_final, dim3(runs < 4096 ? runs : 4096), dim3(1024), rhist, st, keys[side], vals[side], run_off[level_count], runs,
+                       rbits, total, offsets, sorted, rlong, rlong + 1);
+    if (runs > 1) {                 // long runs (none for uniformly random scalars beyond the top window's): slice-parallel
+      const dim3 lgrid(256, runs < 16 ? runs : 16);
+      hipLaunchKernelGGL(msm_radix_long_count, lgrid, dim3(1024), rhist, st, keys[side], run_off[level_count], rbits, rlong, rlong + 1, counts);
+      hipLaunchKernelGGL(msm_radix_long_prefix, dim3(runs < 64 ? runs : 64), dim3(1024), 0, st, run_off[level_count], runs, rbits, total, rlong,
+                         rlong + 1, counts, offsets, cursors);
+      hipLaunchKernelGGL(msm_radix_long_scatter, lgrid, dim3(1024), rhist, st, keys[side], vals[side], run_off[level_count], rbits, rlong, rlong + 1,
+                         cursors, sorted);
+    }
   } else {
   BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4 + 8, st));
   hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits, long_count + 1);

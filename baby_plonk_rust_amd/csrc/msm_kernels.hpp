@@ -484,14 +484,22 @@ __global__ void __launch_bounds__(1024) msm_radix_scatter(const uint32_t* __rest
 // [run << rbits, (run + 1) << rbits).  Writes offsets[bucket] for those (only below `total`) and the run's entries in bucket
 // order; the scattered 4-byte stores stay inside the run's own ~48 KiB of `sorted`, which L2 merges into whole lines.
 // keys may still hold RADIX_EMPTY records when no partition level ran (single run): they are skipped.
+// Runs longer than RADIX_LONG_RUN records (skewed scalars; the narrow top window, whose few buckets collect n entries) are
+// not sorted by one workgroup: they are queued in long_list and handled slice-parallel by the msm_radix_long_* kernels.
+constexpr uint32_t RADIX_LONG_RUN = 1u << 16;
 __global__ void __launch_bounds__(1024) msm_radix_final(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                         const uint32_t* __restrict__ run_off, uint32_t n_runs, uint32_t rbits, uint32_t total,
-                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
+                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted,
+                                                        uint32_t* __restrict__ long_n, uint32_t* __restrict__ long_list) {
   __shared__ uint32_t scan16[16];
   __shared__ uint32_t carry;
   const uint32_t nb = 1u << rbits, mask = nb - 1;
   for (uint32_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
     const uint32_t lo = run_off[run], hi = run_off[run + 1];
+    if (hi - lo > RADIX_LONG_RUN && n_runs > 1) {          // uniform over the workgroup
+      if (threadIdx.x == 0) long_list[atomicAdd(long_n, 1u)] = run;
+      continue;
+    }
     for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) msm_lds_hist[b] = 0;
     __syncthreads();
     for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
@@ -521,6 +529,81 @@ __global__ void __launch_bounds__(1024) msm_radix_final(const uint32_t* __restri
       if (key != RADIX_EMPTY) sorted[lo + atomicAdd(&msm_lds_hist[key & mask], 1u)] = vals[j];
     }
     __syncthreads();
+  }
+}
+
+// long runs, slice-parallel: count -> prefix (offsets and cursors of the run's buckets) -> scatter.  grid (slices, lanes of the
+// list); workgroup (x, y) takes slices x, x + gridDim.x, ... of the long runs y, y + gridDim.y, ...
+__global__ void __launch_bounds__(1024) msm_radix_long_count(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ run_off, uint32_t rbits,
+                                                             const uint32_t* __restrict__ long_n, const uint32_t* __restrict__ long_list,
+                                                             uint32_t* __restrict__ counts) {
+  const uint32_t nb = 1u << rbits, mask = nb - 1, n_long = *long_n;
+  for (uint32_t k = blockIdx.y; k < n_long; k += gridDim.y) {
+    const uint32_t run = long_list[k], lo = run_off[run], hi = run_off[run + 1];
+    for (uint64_t base = lo + (uint64_t)blockIdx.x * RADIX_SLICE; base < hi; base += (uint64_t)gridDim.x * RADIX_SLICE) {
+      for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) msm_lds_hist[b] = 0;
+      __syncthreads();
+      const uint32_t end = base + RADIX_SLICE < hi ? (uint32_t)base + RADIX_SLICE : hi;
+      for (uint32_t j = (uint32_t)base + threadIdx.x; j < end; j += blockDim.x) atomicAdd(&msm_lds_hist[keys[j] & mask], 1u);
+      __syncthreads();
+      for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+        const uint32_t v = msm_lds_hist[b];
+        if (v) atomicAdd(&counts[((size_t)run << rbits) + b], v);
+      }
+      __syncthreads();
+    }
+  }
+}
+// one workgroup per long run
+__global__ void __launch_bounds__(1024) msm_radix_long_prefix(const uint32_t* __restrict__ run_off, uint32_t n_runs, uint32_t rbits, uint32_t total,
+                                                              const uint32_t* __restrict__ long_n, const uint32_t* __restrict__ long_list,
+                                                              const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                                              uint32_t* __restrict__ cursors) {
+  __shared__ uint32_t scan16[16];
+  __shared__ uint32_t carry;
+  const uint32_t nb = 1u << rbits, n_long = *long_n;
+  for (uint32_t k = blockIdx.x; k < n_long; k += gridDim.x) {
+    const uint32_t run = long_list[k], lo = run_off[run];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += blockDim.x) {
+      const uint32_t b = b0 + threadIdx.x;
+      const uint64_t bucket = ((uint64_t)run << rbits) + b;
+      const uint32_t v = (b < nb && bucket < total) ? counts[bucket] : 0u;
+      const uint32_t ex = block_exclusive_scan_1024(v, scan16) + carry;
+      if (b < nb && bucket < total) {
+        offsets[bucket] = lo + ex;
+        cursors[bucket] = lo + ex;
+      }
+      __syncthreads();
+      if (threadIdx.x == blockDim.x - 1) carry = ex + v;
+      __syncthreads();
+    }
+    if (run == n_runs - 1 && threadIdx.x == 0) offsets[total] = lo + carry;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(1024) msm_radix_long_scatter(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                               const uint32_t* __restrict__ run_off, uint32_t rbits,
+                                                               const uint32_t* __restrict__ long_n, const uint32_t* __restrict__ long_list,
+                                                               uint32_t* __restrict__ cursors, uint32_t* __restrict__ sorted) {
+  const uint32_t nb = 1u << rbits, mask = nb - 1, n_long = *long_n;
+  for (uint32_t k = blockIdx.y; k < n_long; k += gridDim.y) {
+    const uint32_t run = long_list[k], lo = run_off[run], hi = run_off[run + 1];
+    for (uint64_t base = lo + (uint64_t)blockIdx.x * RADIX_SLICE; base < hi; base += (uint64_t)gridDim.x * RADIX_SLICE) {
+      for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) msm_lds_hist[b] = 0;
+      __syncthreads();
+      const uint32_t end = base + RADIX_SLICE < hi ? (uint32_t)base + RADIX_SLICE : hi;
+      for (uint32_t j = (uint32_t)base + threadIdx.x; j < end; j += blockDim.x) atomicAdd(&msm_lds_hist[keys[j] & mask], 1u);
+      __syncthreads();
+      for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+        const uint32_t v = msm_lds_hist[b];
+        if (v) msm_lds_hist[b] = atomicAdd(&cursors[((size_t)run << rbits) + b], v);
+      }
+      __syncthreads();
+      for (uint32_t j = (uint32_t)base + threadIdx.x; j < end; j += blockDim.x) sorted[atomicAdd(&msm_lds_hist[keys[j] & mask], 1u)] = vals[j];
+      __syncthreads();
+    }
   }
 }
 
