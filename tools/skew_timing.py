@@ -10,6 +10,7 @@ from oracle import oracle as O
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--log-n", type=int, default=20)
+ap.add_argument("--window-bits", type=int, default=0, help="table width (0 = auto)")
 args = ap.parse_args()
 n = 1 << args.log_n
 Q = O.Q
@@ -37,7 +38,7 @@ sparse = np.zeros((n, 4), dtype=np.uint64); idx = np.random.default_rng(3).integ
 kinds["sparse_1pct"] = sparse
 for tables in (False, True):
     if tables:
-        ctx.srs_precompute(h, 0)
+        print(ctx.srs_precompute(h, args.window_bits))
     for name, sc in kinds.items():
         t = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
         torch.cuda.synchronize()
