@@ -773,7 +773,12 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
       store_proj28(complete ? &bucket_sum[g] : &partial[2 * (size_t)t + (run_start == p0 ? 0 : 1)], acc);
       acc = g1_identity28();
       run_start = p;
-      do { g++; g_end = offsets[g + 1]; } while (p >= g_end);    // skip empty buckets
+      g++;                                        // the next bucket, or -- when that one is empty -- a binary search: with
+      g_end = offsets[g + 1];                     // skewed scalars (all equal: 13 non-empty buckets of 2^19) a linear walk over
+      if (p >= g_end) {                           // the empty buckets took 40 000 dependent loads per boundary lane (14 ms)
+        g = bucket_of(offsets, total, p);
+        g_end = offsets[g + 1];
+      }
     }
     const uint32_t e = e_cur;
     const g1_affine28 q = q_next;
