@@ -103,7 +103,7 @@ int  bp_srs_free(bp_ctx* ctx, uint64_t srs_handle);
  * (windows x srs_len x 112 bytes: 1.9 GB at 2^20 points, 30 GB at 2^24).  With tables every window of an
  * MSM feeds one shared bucket set, so the bucket reduction and the Horner epilogue shrink from `windows`
  * passes to one; results are the same group element.  window_bits: 0 = chosen from srs_len (16 at 2^20 points, 20 -- thirteen
- * windows -- from 2^23 points), BP_SRS_TABLES_OFF = drop the tables, else 4..24 (above 16 the bucket sort is partitioned).  MSMs shorter than 2^window_bits / 8 scalars keep
+ * windows -- from 2^22 points), BP_SRS_TABLES_OFF = drop the tables, else 4..24 (above 16 the bucket sort is partitioned).  MSMs shorter than 2^window_bits / 8 scalars keep
  * using the table-free path.  The reference has no counterpart (its MSM recomputes from the raw points). */
 #define BP_SRS_TABLES_OFF 1u
 int  bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits);
