@@ -76,20 +76,7 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   plan.total = table_c ? plan.B : W * plan.B;
   plan.wbuckets = table_c ? 0 : plan.B;
   plan.wpoints = table_c ? (uint32_t)table_stride : 0;
-  plan.hist = plan.B < (1u << MSM_HIST_LOG) ? plan.B : 1u << MSM_HIST_LOG;
-  plan.parts = plan.B / plan.hist;
-  plan.wide = c > 16;
-  // record kernels: ~32 Ki records per workgroup, at least ~256 workgroups in all
-  {
-    // ~32 Ki records per workgroup, at least ~256 workgroups in all.  (Measured: one fat workgroup per run -- 262 144 records
-    // each at 2^24, c = 22 -- is 4-5x SLOWER per record: the 256 resident workgroups then stream from addresses exactly
-    // 2^19 records apart in lock step and camp on the same HBM channels.)
-    const uint64_t per_run = n / plan.parts + 1;
-    uint32_t rs = (uint32_t)(per_run >> 15), lo_rs = 256 / (W * plan.parts) + 1;
-    if (rs < lo_rs) rs = lo_rs;
-    while (rs > 1 && per_run / rs < 1024) rs >>= 1;
-    plan.rslices = env_u32("BP_MSM_RSLICES", rs);
-  }
+  plan.parts = plan.B <= (1u << MSM_HIST_LOG) ? 1 : plan.B >> MSM_HIST_LOG;
   const uint64_t entries = (uint64_t)W * n;
   // entries per lane: the kernel runs 2 waves per SIMD = 131072 lanes at a time and every lane does the same work, so the
   // lane count should land just under a whole number of such rounds -- 262144 lanes = two rounds.  (A power-of-two chunk
@@ -167,8 +154,6 @@ int msm_init_device(bp_ctx* ctx) {
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_planes_block<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_count, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_count_rec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_scatter_rec, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // these two also hold a few KiB of static LDS: the dynamic limit must leave room for it
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_final, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
@@ -208,10 +193,10 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   const uint32_t blocks_per_window = table_c ? 1u << l2 : ((B + plan.seg - 1) / plan.seg + 255) / 256;
   const uint32_t per_block = table_c ? l1 + 1 : 1, per_window = table_c ? plan.c : 1;     // slots
 
-  void* digits;
+  int16_t* digits = nullptr;
   uint32_t *counts, *offsets, *cursors, *sorted;
   proj28_slot *bucket_sum, *partial, *block_out, *window_sum;
-  BP_TRY(ws_get(ctx, "msm.digits", max_entries * (plan.wide ? sizeof(int32_t) : sizeof(int16_t)), &digits));
+  if (plan.parts == 1) BP_TRY(ws_get(ctx, "msm.digits", max_entries * sizeof(int16_t), (void**)&digits));
   BP_TRY(ws_get(ctx, "msm.counts", (size_t)total * 4 + 8, (void**)&counts));       // + [0] long-bucket counter, [1] scalar status: one memset
   BP_TRY(ws_get(ctx, "msm.offsets", ((size_t)total + 1) * 4, (void**)&offsets));
   BP_TRY(ws_get(ctx, "msm.cursors", (size_t)total * 4, (void**)&cursors));
@@ -234,29 +219,15 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   uint8_t* h_base;
   BP_TRY(pinned_get(ctx, MSM_SLOTS * slot_bytes, (void**)&h_base));
   proj28_slot* h_windows = reinterpret_cast<proj28_slot*>(h_base + (size_t)slot * slot_bytes);
-  // wide windows: partition workspaces
-  const uint32_t n_runs = W * plan.parts;
-  uint32_t *part_cnt = nullptr, *part_off = nullptr, *part_cur = nullptr, *rec_idx = nullptr;
-  uint16_t* rec_lo = nullptr;
-  if (plan.parts > 1) {
-    BP_TRY(ws_get(ctx, "msm.part_cnt", (size_t)n_runs * 4, (void**)&part_cnt));
-    BP_TRY(ws_get(ctx, "msm.part_off", ((size_t)n_runs + 1) * 4, (void**)&part_off));
-    BP_TRY(ws_get(ctx, "msm.part_cur", (size_t)n_runs * 4, (void**)&part_cur));
-    BP_TRY(ws_get(ctx, "msm.rec_idx", max_entries * 4, (void**)&rec_idx));
-    BP_TRY(ws_get(ctx, "msm.rec_lo", max_entries * 2, (void**)&rec_lo));
-  }
-
   hipStream_t st = ctx->stream;
   BP_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-  const size_t hist_bytes = (size_t)plan.hist * 4;
-  const unsigned hist_threads = plan.hist >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
+  const size_t hist_bytes = (size_t)B * 4;
+  const unsigned hist_threads = B >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
   const uint32_t n_tiles = (total + SCAN_TILE - 1) / SCAN_TILE;      // <= 4096 (total <= 2^24)
   // Bucket sort.  c <= 16: the one-histogram counting sort (msm_count / msm_scatter).  Wider windows: the partitioned (radix)
   // sort -- every store coalesced or L2-merged.  (At c = 16 the two cost the same, 0.34 vs 0.35 ms at 2^20: the radix sort
-  // moves 8-byte records three times.)  BP_MSM_SORT: 1 = radix everywhere, 2 = the per-(window, part) record sort of the
-  // first wide-window version (kept for the A/B table).
-  const uint32_t sort_env = env_u32("BP_MSM_SORT", 99);
-  const bool radix = sort_env == 1 || (plan.parts > 1 && sort_env != 2);
+  // moves 8-byte records three times.)  BP_MSM_SORT=1 forces the radix sort everywhere (tests, A/B).
+  const bool radix = plan.parts > 1 || env_u32("BP_MSM_SORT", 0) == 1;
   if (radix) {
     uint32_t kb = 0;
     while ((1ull << kb) < total) kb++;
@@ -319,31 +290,13 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
                          cursors, sorted);
     }
   } else {
-  BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4 + 8, st));
-  hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits, long_count + 1);
-  if (plan.parts == 1) {
-    hipLaunchKernelGGL(msm_count, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, (const int16_t*)digits, plan, counts);
+    BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4 + 8, st));
+    hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits, long_count + 1);
+    hipLaunchKernelGGL(msm_count, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, digits, plan, counts);
     hipLaunchKernelGGL(scan_tile_sums, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums);
     hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(256), 0, st, tile_sums, n_tiles, offsets + total);
     hipLaunchKernelGGL(scan_apply, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums, offsets, cursors);
-    hipLaunchKernelGGL(msm_scatter, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, (const int16_t*)digits, plan, cursors, sorted);
-  } else {
-    // partition every window's digits by the high bucket bits, then the counting sort per (window, part) run
-    const dim3 pgrid((unsigned)((n + PART_SLICE - 1) / PART_SLICE), W);
-    const uint32_t run_tiles = (n_runs + SCAN_TILE - 1) / SCAN_TILE;
-    BP_HIP(ctx, hipMemsetAsync(part_cnt, 0, (size_t)n_runs * 4, st));
-    hipLaunchKernelGGL(msm_part_count, pgrid, dim3(1024), 0, st, (const int32_t*)digits, plan, part_cnt);
-    hipLaunchKernelGGL(scan_tile_sums, dim3(run_tiles), dim3(256), 0, st, part_cnt, n_runs, tile_sums);
-    hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(256), 0, st, tile_sums, run_tiles, part_off + n_runs);
-    hipLaunchKernelGGL(scan_apply, dim3(run_tiles), dim3(256), 0, st, part_cnt, n_runs, tile_sums, part_off, part_cur);
-    hipLaunchKernelGGL(msm_part_scatter, pgrid, dim3(1024), 0, st, (const int32_t*)digits, plan, part_cur, rec_idx, rec_lo);
-    const dim3 rgrid(plan.rslices, n_runs);
-    hipLaunchKernelGGL(msm_count_rec, rgrid, dim3(1024), hist_bytes, st, rec_lo, part_off, plan, counts);
-    hipLaunchKernelGGL(scan_tile_sums, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums);
-    hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(256), 0, st, tile_sums, n_tiles, offsets + total);
-    hipLaunchKernelGGL(scan_apply, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums, offsets, cursors);
-    hipLaunchKernelGGL(msm_scatter_rec, rgrid, dim3(1024), hist_bytes, st, rec_idx, rec_lo, part_off, plan, cursors, sorted);
-  }
+    hipLaunchKernelGGL(msm_scatter, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, digits, plan, cursors, sorted);
   }
   BP_HIP(ctx, hipEventRecord(ctx->ev[1], st));
   const dim3 acc_grid((unsigned)((n_chunks + 255) / 256));

@@ -55,21 +55,15 @@ struct MsmPlan {
   uint32_t total;      // number of buckets: W * B, or B with tables
   uint32_t wbuckets;   // bucket-index stride per window: B, or 0 with tables
   uint32_t wpoints;    // point-index stride per window: 0, or the table row length with tables
-  // Windows wider than 16 bits (fixed-base tables only): one window's 2^(c-1) buckets no longer fit one LDS histogram, so
-  // the digits are first partitioned by the high bucket bits into `parts` runs per window (msm_part_*), and the counting
-  // sort runs per (window, part) over hist = 2^15 buckets (msm_count_rec / msm_scatter_rec).
+  // Windows wider than 16 bits (fixed-base tables only): one window's 2^(c-1) buckets no longer fit one LDS histogram
+  // (parts > 1); those MSMs take the partitioned (radix) bucket sort, section 4c.
   uint32_t parts;      // 1, or B >> 15
-  uint32_t hist;       // buckets per LDS histogram: min(B, 2^15)
-  uint32_t wide;       // digits are stored as int32 (c > 16) instead of int16
-  uint32_t rslices;    // workgroups per (window, part) run in the record kernels
 };
 
 // ---------------------------------------------------------------- 1. digits
 // fmt 0: 32-byte little-endian canonical (Scalar::to_bytes), 1: Montgomery limbs (Scalar::to_array)
 __global__ void __launch_bounds__(256) msm_digits(const fr_t* __restrict__ scalars, int fmt, MsmPlan plan,
-                                                   void* __restrict__ digits_out, uint32_t* __restrict__ status) {
-  int16_t* digits = static_cast<int16_t*>(digits_out);
-  int32_t* digits32 = static_cast<int32_t*>(digits_out);
+                                                   int16_t* __restrict__ digits, uint32_t* __restrict__ status) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= plan.n) return;
   fr_t k = scalars[i];
@@ -94,8 +88,7 @@ __global__ void __launch_bounds__(256) msm_digits(const fr_t* __restrict__ scala
     uint64_t two = (uint64_t)kp[word] | ((uint64_t)kp[word + 1] << 32);
     // windows below the top one are signed (bias already added); the top window keeps its small unsigned value
     int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (w + 1 < plan.W ? (int32_t)half : 0);
-    if (plan.wide) digits32[(size_t)w * plan.n + i] = d;
-    else digits[(size_t)w * plan.n + i] = (int16_t)d;
+    digits[(size_t)w * plan.n + i] = (int16_t)d;
   }
 }
 
@@ -236,7 +229,6 @@ __global__ void __launch_bounds__(1024) msm_scatter(const int16_t* __restrict__ 
   }
 }
 
-// ---------------------------------------------------------------- 4b. windows wider than 16 bits: partition, then sort per part
 // exclusive scan of one value per lane over a 1024-lane workgroup (16 waves); lds16: 16 words
 __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* lds16) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -253,118 +245,6 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
   __syncthreads();
   return base + incl - v;
 }
-constexpr uint32_t PART_SLICE = 8192, PART_PER_LANE = PART_SLICE / 1024, MSM_MAX_PARTS = 256;
-
-// part_cnt[w * parts + part] += number of non-zero digits of window w whose bucket lies in that part.  grid (ceil(n / PART_SLICE), W)
-__global__ void __launch_bounds__(1024) msm_part_count(const int32_t* __restrict__ digits, MsmPlan plan, uint32_t* __restrict__ part_cnt) {
-  __shared__ uint32_t h[MSM_MAX_PARTS];
-  const uint32_t w = blockIdx.y;
-  if (threadIdx.x < MSM_MAX_PARTS) h[threadIdx.x] = 0;
-  __syncthreads();
-  const int32_t* dw = digits + (size_t)w * plan.n;
-  const uint32_t lo = blockIdx.x * PART_SLICE, hi = lo + PART_SLICE < plan.n ? lo + PART_SLICE : plan.n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    const int32_t d = dw[i];
-    if (d != 0) atomicAdd(&h[digit_bucket(d) >> MSM_HIST_LOG], 1u);
-  }
-  __syncthreads();
-  if (threadIdx.x < plan.parts && h[threadIdx.x]) atomicAdd(&part_cnt[w * plan.parts + threadIdx.x], h[threadIdx.x]);
-}
-
-// Records of window w, grouped by part: rec_idx = point index | sign bit, rec_lo = low 15 bits of the bucket.  A workgroup
-// sorts its slice by part in LDS and writes every part's run with adjacent lanes on adjacent addresses (the digits of a
-// slice land in `parts` runs of ~PART_SLICE / parts records each; written lane by lane they would be isolated 4-byte stores).
-__global__ void __launch_bounds__(1024) msm_part_scatter(const int32_t* __restrict__ digits, MsmPlan plan, uint32_t* __restrict__ part_cursor,
-                                                         uint32_t* __restrict__ rec_idx, uint16_t* __restrict__ rec_lo) {
-  __shared__ uint32_t h[MSM_MAX_PARTS], lbase[MSM_MAX_PARTS], gbase[MSM_MAX_PARTS], scan16[16];
-  __shared__ uint32_t st_idx[PART_SLICE];
-  __shared__ uint16_t st_lo[PART_SLICE];
-  __shared__ uint8_t st_part[PART_SLICE];
-  const uint32_t w = blockIdx.y, parts = plan.parts;
-  if (threadIdx.x < MSM_MAX_PARTS) h[threadIdx.x] = 0;
-  __syncthreads();
-  const int32_t* dw = digits + (size_t)w * plan.n;
-  const uint32_t lo = blockIdx.x * PART_SLICE;
-  int32_t d[PART_PER_LANE];
-  uint32_t rank[PART_PER_LANE];
-#pragma unroll
-  for (uint32_t j = 0; j < PART_PER_LANE; j++) {
-    const uint32_t i = lo + j * 1024 + threadIdx.x;
-    d[j] = i < plan.n ? dw[i] : 0;
-    if (d[j] != 0) rank[j] = atomicAdd(&h[digit_bucket(d[j]) >> MSM_HIST_LOG], 1u);
-  }
-  __syncthreads();
-  const uint32_t mine = threadIdx.x < parts ? h[threadIdx.x] : 0u;
-  const uint32_t ex = block_exclusive_scan_1024(mine, scan16);
-  if (threadIdx.x < parts) {
-    lbase[threadIdx.x] = ex;
-    gbase[threadIdx.x] = mine ? atomicAdd(&part_cursor[w * parts + threadIdx.x], mine) : 0u;
-  }
-  __syncthreads();
-  const uint32_t live = lbase[parts - 1] + h[parts - 1];
-#pragma unroll
-  for (uint32_t j = 0; j < PART_PER_LANE; j++) {
-    if (d[j] != 0) {
-      const uint32_t b = digit_bucket(d[j]), part = b >> MSM_HIST_LOG, pos = lbase[part] + rank[j];
-      st_idx[pos] = (lo + j * 1024 + threadIdx.x) | (d[j] < 0 ? 0x80000000u : 0u);
-      st_lo[pos] = (uint16_t)(b & ((1u << MSM_HIST_LOG) - 1u));
-      st_part[pos] = (uint8_t)part;
-    }
-  }
-  __syncthreads();
-  for (uint32_t j = threadIdx.x; j < live; j += blockDim.x) {
-    const uint32_t part = st_part[j], g = gbase[part] + (j - lbase[part]);
-    rec_idx[g] = st_idx[j];
-    rec_lo[g] = st_lo[j];
-  }
-}
-
-// this workgroup's share [a, b) of run seg = (w, part): part_off[seg] .. part_off[seg + 1], cut into gridDim.x pieces
-__device__ __forceinline__ void rec_range(const uint32_t* __restrict__ part_off, uint32_t seg, uint32_t& a, uint32_t& b) {
-  const uint32_t lo = part_off[seg], hi = part_off[seg + 1];
-  const uint32_t per = (hi - lo + gridDim.x - 1) / gridDim.x;
-  a = lo + blockIdx.x * per;
-  if (a > hi) a = hi;
-  b = a + per < hi ? a + per : hi;
-}
-// counting sort per (window, part) over the records: the same two kernels as msm_count / msm_scatter.  grid (rslices, W * parts)
-__global__ void __launch_bounds__(1024) msm_count_rec(const uint16_t* __restrict__ rec_lo, const uint32_t* __restrict__ part_off, MsmPlan plan,
-                                                      uint32_t* __restrict__ counts) {
-  const uint32_t seg = blockIdx.y, w = seg / plan.parts, part = seg % plan.parts, H = plan.hist;
-  for (uint32_t b = threadIdx.x; b < H; b += blockDim.x) msm_lds_hist[b] = 0;
-  __syncthreads();
-  uint32_t a, e;
-  rec_range(part_off, seg, a, e);
-  for (uint32_t j = a + threadIdx.x; j < e; j += blockDim.x) atomicAdd(&msm_lds_hist[rec_lo[j]], 1u);
-  __syncthreads();
-  uint32_t* out = counts + (size_t)w * plan.wbuckets + ((size_t)part << MSM_HIST_LOG);
-  for (uint32_t b = threadIdx.x; b < H; b += blockDim.x) {
-    const uint32_t v = msm_lds_hist[b];
-    if (v) atomicAdd(&out[b], v);
-  }
-}
-__global__ void __launch_bounds__(1024) msm_scatter_rec(const uint32_t* __restrict__ rec_idx, const uint16_t* __restrict__ rec_lo,
-                                                        const uint32_t* __restrict__ part_off, MsmPlan plan, uint32_t* __restrict__ cursors,
-                                                        uint32_t* __restrict__ sorted) {
-  const uint32_t seg = blockIdx.y, w = seg / plan.parts, part = seg % plan.parts, H = plan.hist;
-  for (uint32_t b = threadIdx.x; b < H; b += blockDim.x) msm_lds_hist[b] = 0;
-  __syncthreads();
-  uint32_t a, e;
-  rec_range(part_off, seg, a, e);
-  for (uint32_t j = a + threadIdx.x; j < e; j += blockDim.x) atomicAdd(&msm_lds_hist[rec_lo[j]], 1u);
-  __syncthreads();
-  uint32_t* cur = cursors + (size_t)w * plan.wbuckets + ((size_t)part << MSM_HIST_LOG);
-  for (uint32_t b = threadIdx.x; b < H; b += blockDim.x) {
-    const uint32_t v = msm_lds_hist[b];
-    if (v) msm_lds_hist[b] = atomicAdd(&cur[b], v);
-  }
-  __syncthreads();
-  for (uint32_t j = a + threadIdx.x; j < e; j += blockDim.x) {
-    const uint32_t pos = atomicAdd(&msm_lds_hist[rec_lo[j]], 1u), r = rec_idx[j];
-    sorted[pos] = ((r & 0x7fffffffu) + w * plan.wpoints) | (r & 0x80000000u);
-  }
-}
-
 // ---------------------------------------------------------------- 4c. partitioned bucket sort (MSD radix, coalesced)
 // msm_scatter pays for every entry with an isolated 4-byte store: a workgroup's ~32 Ki entries land in ~32 Ki different bucket
 // regions, the lines leave L2 partially written, and HBM sees ~10x the payload (PMC WRITE_SIZE, round 1).  Here the entries are
