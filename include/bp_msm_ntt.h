@@ -127,7 +127,9 @@ int  bp_msm_g1_partial(bp_ctx* ctx, uint64_t srs_handle, size_t first, const voi
 /* One process per GPU: the same sum as bp_msm_g1_partial, left in HBM as an opaque BP_MSM_BLOB_BYTES record at d_blob (the
  * per-window / per-bit-plane partial sums of this rank, not yet combined).  The caller all-gathers the records of all
  * ranks on the device (RCCL) and hands the gathered host copy to bp_msm_blobs_combine: one collective and one
- * device-to-host copy per MSM, no host hop before the exchange. */
+ * device-to-host copy per MSM, no host hop before the exchange.  The record is complete when the call returns (it is
+ * written on the context's own stream, which the call waits for); work the caller still has pending on d_blob on another
+ * stream -- e.g. the zero fill of a freshly allocated torch tensor -- must have finished before the call. */
 #define BP_MSM_BLOB_BYTES 22592u      /* 64-byte header + 128 accumulator slots of 176 bytes */
 int  bp_msm_g1_blob_device(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
                            int scalars_on_device, void* d_blob);

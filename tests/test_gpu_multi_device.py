@@ -138,6 +138,7 @@ def test_blob_records_one_gather_one_copy():
     edges = [0, 13000, 13001, 40000]                          # ragged, one single-point shard
     for tables in (False, True):
         gathered = torch.zeros((3, _lib.MSM_BLOB_BYTES), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()          # torch fills on ITS stream; the library writes the record on the context's own
         for r in range(3):
             lo, hi = edges[r], edges[r + 1]
             h = ctx.srs_generate_progression(hi - lo, a + lo * d, d)
@@ -148,6 +149,7 @@ def test_blob_records_one_gather_one_copy():
     # an empty shard contributes the identity; a corrupt record and a bad scalar are refused
     h = ctx.srs_generate_progression(10, a, d)
     rec = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()              # (without this the zero fill can land after the record of an empty shard: seen 19 times in 25)
     ctx.msm_blob_device(h, rec.data_ptr(), sc[:0])
     assert bp.combine_blobs(rec.cpu().numpy().tobytes()) == M.enc96(None)
     with pytest.raises(bp.BpError):
