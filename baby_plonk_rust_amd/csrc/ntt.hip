@@ -132,7 +132,7 @@ int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, si
     fr_t* tmp;
     BP_TRY(ws_get(ctx, "ntt.tmp", batch * N * sizeof(fr_t), (void**)&tmp));
     auto tile_lds = [](uint32_t l, uint32_t cl, uint32_t lean) {
-      const uint32_t C = 1u << cl, tstride = ((1u << l) * (lean ? C : C + 1) + 1) & ~1u;
+      const uint32_t C = 1u << cl, tstride = ((1u << l) * ((lean || C == 1) ? C : C + 1) + 1) & ~1u;
       return ((size_t)tstride + (lean ? 0 : 1u << l)) * N29 * 4 + 16;
     };
     auto threads = [](uint32_t l, uint32_t cl, uint32_t lean) { return lean ? 512u : pass_threads(l, cl); };

@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* 
                                                          uint32_t k, uint32_t l, uint32_t s, uint32_t cl, uint32_t lean,
                                                          const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo,
                                                          const tw29_t* __restrict__ tw_hi, uint32_t h) {
-  const uint32_t C = 1u << cl, CP = lean ? C : C + 1;
+  const uint32_t C = 1u << cl, CP = (lean || C == 1) ? C : C + 1;        // a single column needs no row pad
   const uint32_t L = 1u << l, mlog = l + s, tstride = (L * CP + 1) & ~1u;      // even: the limb-pair arrays stay 8-byte aligned
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* 
 __global__ void __launch_bounds__(1024) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
                                                       size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
   const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l;
-  const uint32_t cl = plan.cl[P - 1], lean = plan.lean[P - 1], C = 1u << cl, CP = lean ? C : C + 1, tstride = (L * CP + 1) & ~1u;
+  const uint32_t cl = plan.cl[P - 1], lean = plan.lean[P - 1], C = 1u << cl, CP = (lean || C == 1) ? C : C + 1, tstride = (L * CP + 1) & ~1u;
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
   const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
