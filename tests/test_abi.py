@@ -143,3 +143,26 @@ def test_bucket_msm_rejects_window_parameters_the_reference_truncates():
     for b, c in ((256, 3), (128, 4), (256, 0), (255, 5)):
         with pytest.raises(bp.BpError):
             bp.BucketMSM.bucket_msm(b"", np.zeros((0, 4), dtype=np.uint64), b, c)
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_gpu():
+    """argument checks of the round-2 entry points that need no device: null pointers and bad counts are BP_ERR_INVALID_ARG (-1),
+    a device list on a machine without GPUs is BP_ERR_NO_DEVICE (-8) -- never a crash, never a silent fallback"""
+    import ctypes as C
+    import torch
+    lib = bp.load()
+    h = C.c_void_p()
+    ids = (C.c_int * 2)(0, 0)
+    assert lib.bp_init_multi(None, ids, 2) == -1
+    assert lib.bp_init_multi(C.byref(h), None, 2) == -1
+    assert lib.bp_init_multi(C.byref(h), ids, 0) == -1
+    assert lib.bp_init_multi(C.byref(h), ids, 65) == -1
+    if not torch.cuda.is_available():
+        assert lib.bp_init_multi(C.byref(h), ids, 2) == -8 and not h.value
+    assert lib.bp_ctx_devices(None, None, 0) == -1
+    out = np.zeros(96, dtype=np.uint8)
+    assert lib.bp_msm_blobs_combine(None, 1, out.ctypes.data) == -1
+    assert lib.bp_msm_blobs_combine(out.ctypes.data, 0, None) == -1
+    assert lib.bp_msm_g1_blob_device(None, 1, 0, None, 0, 1, 0, None) == -1
+    assert lib.bp_srs_load_projective144(None, None, 0, None) == -1
+    assert lib.bp_srs_export_projective144(None, 1, 0, 0, None) == -1

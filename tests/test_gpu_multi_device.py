@@ -180,3 +180,32 @@ def test_projective_image_seam():
     hm = many.srs_load_projective144(b"".join(p.tobytes() for p in pts))
     assert (many.srs_export_projective144(hm) == img).all()
     assert many.srs_export(hm) == ctx.srs_export(h) and many.msm(hm, sc) == ctx.msm(h, sc)
+
+
+def test_group_context_edges():
+    """a one-device list is an ordinary context; a bad device id fails like bp_init; records are refused on a group context (it
+    combines its own shards); handles of one context mean nothing to another"""
+    one = bp.Context([0])
+    assert one.n_shards() == 1
+    h = one.srs_generate(10, 5)
+    assert one.msm(h, O.splitmix_scalars(10, 1)) == bp.Context(0).msm(bp.default_context().srs_generate(10, 5) if False else bp.Context(0).srs_generate(10, 5), O.splitmix_scalars(10, 1))
+    with pytest.raises(bp.BpError) as e:
+        bp.Context([0, 4096])
+    assert e.value.code == -8
+    many = bp.Context([0, 0])
+    hm = many.srs_generate(100, 7)
+    rec = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    with pytest.raises(bp.BpError) as e:
+        many.msm_blob_device(hm, rec.data_ptr(), O.splitmix_scalars(100, 2))
+    assert e.value.code == -1
+    with pytest.raises(bp.BpError):
+        one.msm(hm + 1000, O.splitmix_scalars(10, 1))
+    # an out-of-range shard offset and an export past the end
+    with pytest.raises(bp.BpError):
+        many.msm_partial(hm, O.splitmix_scalars(4, 1), first=101)
+    with pytest.raises(bp.BpError):
+        many.srs_export(hm, 99, 2)
+    assert many.srs_export(hm, 100, 0) == b""
+    many.close()
+    one.close()
