@@ -191,8 +191,9 @@ def test_full_size_2p24_closed_form_both_paths(ctx):
 
 @pytest.mark.parametrize("c,log_n", [(17, 14), (18, 15), (19, 16), (20, 17), (21, 18), (22, 19), (24, 21)])
 def test_windows_wider_than_16_bits(ctx, c, log_n):
-    """fixed-base tables with c > 16: one window's 2^(c-1) buckets exceed the LDS histogram, so the digits are partitioned by
-    the high bucket bits first (msm_part_*), sorted per (window, part), and the bit-plane tree takes extra merge steps.
+    """fixed-base tables with c > 16: one window's 2^(c-1) buckets exceed the LDS histogram, so the entries go through the
+    partitioned (radix) bucket sort (msm_digit_records, msm_radix_*: runs of ~12 Ki entries sorted by one workgroup each, long
+    runs -- the narrow top window of c = 18, 19, 21 -- slice-parallel) and the bit-plane tree takes extra merge steps.
     Same bytes as the closed form and as the c <= 16 paths; every table row probed on its own; skewed and edge scalars."""
     n, a, d = (1 << log_n) + 13, Q - 98765, 0x0F1E2D3C4B5A6978
     h = ctx.srs_generate_progression(n, a, d)
