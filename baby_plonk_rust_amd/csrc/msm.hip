@@ -334,7 +334,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
       const uint32_t m = r < 7 ? r : 7, nodes = 1u << (r - m);
       const bool last = r == m;
       proj28_slot* out_nodes = last ? window_sum : tmp[flip];
-      hipLaunchKernelGGL(msm_planes_window, dim3(k + 1, nodes), dim3(128), 256 * sizeof(proj28_slot), st, in, k, m, out_nodes, long_count + 1,
+      hipLaunchKernelGGL(msm_planes_window, dim3(k + 1, nodes), dim3(512), 256 * sizeof(proj28_slot), st, in, k, m, out_nodes, long_count + 1,
                          offsets + total, last ? reinterpret_cast<uint32_t*>(window_sum + n_planes) : (uint32_t*)nullptr);
       in = out_nodes;
       flip ^= 1;

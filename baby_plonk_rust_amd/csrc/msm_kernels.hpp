@@ -864,22 +864,27 @@ constexpr uint32_t PLANES_BLOCK_LOG = 8;
 
 // cur: 2^levels leaves (one slot each).  Returns the buffer holding the root: A at [0], T_j at [1 + j].
 // planes == false: plain tree sum, only slot [0] of the result is meaningful.
+// COOP_TREE: every addition is shared by a group of COOP lanes (g1_add28_coop: ~1 600 instructions deep instead of ~6 600),
+// for trees with fewer pending additions than lanes / COOP -- the merge steps over a few hundred nodes (msm_planes_window:
+// 512 lanes = 64 groups, 7 levels in ~9 rounds of ~3 us instead of 7 x 12 us).  The wide block stage keeps one addition per
+// lane (cooperative additions there measured 156 us against 131: the wide levels pay twice the work).
+template <bool COOP_TREE>
 __device__ __forceinline__ proj28_slot* planes_tree(proj28_slot* cur, proj28_slot* nxt, uint32_t levels, bool planes) {
-  // one addition per lane.  (Measured alternatives: cooperative additions on every level, 1024 lanes: 156 + 90 us against
-  // 131 + 116 us here -- the wide levels pay twice the work; a hybrid of both forms in one kernel spills at 128 VGPRs.)
   for (uint32_t k = 0; k < levels; k++) {
     const uint32_t merges = 1u << (levels - k - 1);
     const uint32_t in_per = planes ? k + 1 : 1, out_per = planes ? k + 2 : 1;
-    for (uint32_t item = threadIdx.x; item < merges * out_per; item += blockDim.x) {
+    const uint32_t first = COOP_TREE ? threadIdx.x / COOP : threadIdx.x, step = COOP_TREE ? blockDim.x / COOP : blockDim.x;
+    for (uint32_t item = first; item < merges * out_per; item += step) {
       const uint32_t m = item / out_per, v = item - m * out_per;
       const proj28_slot* L = cur + (size_t)(2 * m) * in_per;
       const proj28_slot* R = L + in_per;
+      const bool writer = !COOP_TREE || (threadIdx.x & (COOP - 1)) == 0;
       if (v == k + 1) {
-        nxt[(size_t)m * out_per + v] = R[0];                   // T_k = A_r
+        if (writer) nxt[(size_t)m * out_per + v] = R[0];       // T_k = A_r
       } else {
         g1_proj28 a = load_proj28(&L[v]), b = load_proj28(&R[v]);
-        g1_add28(a, a, b);
-        store_proj28(&nxt[(size_t)m * out_per + v], a);
+        if (COOP_TREE) a = g1_add28_coop(a, b); else g1_add28(a, a, b);
+        if (writer) store_proj28(&nxt[(size_t)m * out_per + v], a);
       }
     }
     __syncthreads();
@@ -903,18 +908,18 @@ msm_planes_block(const uint32_t* __restrict__ offsets, MsmPlan plan, const proj2
     store_proj28(&buf[threadIdx.x], s);
   }
   __syncthreads();
-  const proj28_slot* root = planes_tree(buf, buf + nb, l1, true);
+  const proj28_slot* root = planes_tree<false>(buf, buf + nb, l1, true);
   if (threadIdx.x <= l1) out[((size_t)w * gridDim.x + blockIdx.x) * (l1 + 1) + threadIdx.x] = root[threadIdx.x];
 }
 
-// grid (l1 + 1, nodes out), 128 lanes (l2 <= 7).  Generic merge step of the tree: 2^l2 input nodes of (l1 + 1) values each (A and
+// grid (l1 + 1, nodes out), 512 lanes = 64 cooperative groups (l2 <= 7).  Generic merge step of the tree: 2^l2 input nodes of (l1 + 1) values each (A and
 // l1 planes) become one output node of (l1 + l2 + 1) values; blockIdx.y = output node ("window" w below).  The host applies
 // it repeatedly until one node is left (wide windows: 2^(c-1) buckets need more than the two stages of c <= 16).
 // Workgroup v folds value v of the 2^l2 input nodes of output node w:
 //   v = 0: the block sums A -> window A and the planes l1 .. l1 + l2 - 1 (the block index supplies the high bits);
 //   v > 0: plane v - 1, a plain sum over the blocks.
 // out[w * (l1 + l2 + 1) + {0: A, 1 + j: T_j}]
-__global__ void __launch_bounds__(128, 1)
+__global__ void __launch_bounds__(512, 1)
 msm_planes_window(const proj28_slot* __restrict__ in, uint32_t l1, uint32_t l2, proj28_slot* __restrict__ out,
                   const uint32_t* __restrict__ status_in, const uint32_t* __restrict__ entries_in, uint32_t* __restrict__ status_out) {
   proj28_slot* buf = reinterpret_cast<proj28_slot*>(msm_lds_tree);
@@ -923,7 +928,7 @@ msm_planes_window(const proj28_slot* __restrict__ in, uint32_t l1, uint32_t l2, 
   if (status_out && v == 0 && w == 0 && threadIdx.x == 0) { status_out[0] = *status_in; status_out[1] = *entries_in; }
   if (threadIdx.x < nblk) buf[threadIdx.x] = in[((size_t)w * nblk + threadIdx.x) * (l1 + 1) + v];
   __syncthreads();
-  const proj28_slot* root = planes_tree(buf, buf + 128, l2, v == 0);
+  const proj28_slot* root = planes_tree<true>(buf, buf + 128, l2, v == 0);
   if (v == 0) {
     if (threadIdx.x == 0) out[(size_t)w * c] = root[0];
     else if (threadIdx.x <= l2) out[(size_t)w * c + l1 + threadIdx.x] = root[threadIdx.x];     // T'_{j} -> plane l1 + j
