@@ -868,22 +868,25 @@ constexpr uint32_t PLANES_BLOCK_LOG = 8;
 // for trees with fewer pending additions than lanes / COOP -- the merge steps over a few hundred nodes (msm_planes_window:
 // 512 lanes = 64 groups, 7 levels in ~9 rounds of ~3 us instead of 7 x 12 us).  The wide block stage keeps one addition per
 // lane (cooperative additions there measured 156 us against 131: the wide levels pay twice the work).
-template <bool COOP_TREE>
+// MODE 0: one addition per lane on every level; 1: cooperative on every level; 2: cooperative on the levels that have at most
+// two rounds of it to do (the narrow upper levels of a block), one addition per lane below.
+template <int MODE>
 __device__ __forceinline__ proj28_slot* planes_tree(proj28_slot* cur, proj28_slot* nxt, uint32_t levels, bool planes) {
   for (uint32_t k = 0; k < levels; k++) {
     const uint32_t merges = 1u << (levels - k - 1);
-    const uint32_t in_per = planes ? k + 1 : 1, out_per = planes ? k + 2 : 1;
-    const uint32_t first = COOP_TREE ? threadIdx.x / COOP : threadIdx.x, step = COOP_TREE ? blockDim.x / COOP : blockDim.x;
-    for (uint32_t item = first; item < merges * out_per; item += step) {
+    const uint32_t in_per = planes ? k + 1 : 1, out_per = planes ? k + 2 : 1, items = merges * out_per;
+    const bool coop = MODE == 1 || (MODE == 2 && items * COOP <= 2 * blockDim.x);      // uniform over the workgroup
+    const uint32_t first = coop ? threadIdx.x / COOP : threadIdx.x, step = coop ? blockDim.x / COOP : blockDim.x;
+    const bool writer = !coop || (threadIdx.x & (COOP - 1)) == 0;
+    for (uint32_t item = first; item < items; item += step) {
       const uint32_t m = item / out_per, v = item - m * out_per;
       const proj28_slot* L = cur + (size_t)(2 * m) * in_per;
       const proj28_slot* R = L + in_per;
-      const bool writer = !COOP_TREE || (threadIdx.x & (COOP - 1)) == 0;
       if (v == k + 1) {
         if (writer) nxt[(size_t)m * out_per + v] = R[0];       // T_k = A_r
       } else {
         g1_proj28 a = load_proj28(&L[v]), b = load_proj28(&R[v]);
-        if (COOP_TREE) a = g1_add28_coop(a, b); else g1_add28(a, a, b);
+        if (MODE != 0 && coop) a = g1_add28_coop(a, b); else g1_add28(a, a, b);
         if (writer) store_proj28(&nxt[(size_t)m * out_per + v], a);
       }
     }
@@ -908,7 +911,7 @@ msm_planes_block(const uint32_t* __restrict__ offsets, MsmPlan plan, const proj2
     store_proj28(&buf[threadIdx.x], s);
   }
   __syncthreads();
-  const proj28_slot* root = planes_tree<false>(buf, buf + nb, l1, true);
+  const proj28_slot* root = planes_tree<THREADS == 256 ? 2 : 0>(buf, buf + nb, l1, true);
   if (threadIdx.x <= l1) out[((size_t)w * gridDim.x + blockIdx.x) * (l1 + 1) + threadIdx.x] = root[threadIdx.x];
 }
 
@@ -928,7 +931,7 @@ msm_planes_window(const proj28_slot* __restrict__ in, uint32_t l1, uint32_t l2, 
   if (status_out && v == 0 && w == 0 && threadIdx.x == 0) { status_out[0] = *status_in; status_out[1] = *entries_in; }
   if (threadIdx.x < nblk) buf[threadIdx.x] = in[((size_t)w * nblk + threadIdx.x) * (l1 + 1) + v];
   __syncthreads();
-  const proj28_slot* root = planes_tree<true>(buf, buf + 128, l2, v == 0);
+  const proj28_slot* root = planes_tree<1>(buf, buf + 128, l2, v == 0);
   if (v == 0) {
     if (threadIdx.x == 0) out[(size_t)w * c] = root[0];
     else if (threadIdx.x <= l2) out[(size_t)w * c + l1 + threadIdx.x] = root[threadIdx.x];     // T'_{j} -> plane l1 + j
