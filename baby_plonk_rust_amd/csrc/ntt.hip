@@ -61,7 +61,6 @@ static void make_ntt_plan(NttPlan& plan, uint32_t k) {
     if (plan.l[i] == 9) plan.cl[i] = env_ntt("BP_NTT_COLS_LOG_L9", plan.cl[i]);
     if (plan.l[i] == 10) plan.cl[i] = env_ntt("BP_NTT_COLS_LOG_L10", plan.cl[i]);
     if (plan.cl[i] > 3) plan.cl[i] = 3;
-    plan.lean[i] = env_ntt("BP_NTT_LEAN_L10", 0) && plan.l[i] == 10 ? 1 : 0;      // measured slower (0.181 vs 0.169 ms at 2^20): off
   }
   // experiment knob: BP_NTT_SPLIT="k:l1,l2,l3" replaces the digit widths of one size (widths must add up to k, each <= 10)
   if (const char* e = getenv("BP_NTT_SPLIT")) {
@@ -70,7 +69,7 @@ static void make_ntt_plan(NttPlan& plan, uint32_t k) {
     if (got >= 3 && kk == k && a + b + c == k && a <= 10 && b <= 10 && c <= 10 && a >= 1 && b >= 1) {
       plan.P = c ? 3 : 2;
       plan.l[0] = a; plan.l[1] = b; plan.l[2] = c;
-      for (uint32_t i = 0; i < plan.P; i++) { plan.cl[i] = ntt_tile_cols_log(plan.l[i]); plan.lean[i] = 0; }
+      for (uint32_t i = 0; i < plan.P; i++) plan.cl[i] = ntt_tile_cols_log(plan.l[i]);
     }
   }
   plan.h = (k + 1) / 2;
@@ -131,24 +130,23 @@ int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, si
     // ping-pong: pass 1 data -> tmp, middle passes in tmp, last pass tmp -> data
     fr_t* tmp;
     BP_TRY(ws_get(ctx, "ntt.tmp", batch * N * sizeof(fr_t), (void**)&tmp));
-    auto tile_lds = [](uint32_t l, uint32_t cl, uint32_t lean) {
-      const uint32_t C = 1u << cl, tstride = ((1u << l) * ((lean || C == 1) ? C : C + 1) + 1) & ~1u;
-      return ((size_t)tstride + (lean ? 0 : 1u << l)) * N29 * 4 + 16;
+    auto tile_lds = [](uint32_t l, uint32_t cl) {
+      const uint32_t C = 1u << cl, tstride = ((1u << l) * (C == 1 ? C : C + 1) + 1) & ~1u;
+      return ((size_t)tstride + (1u << l)) * N29 * 4 + 16;
     };
-    auto threads = [](uint32_t l, uint32_t cl, uint32_t lean) { return lean ? 512u : pass_threads(l, cl); };
     uint32_t s = k;
     for (uint32_t i = 0; i + 1 < plan.P; i++) {
       const uint32_t l = plan.l[i], cl = plan.cl[i];
       s -= l;
-      const size_t lds = tile_lds(l, cl, plan.lean[i]);
+      const size_t lds = tile_lds(l, cl);
       const tw29_t* hi = (inverse && i == 0) ? tab->hi_scaled : tab->hi;   // N^-1 rides on the first twiddle
-      hipLaunchKernelGGL(ntt_pass_strided, dim3((unsigned)(N >> (l + cl)), (unsigned)batch), dim3(threads(l, cl, plan.lean[i])), lds, st,
-                         i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp, tmp, i == 0 ? stride : N, N, k, l, s, cl, plan.lean[i], small, tab->lo, hi,
+      hipLaunchKernelGGL(ntt_pass_strided, dim3((unsigned)(N >> (l + cl)), (unsigned)batch), dim3(pass_threads(l, cl)), lds, st,
+                         i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp, tmp, i == 0 ? stride : N, N, k, l, s, cl, small, tab->lo, hi,
                          tab->h);
     }
     const uint32_t l = plan.l[plan.P - 1], cl = plan.cl[plan.P - 1];
-    const size_t lds = tile_lds(l, cl, plan.lean[plan.P - 1]);
-    hipLaunchKernelGGL(ntt_pass_last, dim3((unsigned)(N >> (l + cl)), (unsigned)batch), dim3(threads(l, cl, plan.lean[plan.P - 1])), lds, st,
+    const size_t lds = tile_lds(l, cl);
+    hipLaunchKernelGGL(ntt_pass_last, dim3((unsigned)(N >> (l + cl)), (unsigned)batch), dim3(pass_threads(l, cl)), lds, st,
                        (const fr_t*)tmp, d_data, N, stride, plan, small);
   }
   BP_HIP(ctx, hipGetLastError());

@@ -34,8 +34,6 @@ struct NttPlan {
   uint32_t P;            // passes
   uint32_t l[4];         // digit widths
   uint32_t cl[4];        // log2 of the tile's column count per pass (ntt_tile_cols_log unless overridden)
-  uint32_t lean[4];      // 1: tile without the row pad and stage twiddles read from the L1-resident table instead of LDS (l = 10:
-                         //    73.7 KiB per tile, two 512-lane workgroups per CU instead of one 1 024-lane workgroup with 147 KiB)
   uint32_t h;            // low table has 2^h entries, high table 2^(k-h)
 };
 
@@ -128,9 +126,7 @@ __device__ __forceinline__ void lds_fill_stage_twiddles(uint32_t* tw, uint32_t l
     lds_st29(tw, L, x, load_tw29(&small_tw[(j << s) << (NTT_SMALL_MAX_LOG - l)]));
   }
 }
-// tw_global != null: stage twiddles come from the w_1024^j table in HBM (24 KiB, L1-resident) instead of the LDS copy `tw`
-__device__ __forceinline__ void lds_ntt_dif(uint32_t* tile, uint32_t tstride, const uint32_t* tw, uint32_t l, uint32_t cl, uint32_t CP,
-                                            const tw29_t* __restrict__ tw_global = nullptr) {
+__device__ __forceinline__ void lds_ntt_dif(uint32_t* tile, uint32_t tstride, const uint32_t* tw, uint32_t l, uint32_t cl, uint32_t CP) {
   const uint32_t L = 1u << l, C = 1u << cl, nbf = (L >> 1) << cl;
   for (uint32_t s = 0; s < l; s++) {
     const uint32_t hl = l - s - 1, half = 1u << hl;
@@ -142,7 +138,7 @@ __device__ __forceinline__ void lds_ntt_dif(uint32_t* tile, uint32_t tstride, co
       if (half == 1) {                               // last stage: every twiddle is 1 (uniform branch)
         fr29_butterfly_notwiddle(u, v);
       } else {
-        fr29 w = tw_global ? load_tw29(&tw_global[(j << s) << (NTT_SMALL_MAX_LOG - l)]) : lds_ld29(tw, L, L - 2 * half + j);
+        fr29 w = lds_ld29(tw, L, L - 2 * half + j);
         fr29_butterfly(u, v, w);
       }
       lds_st29(tile, tstride, i0, u);
@@ -182,10 +178,10 @@ __device__ __forceinline__ fr29 twiddle_lookup(const tw29_t* __restrict__ lo, co
 //   l      digit width, s = bits below the digit, mlog = l + s, k = log2 N
 //   element (hi, d, r): address hi * 2^mlog + d * 2^s + r; tile = all d x C consecutive r.
 __global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride,
-                                                         uint32_t k, uint32_t l, uint32_t s, uint32_t cl, uint32_t lean,
+                                                         uint32_t k, uint32_t l, uint32_t s, uint32_t cl,
                                                          const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo,
                                                          const tw29_t* __restrict__ tw_hi, uint32_t h) {
-  const uint32_t C = 1u << cl, CP = (lean || C == 1) ? C : C + 1;        // a single column needs no row pad
+  const uint32_t C = 1u << cl, CP = C == 1 ? C : C + 1;        // a single column needs no row pad
   const uint32_t L = 1u << l, mlog = l + s, tstride = (L * CP + 1) & ~1u;      // even: the limb-pair arrays stay 8-byte aligned
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
@@ -197,9 +193,9 @@ __global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* 
     const uint32_t c = x & (C - 1), d = x >> cl;
     lds_st29(tile, tstride, d * CP + c, fr29_from_sat(load_fr(&src[soff + base + ((size_t)d << s) + c])));
   }
-  if (!lean) lds_fill_stage_twiddles(tw, l, small_tw);
+  lds_fill_stage_twiddles(tw, l, small_tw);
   __syncthreads();
-  lds_ntt_dif(tile, tstride, tw, l, cl, CP, lean ? small_tw : nullptr);
+  lds_ntt_dif(tile, tstride, tw, l, cl, CP);
   const uint32_t tshift = k - mlog;                 // w_M^x = w_N^(x << tshift)
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t c = x & (C - 1), e = x >> cl;
@@ -217,7 +213,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* 
 __global__ void __launch_bounds__(1024) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
                                                       size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
   const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l;
-  const uint32_t cl = plan.cl[P - 1], lean = plan.lean[P - 1], C = 1u << cl, CP = (lean || C == 1) ? C : C + 1, tstride = (L * CP + 1) & ~1u;
+  const uint32_t cl = plan.cl[P - 1], C = 1u << cl, CP = C == 1 ? C : C + 1, tstride = (L * CP + 1) & ~1u;
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
   const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
@@ -229,9 +225,9 @@ __global__ void __launch_bounds__(1024) ntt_pass_last(const fr_t* __restrict__ s
     const size_t row = ((size_t)(e1_0 + c) << midbits) + mid;
     lds_st29(tile, tstride, d * CP + c, fr29_from_sat(load_fr(&src[soff + (row << l) + d])));
   }
-  if (!lean) lds_fill_stage_twiddles(tw, l, small_tw);
+  lds_fill_stage_twiddles(tw, l, small_tw);
   __syncthreads();
-  lds_ntt_dif(tile, tstride, tw, l, cl, CP, lean ? small_tw : nullptr);
+  lds_ntt_dif(tile, tstride, tw, l, cl, CP);
   // digit-reverse mid: mid = e_2 * 2^(l_3+..+l_{P-1}) + ... + e_{P-1}; output wants e_2 lowest.
   uint32_t mid_out = 0, shift_out = 0, rem = midbits;
   for (uint32_t i = 1; i + 1 < P; i++) {
