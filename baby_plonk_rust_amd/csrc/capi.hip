@@ -287,6 +287,8 @@ void bp_destroy(bp_ctx* ctx) {
     (void)hipFree(kv.second.lo);
     (void)hipFree(kv.second.hi);
     if (kv.second.hi_scaled) (void)hipFree(kv.second.hi_scaled);
+    for (auto* f : kv.second.full)
+      if (f) (void)hipFree(f);
     if (kv.second.n_inv) (void)hipFree(kv.second.n_inv);
     if (kv.second.n_inv_tw) (void)hipFree(kv.second.n_inv_tw);
   }

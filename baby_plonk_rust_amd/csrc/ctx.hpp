@@ -52,6 +52,11 @@ struct NttTables {       // per (log_n, inverse); entries are 48-byte 29-bit-lim
   tw29_t* n_inv_tw = nullptr;  // N^-1 as a twiddle record (single-pass inverses)
   fr_t* n_inv = nullptr;       // N^-1, Montgomery (table builder input)
   uint32_t h = 0;
+  // inter-pass twiddles as full tables (one per strided pass): full[i][(e << s_i) + r] = w_M^(e r), M = 2^(l_i + s_i), N^-1
+  // folded into pass 0 of an inverse -- one product per element instead of lookup product + application.  Built on first
+  // use for N <= 2^24 (48 B per entry: 50 MB at 2^20, 805 MB at 2^24); nullptr = use lo/hi.
+  tw29_t* full[3] = {nullptr, nullptr, nullptr};
+  uint32_t full_ls[3] = {0, 0, 0};     // (l << 8) | s the table was built for (the experiment knobs can change the split)
 };
 
 }  // namespace bp

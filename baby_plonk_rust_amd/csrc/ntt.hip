@@ -140,9 +140,22 @@ int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, si
       s -= l;
       const size_t lds = tile_lds(l, cl);
       const tw29_t* hi = (inverse && i == 0) ? tab->hi_scaled : tab->hi;   // N^-1 rides on the first twiddle
+      if (tab->full[i] && tab->full_ls[i] != ((l << 8) | s)) {
+        BP_HIP(ctx, hipStreamSynchronize(st));
+        BP_HIP(ctx, hipFree(tab->full[i]));
+        tab->full[i] = nullptr;
+      }
+      if (!tab->full[i] && k <= env_ntt("BP_NTT_FULL_TWIDDLES_MAX_LOG", 24)) {      // built once per (N, direction, pass)
+        const size_t M = (size_t)1 << (l + s);
+        tab->full_ls[i] = (l << 8) | s;
+        BP_HIP(ctx, hipMalloc((void**)&tab->full[i], M * sizeof(tw29_t)));
+        hipLaunchKernelGGL(ntt_make_pass_table, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, tab->lo, hi, tab->h, l, s, k - (l + s),
+                           tab->full[i]);
+        BP_HIP(ctx, hipGetLastError());
+      }
       hipLaunchKernelGGL(ntt_pass_strided, dim3((unsigned)(N >> (l + cl)), (unsigned)batch), dim3(pass_threads(l, cl)), lds, st,
                          i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp, tmp, i == 0 ? stride : N, N, k, l, s, cl, small, tab->lo, hi,
-                         tab->h);
+                         tab->h, tab->full[i]);
     }
     const uint32_t l = plan.l[plan.P - 1], cl = plan.cl[plan.P - 1];
     const size_t lds = tile_lds(l, cl);

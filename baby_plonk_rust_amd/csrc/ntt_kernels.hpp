@@ -174,13 +174,23 @@ __device__ __forceinline__ fr29 twiddle_lookup(const tw29_t* __restrict__ lo, co
   return fr29_mul(load_tw29(&lo[E & ((1u << h) - 1u)]), load_tw29(&hi[E >> h]));
 }
 
+// full inter-pass twiddle table of one strided pass: out[(e << s) + r] = w_N^((e r) << tshift) (from the two-level table; hi may
+// carry N^-1), e < 2^l, r < 2^s
+__global__ void __launch_bounds__(256) ntt_make_pass_table(const tw29_t* __restrict__ lo, const tw29_t* __restrict__ hi, uint32_t h, uint32_t l,
+                                                            uint32_t s, uint32_t tshift, tw29_t* __restrict__ out) {
+  const size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >> (l + s)) return;
+  const uint64_t e = x >> s, r = x & (((size_t)1 << s) - 1);
+  store_tw29(&out[x], twiddle_lookup(lo, hi, h, (e * r) << tshift));
+}
+
 // Strided pass (every pass but the last).  grid.x = tiles, grid.y = batch.
 //   l      digit width, s = bits below the digit, mlog = l + s, k = log2 N
 //   element (hi, d, r): address hi * 2^mlog + d * 2^s + r; tile = all d x C consecutive r.
 __global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride,
                                                          uint32_t k, uint32_t l, uint32_t s, uint32_t cl,
                                                          const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo,
-                                                         const tw29_t* __restrict__ tw_hi, uint32_t h) {
+                                                         const tw29_t* __restrict__ tw_hi, uint32_t h, const tw29_t* __restrict__ tw_full) {
   const uint32_t C = 1u << cl, CP = C == 1 ? C : C + 1;        // a single column needs no row pad
   const uint32_t L = 1u << l, mlog = l + s, tstride = (L * CP + 1) & ~1u;      // even: the limb-pair arrays stay 8-byte aligned
   uint32_t* tile = ntt_lds_raw;
@@ -200,8 +210,12 @@ __global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* 
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t c = x & (C - 1), e = x >> cl;
     fr29 v = lds_ld29(tile, tstride, bitrev(e, l) * CP + c);
-    const uint64_t E = ((uint64_t)e * (r0 + c)) << tshift;
-    v = fr29_mul(v, twiddle_lookup(tw_lo, tw_hi, h, E));     // tw_hi may carry the folded N^-1 (first pass of an inverse)
+    if (tw_full) {                                             // precomputed w_M^(e r): one product (uniform branch)
+      v = fr29_mul(v, load_tw29(&tw_full[((size_t)e << s) + r0 + c]));
+    } else {
+      const uint64_t E = ((uint64_t)e * (r0 + c)) << tshift;
+      v = fr29_mul(v, twiddle_lookup(tw_lo, tw_hi, h, E));   // tw_hi may carry the folded N^-1 (first pass of an inverse)
+    }
     store_fr(&dst[doff + base + ((size_t)e << s) + c], fr29_to_sat_canonical(v));
   }
 }
