@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "ctx.hpp"
@@ -630,19 +631,36 @@ static int msm_all_shards(bp_ctx* ctx, uint64_t srs_handle, size_t first, const 
     rc = lift(ctx, sh[r], msm_shard_launch(sh[r], e, lo < hi ? lo - e->first : 0, sc, cnt, scalar_fmt, where, ctx->device, ctx->ev[4], 0, nullptr, &pend[r]));
     used[r] = rc == BP_OK;
   }
+  // every launched shard is waited for, also after a failure elsewhere.  With three or more shards the waits and the host
+  // epilogues (window sums -> Horner, ~0.1 ms each) run on one host thread per shard: eight in sequence would cost more than
+  // the shards' GPU time of a 2^20-point MSM split eight ways.
+  std::vector<g1_proj> part(sh.size());
+  std::vector<int> rcs(sh.size(), BP_OK);
+  auto finish_one = [&](size_t r) {
+    DeviceGuard guard(sh[r]->device);
+    rcs[r] = msm_finish(sh[r], pend[r], &part[r]);
+  };
+  {
+    std::vector<std::thread> workers;
+    size_t n_used = 0;
+    for (size_t r = 0; r < sh.size(); r++) n_used += used[r] ? 1 : 0;
+    for (size_t r = 1; r < sh.size(); r++)
+      if (used[r] && n_used >= 3) workers.emplace_back(finish_one, r);
+    for (size_t r = 0; r < sh.size(); r++)
+      if (used[r] && (r == 0 || n_used < 3)) finish_one(r);
+    for (auto& t : workers) t.join();
+  }
   g1_proj acc = g1_identity();
   float acc_ms = 0, dev_ms = 0;
   uint64_t adds = 0;
-  for (size_t r = 0; r < sh.size(); r++) {               // every launched shard is waited for, also after a failure elsewhere
+  for (size_t r = 0; r < sh.size(); r++) {
     if (!used[r]) continue;
-    DeviceGuard guard(sh[r]->device);
-    g1_proj part;
-    const int rc1 = lift(ctx, sh[r], msm_finish(sh[r], pend[r], &part));
+    const int rc1 = lift(ctx, sh[r], rcs[r]);
     if (rc1 != BP_OK) {
       if (rc == BP_OK) rc = rc1;
       continue;
     }
-    if (sh.size() == 1) acc = part; else g1_add(acc, acc, part);
+    if (sh.size() == 1) acc = part[r]; else g1_add(acc, acc, part[r]);
     acc_ms = std::max(acc_ms, sh[r]->msm_accumulate_ms);
     dev_ms = std::max(dev_ms, sh[r]->msm_total_ms);
     adds += sh[r]->msm_adds;
