@@ -603,9 +603,14 @@ static int msm_shard_launch(bp_ctx* m, SrsEntry* e, size_t local_first, const vo
   return msm_launch(m, e->d_points28 + local_first, n, d_scalars, fmt, 0, 0, slot, d_blob, pend);
 }
 
-// sum_{i < n} s_i P_{first + i} over every shard of the SRS: all shards are enqueued before the first one is waited for
-static int msm_all_shards(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
-                          int scalars_on_device, g1_proj* out) {
+// sum_{i < n} s_i P_{first + i} over every shard of the SRS, in two steps so that several such sums can be in flight:
+// launch enqueues every shard's whole pipeline (result slot `slot` of each member), finish waits and adds the partial sums.
+struct ShardedPending {
+  std::vector<MsmPending> pend;
+  std::vector<bool> used;
+};
+static int msm_all_shards_launch(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
+                                 int scalars_on_device, int slot, ShardedPending* sp) {
   SrsEntry* lead;
   BP_TRY(srs_find(ctx, srs_handle, &lead));
   if (first > lead->n_global) return fail(ctx, BP_ERR_INVALID_ARG, "SRS offset out of bounds", hipSuccess, __FILE__, __LINE__);
@@ -616,8 +621,8 @@ static int msm_all_shards(bp_ctx* ctx, uint64_t srs_handle, size_t first, const 
     DeviceGuard guard(ctx->device);
     BP_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   }
-  std::vector<MsmPending> pend(sh.size());
-  std::vector<bool> used(sh.size(), false);
+  sp->pend.assign(sh.size(), MsmPending());
+  sp->used.assign(sh.size(), false);
   int rc = BP_OK;
   for (size_t r = 0; r < sh.size() && rc == BP_OK; r++) {
     SrsEntry* e;
@@ -628,9 +633,16 @@ static int msm_all_shards(bp_ctx* ctx, uint64_t srs_handle, size_t first, const 
     const size_t cnt = lo < hi ? hi - lo : 0;
     const uint8_t* sc = (const uint8_t*)scalars + (lo < hi ? (lo - first) * sizeof(fr_t) : 0);
     const int where = !scalars_on_device ? 0 : (r == 0 ? 1 : 2);
-    rc = lift(ctx, sh[r], msm_shard_launch(sh[r], e, lo < hi ? lo - e->first : 0, sc, cnt, scalar_fmt, where, ctx->device, ctx->ev[4], 0, nullptr, &pend[r]));
-    used[r] = rc == BP_OK;
+    rc = lift(ctx, sh[r], msm_shard_launch(sh[r], e, lo < hi ? lo - e->first : 0, sc, cnt, scalar_fmt, where, ctx->device, ctx->ev[4], slot, nullptr,
+                                           &sp->pend[r]));
+    sp->used[r] = rc == BP_OK;
   }
+  return rc;               // the caller still finishes whatever was launched
+}
+static int msm_all_shards_finish(bp_ctx* ctx, const ShardedPending& sp, int rc, g1_proj* out) {
+  const std::vector<bp_ctx*> sh = shards_of(ctx);
+  const std::vector<MsmPending>& pend = sp.pend;
+  const std::vector<bool>& used = sp.used;
   // every launched shard is waited for, also after a failure elsewhere.  With three or more shards the waits and the host
   // epilogues (window sums -> Horner, ~0.1 ms each) run on one host thread per shard: eight in sequence would cost more than
   // the shards' GPU time of a 2^20-point MSM split eight ways.
@@ -674,6 +686,12 @@ static int msm_all_shards(bp_ctx* ctx, uint64_t srs_handle, size_t first, const 
   *out = acc;
   return BP_OK;
 }
+static int msm_all_shards(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
+                          int scalars_on_device, g1_proj* out) {
+  ShardedPending sp;
+  const int rc = msm_all_shards_launch(ctx, srs_handle, first, scalars, n_scalars, scalar_fmt, scalars_on_device, 0, &sp);
+  return msm_all_shards_finish(ctx, sp, rc, out);
+}
 
 }  // extern "C"
 
@@ -683,8 +701,19 @@ int commit_many(bp_ctx* ctx, uint64_t srs_handle, const fr_t* const* d_coeffs, c
   if (k <= 0) return BP_OK;
   SrsEntry* e;
   BP_TRY(srs_find(ctx, srs_handle, &e));
-  if (is_group(ctx) || k == 1) {            // a group context already keeps every GPU busy with one commitment's shards
-    for (int j = 0; j < k; j++) BP_TRY(msm_all_shards(ctx, srs_handle, 0, d_coeffs[j], n[j], BP_FR_MONT, 1, &out[j]));
+  if (is_group(ctx) || k == 1) {            // group: every member queues its shards of up to MSM_SLOTS commitments back to back
+    for (int base = 0; base < k; base += MSM_SLOTS) {
+      const int cnt = std::min((int)MSM_SLOTS, k - base);
+      ShardedPending sp[MSM_SLOTS];
+      int rcs[MSM_SLOTS], rc = BP_OK;
+      for (int j = 0; j < cnt; j++) rcs[j] = rc == BP_OK ? (rc = msm_all_shards_launch(ctx, srs_handle, 0, d_coeffs[base + j], n[base + j], BP_FR_MONT, 1, j, &sp[j])) : BP_OK;
+      for (int j = 0; j < cnt; j++) {
+        if (sp[j].pend.empty()) continue;
+        const int rc1 = msm_all_shards_finish(ctx, sp[j], rcs[j], &out[base + j]);
+        if (rc == BP_OK) rc = rc1;
+      }
+      if (rc != BP_OK) return rc;
+    }
     return BP_OK;
   }
   DeviceGuard guard(ctx->device);
