@@ -643,6 +643,7 @@ static int msm_all_shards_finish(bp_ctx* ctx, const ShardedPending& sp, int rc, 
   const std::vector<bp_ctx*> sh = shards_of(ctx);
   const std::vector<MsmPending>& pend = sp.pend;
   const std::vector<bool>& used = sp.used;
+  if (pend.size() != sh.size()) return rc != BP_OK ? rc : BP_ERR_INVALID_ARG;      // nothing was launched (bad handle / offset)
   // every launched shard is waited for, also after a failure elsewhere.  With three or more shards the waits and the host
   // epilogues (window sums -> Horner, ~0.1 ms each) run on one host thread per shard: eight in sequence would cost more than
   // the shards' GPU time of a 2^20-point MSM split eight ways.
