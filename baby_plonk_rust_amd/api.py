@@ -182,6 +182,10 @@ class Context:
             rc = self._lib.bp_msm_g1_blob_device(self._h, handle, first, s.ctypes.data, len(s), fmt, 0, d_blob_ptr)
         self.check(rc, "bp_msm_g1_blob_device")
 
+    def msm_blobs_sum_device(self, d_blobs_ptr, n_blobs, d_out_ptr):
+        """gathered records of equal layout -> one record, added slot by slot on the GPU (see bp_msm_blobs_sum_device)"""
+        self.check(self._lib.bp_msm_blobs_sum_device(self._h, d_blobs_ptr, n_blobs, d_out_ptr), "bp_msm_blobs_sum_device")
+
     def msm_stats(self):
         a, t, adds, c = C.c_float(), C.c_float(), C.c_uint64(), C.c_uint32()
         self.check(self._lib.bp_msm_last_stats(self._h, C.byref(a), C.byref(t), C.byref(adds), C.byref(c)), "bp_msm_last_stats")

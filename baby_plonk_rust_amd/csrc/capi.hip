@@ -788,6 +788,12 @@ int bp_msm_g1_blob_device(bp_ctx* ctx, uint64_t srs_handle, size_t first, const 
   return msm_finish(ctx, pend, nullptr);
 }
 
+int bp_msm_blobs_sum_device(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out_blob) {
+  if (!ctx || !d_blobs || !d_out_blob || n_blobs == 0 || n_blobs > 4096) return BP_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  return msm_blobs_sum_device_run(ctx, d_blobs, n_blobs, d_out_blob);
+}
+
 int bp_msm_blobs_combine(const void* blobs, size_t n_blobs, uint8_t out96[96]) {
   if (!out96 || (n_blobs && !blobs)) return BP_ERR_INVALID_ARG;
   g1_proj r;

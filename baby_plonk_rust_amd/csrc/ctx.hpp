@@ -144,6 +144,7 @@ struct MsmPending {
 int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
                int slot, void* d_blob, MsmPending* out);
 int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out);
+int msm_blobs_sum_device_run(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out);
 int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out);
 int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
             g1_proj* host_out);

@@ -442,6 +442,14 @@ int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out) {
   return BP_OK;
 }
 
+int msm_blobs_sum_device_run(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out) {
+  hipLaunchKernelGGL(msm_blob_sum, dim3((MSM_MAX_WINDOWS + 7) / 8), dim3(64), 0, ctx->stream, (const uint8_t*)d_blobs, (uint32_t)n_blobs,
+                     (uint32_t)BP_MSM_BLOB_BYTES, (uint8_t*)d_out);
+  BP_HIP(ctx, hipGetLastError());
+  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return BP_OK;
+}
+
 int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
             g1_proj* host_out) {
   MsmPending pend;

@@ -697,6 +697,38 @@ __global__ void __launch_bounds__(256) msm_write_blob(const proj28_slot* __restr
   }
 }
 
+// Sum of n records of equal layout, slot by slot, on the device (after the ranks' all-gather): one cooperative group of
+// COOP lanes per slot walks the n records.  Records that differ in layout leave magic = 0 in the output: the caller then
+// combines the gathered records on the host instead.  grid ceil(n_planes / 8), 64 lanes.
+__global__ void __launch_bounds__(64) msm_blob_sum(const uint8_t* __restrict__ blobs, uint32_t n_blobs, uint32_t blob_bytes,
+                                                   uint8_t* __restrict__ out) {
+  const MsmBlobHeader h0 = *reinterpret_cast<const MsmBlobHeader*>(blobs);
+  bool same = h0.magic == MSM_BLOB_MAGIC;
+  uint32_t status = 0, entries = 0;
+  for (uint32_t k = 0; k < n_blobs; k++) {
+    const MsmBlobHeader h = *reinterpret_cast<const MsmBlobHeader*>(blobs + (size_t)k * blob_bytes);
+    same = same && h.magic == h0.magic && h.c == h0.c && h.Wr == h0.Wr && h.n_planes == h0.n_planes && h.tables == h0.tables;
+    status |= h.status;
+    entries += h.entries;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    MsmBlobHeader ho = h0;
+    ho.magic = same ? MSM_BLOB_MAGIC : 0u;
+    ho.status = status;
+    ho.entries = entries;
+    *reinterpret_cast<MsmBlobHeader*>(out) = ho;
+  }
+  const uint32_t slot = blockIdx.x * (64 / COOP) + threadIdx.x / COOP;
+  if (!same || slot >= h0.n_planes) return;                  // uniform over a cooperative group
+  const proj28_slot* first = reinterpret_cast<const proj28_slot*>(blobs + sizeof(MsmBlobHeader)) + slot;
+  g1_proj28 acc = load_proj28(first);
+  for (uint32_t k = 1; k < n_blobs; k++) {
+    const g1_proj28 b = load_proj28(reinterpret_cast<const proj28_slot*>(blobs + (size_t)k * blob_bytes + sizeof(MsmBlobHeader)) + slot);
+    acc = g1_add28_coop(acc, b);
+  }
+  if ((threadIdx.x & (COOP - 1)) == 0) store_proj28(reinterpret_cast<proj28_slot*>(out + sizeof(MsmBlobHeader)) + slot, acc);
+}
+
 // ---------------------------------------------------------------- 6. fixup
 // Buckets that straddle chunk edges: add their partials.  Short chains (the common case: 2-3 partials) are
 // summed by one lane; a bucket cut into more than FIXUP_LONG chunks (skewed scalars, the narrow top window)

@@ -133,6 +133,11 @@ int  bp_msm_g1_partial(bp_ctx* ctx, uint64_t srs_handle, size_t first, const voi
 #define BP_MSM_BLOB_BYTES 22592u      /* 64-byte header + 128 accumulator slots of 176 bytes */
 int  bp_msm_g1_blob_device(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
                            int scalars_on_device, void* d_blob);
+/* Optional device-side pre-sum of the gathered records (n_blobs of them in HBM, BP_MSM_BLOB_BYTES apart): records of equal
+ * window layout -- the normal case -- are added slot by slot on the GPU into ONE record at d_out_blob, so only 22 KB cross to
+ * the host and the host does one Horner pass.  If the layouts differ the output record is marked invalid (bp_msm_blobs_combine
+ * rejects it with BP_ERR_INVALID_ARG) and the caller combines the gathered records on the host instead. */
+int  bp_msm_blobs_sum_device(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out_blob);
 /* Host-side: combine n_blobs records (host memory, BP_MSM_BLOB_BYTES apart) into the affine result.  Records with the
  * same window layout are added slot by slot before the one Horner pass (msm.rs:107-115). */
 int  bp_msm_blobs_combine(const void* blobs, size_t n_blobs, uint8_t out96[96]);

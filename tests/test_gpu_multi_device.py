@@ -146,6 +146,24 @@ def test_blob_records_one_gather_one_copy():
                 ctx.srs_precompute(h, 0)
             ctx.msm_blob_device(h, gathered[r].data_ptr(), sc[lo:hi])
         assert bp.combine_blobs(gathered.cpu().numpy().tobytes()) == want
+    # device-side pre-sum of gathered records (what ShardedMsm does after the all-gather): equal layouts -> one record;
+    # different layouts (the ragged shards above pick different window widths) -> marked invalid, the host combines all
+    out = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.msm_blobs_sum_device(gathered.data_ptr(), 3, out.data_ptr())
+    with pytest.raises(bp.BpError):
+        bp.combine_blobs(out.cpu().numpy().tobytes())
+    for tables in (False, True):
+        eq = torch.zeros((4, _lib.MSM_BLOB_BYTES), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        for r in range(4):
+            h = ctx.srs_generate_progression(10000, a + 10000 * r * d, d)
+            if tables:
+                ctx.srs_precompute(h, 11)
+            ctx.msm_blob_device(h, eq[r].data_ptr(), sc[10000 * r: 10000 * (r + 1)])
+        ctx.msm_blobs_sum_device(eq.data_ptr(), 4, out.data_ptr())
+        one = out.cpu().numpy().tobytes()
+        assert bp.combine_blobs(one) == bp.combine_blobs(eq.cpu().numpy().tobytes()) == want
     # an empty shard contributes the identity; a corrupt record and a bad scalar are refused
     h = ctx.srs_generate_progression(10, a, d)
     rec = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device="cuda:0")
