@@ -35,10 +35,12 @@ int ntt_init_tables(bp_ctx* ctx) {
   return BP_OK;
 }
 
-// one butterfly per lane per stage: 2^(l-1) * columns lanes, capped at 1024
+// one radix-4 group (four elements, two stages in registers) per lane: 2^(l-2) * columns lanes, capped at 512 (the kernels'
+// launch bound: a group needs ~140 registers).  BP_NTT_LANES_SHIFT = 1 doubles the lanes (they only help the load/store phases).
+static uint32_t env_ntt(const char* name, uint32_t dflt);
 static unsigned pass_threads(uint32_t l, uint32_t cl) {
-  unsigned t = (1u << (l - 1)) << cl;
-  return t > 1024 ? 1024 : (t < 64 ? 64 : t);
+  unsigned t = (((1u << l) << cl) >> 2) << env_ntt("BP_NTT_LANES_SHIFT", 0);
+  return t > 512 ? 512 : (t < 64 ? 64 : t);
 }
 static uint32_t env_ntt(const char* name, uint32_t dflt) {
   const char* v = getenv(name);
@@ -49,7 +51,9 @@ static void make_ntt_plan(NttPlan& plan, uint32_t k) {
   memset(&plan, 0, sizeof plan);
   plan.k = k;
   plan.P = k <= NTT_SMALL_MAX_LOG ? 1 : (k <= 2 * NTT_MAX_PASS_LOG ? 2 : 3);
-  if (plan.P == 2 && k >= env_ntt("BP_NTT_THREE_PASS_FROM", 99)) plan.P = 3;
+  // 2^20 as 7 + 7 + 6: small tiles keep three workgroups per CU busy (0.152 ms against 0.159 for 10 + 10, whose 74-KiB tiles
+  // leave one 512-lane workgroup per CU); 2^19 stays 10 + 9 (0.080 against 0.084).  profiles/r02_ntt_radix4_ab.txt
+  if (plan.P == 2 && k >= env_ntt("BP_NTT_THREE_PASS_FROM", 20)) plan.P = 3;
   uint32_t rem = k;
   for (uint32_t i = 0; i < plan.P; i++) {          // balanced widths, larger ones first
     uint32_t left = plan.P - i;

@@ -5,15 +5,16 @@
 // unique reduced residue, so an O(N log N) factorisation produces bit-identical output.
 //
 // Factorisation (decimation by index digits, "four-step" applied recursively):
-//   N = 2^k, k = l_1 + ... + l_P, each l_i <= 10 (two passes up to 2^20, three up to 2^28).  Input index n = (d_1, ..., d_P), d_1 most significant.
+//   N = 2^k, k = l_1 + ... + l_P, each l_i <= 10 (two passes up to 2^19, three from 2^20 to 2^28).  Input index n = (d_1, ..., d_P), d_1 most significant.
 //   pass i < P : length-2^(l_i) transforms over digit d_i (stride 2^(s_i), s_i = bits below d_i), all
 //                butterflies in LDS, then one multiply by w_{M}^(e_i * r) (M = 2^(l_i+s_i), r = low part)
 //                from a two-level precomputed table; written back in place of d_i.
 //   pass P     : length-2^(l_P) transforms over contiguous rows; the result goes to the digit-reversed
 //                position e_1 + 2^(l_1) e_2 + ..., i.e. natural order, written in coalesced runs.
 //   A tile is 2^l x C elements (C = 8 adjacent columns = 256-B global runs) staged in LDS limb-major
-//   (9 x 29-bit limbs per element, fr29.hpp: one v_mad_u64_u32 per partial product, lazy butterflies).
-//   HBM traffic: P reads + P writes of the vector (P = 1 up to 2^10, 2 up to 2^20, 3 beyond).
+//   (9 x 29-bit limbs per element, fr29.hpp: one v_mad_u64_u32 per partial product, lazy butterflies); a lane keeps a
+//   radix-4 group of four elements in registers over two stages (lds_ntt_dif).
+//   HBM traffic: P reads + P writes of the vector (P = 1 up to 2^10, 2 up to 2^19, 3 beyond).
 #pragma once
 #include "fr_io.hpp"
 #include "fr29.hpp"
@@ -126,23 +127,57 @@ __device__ __forceinline__ void lds_fill_stage_twiddles(uint32_t* tw, uint32_t l
     lds_st29(tw, L, x, load_tw29(&small_tw[(j << s) << (NTT_SMALL_MAX_LOG - l)]));
   }
 }
+// One radix-2 stage (only the first stage of an odd l), then PAIRS of stages with the four elements of a radix-4 group held in
+// registers: a group (rows j, j + quarter, j + half, j + half + quarter of a block of 2 * half rows) is closed under stages s
+// and s + 1, so a lane reads 4 elements + 3 twiddles and writes 4 elements per two stages where one butterfly per lane per stage
+// moved 4 + 2 + 4 per ONE stage -- half the LDS traffic and half the barriers; the multiplications are the same (a prime field has
+// no free fourth root of unity).  The last pair knows its twiddles: (1, i) then (1, 1): one product per group instead of two.
 __device__ __forceinline__ void lds_ntt_dif(uint32_t* tile, uint32_t tstride, const uint32_t* tw, uint32_t l, uint32_t cl, uint32_t CP) {
-  const uint32_t L = 1u << l, C = 1u << cl, nbf = (L >> 1) << cl;
-  for (uint32_t s = 0; s < l; s++) {
-    const uint32_t hl = l - s - 1, half = 1u << hl;
+  const uint32_t L = 1u << l, C = 1u << cl;
+  uint32_t s = 0;
+  if (l & 1) {
+    const uint32_t hl = l - 1, half = 1u << hl, nbf = half << cl;
     for (uint32_t b = threadIdx.x; b < nbf; b += blockDim.x) {
-      const uint32_t c = b & (C - 1), jp = b >> cl;
-      const uint32_t blk = jp >> hl, j = jp & (half - 1);
-      const uint32_t i0 = (blk * 2 * half + j) * CP + c, i1 = i0 + half * CP;
+      const uint32_t c = b & (C - 1), j = b >> cl;
+      const uint32_t i0 = j * CP + c, i1 = i0 + half * CP;
       fr29 u = lds_ld29(tile, tstride, i0), v = lds_ld29(tile, tstride, i1);
-      if (half == 1) {                               // last stage: every twiddle is 1 (uniform branch)
+      if (half == 1) {                               // l = 1: the twiddle is 1 (uniform branch)
         fr29_butterfly_notwiddle(u, v);
       } else {
-        fr29 w = lds_ld29(tw, L, L - 2 * half + j);
+        fr29 w = lds_ld29(tw, L, j);
         fr29_butterfly(u, v, w);
       }
       lds_st29(tile, tstride, i0, u);
       lds_st29(tile, tstride, i1, v);
+    }
+    __syncthreads();
+    s = 1;
+  }
+  const uint32_t nquad = (L >> 2) << cl;
+  for (; s < l; s += 2) {
+    const uint32_t hl = l - s - 1, half = 1u << hl, quarter = half >> 1;      // hl >= 1
+    for (uint32_t b = threadIdx.x; b < nquad; b += blockDim.x) {
+      const uint32_t c = b & (C - 1), jp = b >> cl;
+      const uint32_t blk = jp >> (hl - 1), j = jp & (quarter - 1);
+      const uint32_t i0 = (blk * 2 * half + j) * CP + c, i1 = i0 + quarter * CP, i2 = i0 + half * CP, i3 = i2 + quarter * CP;
+      fr29 a0 = lds_ld29(tile, tstride, i0), a1 = lds_ld29(tile, tstride, i1);
+      fr29 a2 = lds_ld29(tile, tstride, i2), a3 = lds_ld29(tile, tstride, i3);
+      if (quarter == 1) {                            // stages l-2 and l-1 (uniform branch): twiddles (1, w_4) and (1, 1)
+        fr29_butterfly_notwiddle(a0, a2);
+        fr29_butterfly(a1, a3, lds_ld29(tw, L, L - 3));
+        fr29_butterfly_notwiddle(a0, a1);
+        fr29_butterfly_notwiddle(a2, a3);
+      } else {
+        fr29_butterfly(a0, a2, lds_ld29(tw, L, L - 2 * half + j));
+        fr29_butterfly(a1, a3, lds_ld29(tw, L, L - 2 * half + j + quarter));
+        const fr29 w = lds_ld29(tw, L, L - 2 * quarter + j);
+        fr29_butterfly(a0, a1, w);
+        fr29_butterfly(a2, a3, w);
+      }
+      lds_st29(tile, tstride, i0, a0);
+      lds_st29(tile, tstride, i1, a1);
+      lds_st29(tile, tstride, i2, a2);
+      lds_st29(tile, tstride, i3, a3);
     }
     __syncthreads();
   }
@@ -187,7 +222,7 @@ __global__ void __launch_bounds__(256) ntt_make_pass_table(const tw29_t* __restr
 // Strided pass (every pass but the last).  grid.x = tiles, grid.y = batch.
 //   l      digit width, s = bits below the digit, mlog = l + s, k = log2 N
 //   element (hi, d, r): address hi * 2^mlog + d * 2^s + r; tile = all d x C consecutive r.
-__global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride,
+__global__ void __launch_bounds__(512) ntt_pass_strided(const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride,
                                                          uint32_t k, uint32_t l, uint32_t s, uint32_t cl,
                                                          const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo,
                                                          const tw29_t* __restrict__ tw_hi, uint32_t h, const tw29_t* __restrict__ tw_full) {
@@ -224,7 +259,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_strided(const fr_t* src, fr_t* 
 // Row (e_1, mid): src address (e_1 * 2^(s1 - l) + mid) * L + d, s1 = k - l_1.
 // Output index = e_1 + 2^(l_1) * rev_digits(mid) + 2^(k - l) * e_P, where mid = (e_2..e_{P-1}) is re-ordered
 // digit by digit (least significant output digit first).
-__global__ void __launch_bounds__(1024) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
+__global__ void __launch_bounds__(512) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
                                                       size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
   const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l;
   const uint32_t cl = plan.cl[P - 1], C = 1u << cl, CP = C == 1 ? C : C + 1, tstride = (L * CP + 1) & ~1u;
