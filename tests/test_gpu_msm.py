@@ -119,9 +119,10 @@ def test_bad_inputs(ctx):
     ctx.srs_free(h)
 
 
-@pytest.mark.parametrize("logn", [10, 14, 16])
+@pytest.mark.parametrize("logn", [10, 14, 16, 20])
 def test_vs_oracle_bucket_msm(ctx, logn):
-    """BASELINE configs[1]: 2^16-point MSM bit-exact vs the restated src/msm.rs CPU path"""
+    """BASELINE configs[1] and [2]: 2^16- and 2^20-point MSM bit-exact vs the restated src/msm.rs CPU path (the 2^20
+    case costs the oracle about a core-minute, spread over the box's threads)"""
     n = 1 << logn
     a, d = 0x1234567 + logn, 0xABCDEF01
     aff = O.points_progression(n, a, d)
@@ -131,6 +132,9 @@ def test_vs_oracle_bucket_msm(ctx, logn):
     want = O.g1_bytes96(O.bucket_msm(O.affine_to_proj(aff) if n <= 4096 else _bulk_proj(aff), sc, threads=NTHREADS))
     assert got == want
     assert got == M.enc96(M.ec_mul(oracle_dot(sc, a, d)))
+    if logn >= 16:                                                   # and through the fixed-base tables (the bench path)
+        ctx.srs_precompute(h)
+        assert ctx.msm(h, sc) == want and ctx.msm_stats()["tables"]
     ctx.srs_free(h)
 
 
