@@ -32,6 +32,8 @@ int ntt_init_tables(bp_ctx* ctx) {
   BP_HIP(ctx, hipFuncSetAttribute((const void*)ntt_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_last, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_strided_swz, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_last_swz, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   return BP_OK;
 }
 
@@ -127,16 +129,19 @@ int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, si
   const tw29_t* small = ctx->small_tw[inverse ? 1 : 0];
   BP_HIP(ctx, hipEventRecord(ctx->ev[0], st));
   if (plan.P == 1) {
-    const size_t lds = (N + N) * N29 * 4 + 16;
+    const size_t lds = (((N + 1) & ~(size_t)1) + ntt_tw_slots(k)) * N29 * 4 + 16;
     hipLaunchKernelGGL(ntt_small, dim3((unsigned)batch), dim3(256), lds, st, d_data, stride, k, small,
                        inverse ? tab->n_inv_tw : (const tw29_t*)nullptr);
   } else {
     // ping-pong: pass 1 data -> tmp, middle passes in tmp, last pass tmp -> data
     fr_t* tmp;
     BP_TRY(ws_get(ctx, "ntt.tmp", batch * N * sizeof(fr_t), (void**)&tmp));
-    auto tile_lds = [](uint32_t l, uint32_t cl) {
-      const uint32_t C = 1u << cl, tstride = ((1u << l) * (C == 1 ? C : C + 1) + 1) & ~1u;
-      return ((size_t)tstride + (1u << l)) * N29 * 4 + 16;
+    // 2^l x 8 tiles with l <= 7 run unpadded with swizzled rows (39 KiB at l = 7: four workgroups per CU); BP_NTT_SWIZZLE=0: padded
+    const bool swz_on = env_ntt("BP_NTT_SWIZZLE", 1) != 0;
+    auto swizzled = [&](uint32_t l, uint32_t cl) { return swz_on && cl == 3 && l <= 7 && l >= 2; };
+    auto tile_lds = [&](uint32_t l, uint32_t cl) {
+      const uint32_t C = 1u << cl, tstride = ((1u << l) * (swizzled(l, cl) || C == 1 ? C : C + 1) + 1) & ~1u;
+      return ((size_t)tstride + ntt_tw_slots(l)) * N29 * 4 + 16;
     };
     uint32_t s = k;
     for (uint32_t i = 0; i + 1 < plan.P; i++) {
@@ -157,14 +162,14 @@ int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, si
                            tab->full[i]);
         BP_HIP(ctx, hipGetLastError());
       }
-      hipLaunchKernelGGL(ntt_pass_strided, dim3((unsigned)(N >> (l + cl)), (unsigned)batch), dim3(pass_threads(l, cl)), lds, st,
-                         i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp, tmp, i == 0 ? stride : N, N, k, l, s, cl, small, tab->lo, hi,
-                         tab->h, tab->full[i]);
+      hipLaunchKernelGGL(swizzled(l, cl) ? ntt_pass_strided_swz : ntt_pass_strided, dim3((unsigned)(N >> (l + cl)), (unsigned)batch),
+                         dim3(pass_threads(l, cl)), lds, st, i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp, tmp, i == 0 ? stride : N, N, k, l, s,
+                         cl, small, tab->lo, hi, tab->h, tab->full[i]);
     }
     const uint32_t l = plan.l[plan.P - 1], cl = plan.cl[plan.P - 1];
     const size_t lds = tile_lds(l, cl);
-    hipLaunchKernelGGL(ntt_pass_last, dim3((unsigned)(N >> (l + cl)), (unsigned)batch), dim3(pass_threads(l, cl)), lds, st,
-                       (const fr_t*)tmp, d_data, N, stride, plan, small);
+    hipLaunchKernelGGL(swizzled(l, cl) ? ntt_pass_last_swz : ntt_pass_last, dim3((unsigned)(N >> (l + cl)), (unsigned)batch),
+                       dim3(pass_threads(l, cl)), lds, st, (const fr_t*)tmp, d_data, N, stride, plan, small);
   }
   BP_HIP(ctx, hipGetLastError());
   BP_HIP(ctx, hipEventRecord(ctx->ev[1], st));

@@ -112,19 +112,76 @@ __device__ __forceinline__ void fr29_butterfly_notwiddle(fr29& u, fr29& v) {
   u = s;
 }
 
-// In-LDS radix-2 decimation-in-frequency transform of length L = 2^l on every column of a tile [L][CP]
-// (CP = padded column count, C = 2^cl live columns).  Result of output index e sits at row bitrev(e).
-// tw (LDS, SoA with stride L): stage s reads its twiddles w_L^(j << s), j < half = L >> (s+1), from the contiguous
-// run starting at L - 2*half, so the lanes of a wave read adjacent words whatever the stage (a single table
-// indexed j << s puts every j of a late stage on one bank).
+// Tile addressing, element (row, c) of a tile of 2^l rows x C columns:
+//   padded   (SWZ = false): row * CP + c with CP = C + 1 (a single column needs no pad);
+//   swizzled (SWZ = true, C = 8 and l <= 7 only): no pad -- ((row ^ z(row)) << 3) | c, where z puts the parity of row bits
+//            2, 4, 6 into bit 0 and the parity of bits 3, 5 into bit 1.  Every access pattern of a pass (the fill: consecutive
+//            rows; a stage: rows j, j + 1, .. of one block, or -- last stage pairs -- rows 4 or 8 apart; the drain: rows in
+//            bit-reversed order, i.e. 64, 32, 96 apart) then spreads the 8-element groups of the lanes of one LDS cycle over
+//            different banks, which the one-element pad does not do for the drain (row pitch 72 B: rows 16 apart collide).
+//            Without the pad a 2^7 x 8 tile plus its stage twiddles is 39 KiB: FOUR workgroups per CU, so the 1 024 tiles of a
+//            2^20 pass run as one full round instead of three per CU and a last round of one per CU.
+template <bool SWZ>
+__device__ __forceinline__ uint32_t tile_at(uint32_t row, uint32_t c, uint32_t CP) {
+  if (SWZ) {
+    const uint32_t z = (__popc(row & 0x54u) & 1u) | ((__popc(row & 0x28u) & 1u) << 1);
+    return ((row ^ z) << 3) | c;
+  }
+  return row * CP + c;
+}
+__host__ __device__ constexpr uint32_t ntt_tw_slots(uint32_t l) { return (1u << l) < 4 ? 2u : (1u << l) >> 1; }
+
+// In-LDS radix-2 decimation-in-frequency transform of length L = 2^l on every column of a tile (C = 2^cl live columns).
+// Result of output index e sits at row bitrev(e).
+// tw (LDS, SoA with stride L/2): the twiddles of the stages s >= 1, w_L^(j << s), j < half = L >> (s+1), as the contiguous run
+// starting at L/2 - 2*half, so the lanes of a wave read adjacent words whatever the stage (a single table indexed j << s puts
+// every j of a late stage on one bank).  Stage 0 reads its L/2 twiddles straight from the 24-KiB global table (once per tile,
+// issued with the tile's first LDS reads): keeping them in LDS would cost as much again as all other stages together.
 __device__ __forceinline__ void lds_fill_stage_twiddles(uint32_t* tw, uint32_t l, const tw29_t* __restrict__ small_tw) {
-  const uint32_t L = 1u << l;
-  for (uint32_t x = threadIdx.x; x + 1 < L; x += blockDim.x) {
+  const uint32_t L = 1u << l, twn = ntt_tw_slots(l);
+  for (uint32_t x = (L >> 1) + threadIdx.x; x + 1 < L; x += blockDim.x) {
     // x in [L - 2*half, L - half)  <=>  stage s with half = L >> (s+1); j = x - (L - 2*half)
     const uint32_t rem = L - x;                           // in (half, 2*half]
     const uint32_t hl = 31 - __clz(rem - 1);              // floor(log2(rem - 1)) : half = 2^hl when rem - 1 >= half
     const uint32_t half = 1u << hl, s = l - hl - 1, j = x - (L - 2 * half);
-    lds_st29(tw, L, x, load_tw29(&small_tw[(j << s) << (NTT_SMALL_MAX_LOG - l)]));
+    lds_st29(tw, twn, x - (L >> 1), load_tw29(&small_tw[(j << s) << (NTT_SMALL_MAX_LOG - l)]));
+  }
+}
+// stages s and s + 1 on the radix-4 groups of a tile.  GLOBAL0: s = 0, whose twiddles come from the global table.
+template <bool SWZ, bool GLOBAL0>
+__device__ __forceinline__ void ntt_stage_pair(uint32_t* tile, uint32_t tstride, const uint32_t* tw, const tw29_t* __restrict__ small_tw,
+                                               uint32_t l, uint32_t cl, uint32_t CP, uint32_t s) {
+  const uint32_t L = 1u << l, C = 1u << cl, twn = ntt_tw_slots(l), g0 = NTT_SMALL_MAX_LOG - l, tw0 = L >> 1;
+  const uint32_t nquad = (L >> 2) << cl;
+  const uint32_t hl = l - s - 1, half = 1u << hl, quarter = half >> 1;      // hl >= 1
+  for (uint32_t b = threadIdx.x; b < nquad; b += blockDim.x) {
+    const uint32_t c = b & (C - 1), jp = b >> cl;
+    const uint32_t blk = jp >> (hl - 1), j = jp & (quarter - 1), r0 = blk * 2 * half + j;
+    const uint32_t i0 = tile_at<SWZ>(r0, c, CP), i1 = tile_at<SWZ>(r0 + quarter, c, CP);
+    const uint32_t i2 = tile_at<SWZ>(r0 + half, c, CP), i3 = tile_at<SWZ>(r0 + half + quarter, c, CP);
+    fr29 a0 = lds_ld29(tile, tstride, i0), a2 = lds_ld29(tile, tstride, i2);
+    if (quarter == 1) {                            // stages l-2 and l-1 (uniform branch): twiddles (1, w_4) and (1, 1)
+      fr29 a1 = lds_ld29(tile, tstride, i1), a3 = lds_ld29(tile, tstride, i3);
+      fr29_butterfly_notwiddle(a0, a2);
+      fr29_butterfly(a1, a3, GLOBAL0 ? load_tw29(&small_tw[1u << g0]) : lds_ld29(tw, twn, tw0 - 3));
+      fr29_butterfly_notwiddle(a0, a1);
+      fr29_butterfly_notwiddle(a2, a3);
+      lds_st29(tile, tstride, i0, a0);
+      lds_st29(tile, tstride, i1, a1);
+      lds_st29(tile, tstride, i2, a2);
+      lds_st29(tile, tstride, i3, a3);
+    } else {
+      fr29_butterfly(a0, a2, GLOBAL0 ? load_tw29(&small_tw[j << g0]) : lds_ld29(tw, twn, tw0 - 2 * half + j));
+      fr29 a1 = lds_ld29(tile, tstride, i1), a3 = lds_ld29(tile, tstride, i3);
+      fr29_butterfly(a1, a3, GLOBAL0 ? load_tw29(&small_tw[(j + quarter) << g0]) : lds_ld29(tw, twn, tw0 - 2 * half + j + quarter));
+      const fr29 w = lds_ld29(tw, twn, tw0 - 2 * quarter + j);
+      fr29_butterfly(a0, a1, w);
+      lds_st29(tile, tstride, i0, a0);
+      lds_st29(tile, tstride, i1, a1);
+      fr29_butterfly(a2, a3, w);
+      lds_st29(tile, tstride, i2, a2);
+      lds_st29(tile, tstride, i3, a3);
+    }
   }
 }
 // One radix-2 stage (only the first stage of an odd l), then PAIRS of stages with the four elements of a radix-4 group held in
@@ -132,20 +189,21 @@ __device__ __forceinline__ void lds_fill_stage_twiddles(uint32_t* tw, uint32_t l
 // and s + 1, so a lane reads 4 elements + 3 twiddles and writes 4 elements per two stages where one butterfly per lane per stage
 // moved 4 + 2 + 4 per ONE stage -- half the LDS traffic and half the barriers; the multiplications are the same (a prime field has
 // no free fourth root of unity).  The last pair knows its twiddles: (1, i) then (1, 1): one product per group instead of two.
-__device__ __forceinline__ void lds_ntt_dif(uint32_t* tile, uint32_t tstride, const uint32_t* tw, uint32_t l, uint32_t cl, uint32_t CP) {
-  const uint32_t L = 1u << l, C = 1u << cl;
+template <bool SWZ>
+__device__ __forceinline__ void lds_ntt_dif(uint32_t* tile, uint32_t tstride, const uint32_t* tw, const tw29_t* __restrict__ small_tw,
+                                            uint32_t l, uint32_t cl, uint32_t CP) {
+  const uint32_t C = 1u << cl, g0 = NTT_SMALL_MAX_LOG - l;
   uint32_t s = 0;
   if (l & 1) {
     const uint32_t hl = l - 1, half = 1u << hl, nbf = half << cl;
     for (uint32_t b = threadIdx.x; b < nbf; b += blockDim.x) {
       const uint32_t c = b & (C - 1), j = b >> cl;
-      const uint32_t i0 = j * CP + c, i1 = i0 + half * CP;
+      const uint32_t i0 = tile_at<SWZ>(j, c, CP), i1 = tile_at<SWZ>(j + half, c, CP);
       fr29 u = lds_ld29(tile, tstride, i0), v = lds_ld29(tile, tstride, i1);
       if (half == 1) {                               // l = 1: the twiddle is 1 (uniform branch)
         fr29_butterfly_notwiddle(u, v);
       } else {
-        fr29 w = lds_ld29(tw, L, j);
-        fr29_butterfly(u, v, w);
+        fr29_butterfly(u, v, load_tw29(&small_tw[j << g0]));
       }
       lds_st29(tile, tstride, i0, u);
       lds_st29(tile, tstride, i1, v);
@@ -153,32 +211,9 @@ __device__ __forceinline__ void lds_ntt_dif(uint32_t* tile, uint32_t tstride, co
     __syncthreads();
     s = 1;
   }
-  const uint32_t nquad = (L >> 2) << cl;
   for (; s < l; s += 2) {
-    const uint32_t hl = l - s - 1, half = 1u << hl, quarter = half >> 1;      // hl >= 1
-    for (uint32_t b = threadIdx.x; b < nquad; b += blockDim.x) {
-      const uint32_t c = b & (C - 1), jp = b >> cl;
-      const uint32_t blk = jp >> (hl - 1), j = jp & (quarter - 1);
-      const uint32_t i0 = (blk * 2 * half + j) * CP + c, i1 = i0 + quarter * CP, i2 = i0 + half * CP, i3 = i2 + quarter * CP;
-      fr29 a0 = lds_ld29(tile, tstride, i0), a1 = lds_ld29(tile, tstride, i1);
-      fr29 a2 = lds_ld29(tile, tstride, i2), a3 = lds_ld29(tile, tstride, i3);
-      if (quarter == 1) {                            // stages l-2 and l-1 (uniform branch): twiddles (1, w_4) and (1, 1)
-        fr29_butterfly_notwiddle(a0, a2);
-        fr29_butterfly(a1, a3, lds_ld29(tw, L, L - 3));
-        fr29_butterfly_notwiddle(a0, a1);
-        fr29_butterfly_notwiddle(a2, a3);
-      } else {
-        fr29_butterfly(a0, a2, lds_ld29(tw, L, L - 2 * half + j));
-        fr29_butterfly(a1, a3, lds_ld29(tw, L, L - 2 * half + j + quarter));
-        const fr29 w = lds_ld29(tw, L, L - 2 * quarter + j);
-        fr29_butterfly(a0, a1, w);
-        fr29_butterfly(a2, a3, w);
-      }
-      lds_st29(tile, tstride, i0, a0);
-      lds_st29(tile, tstride, i1, a1);
-      lds_st29(tile, tstride, i2, a2);
-      lds_st29(tile, tstride, i3, a3);
-    }
+    if (s == 0) ntt_stage_pair<SWZ, true>(tile, tstride, tw, small_tw, l, cl, CP, s);     // own code: the global reads of stage 0
+    else ntt_stage_pair<SWZ, false>(tile, tstride, tw, small_tw, l, cl, CP, s);          //   must not cost the other pairs registers
     __syncthreads();
   }
 }
@@ -187,14 +222,14 @@ __device__ __forceinline__ void lds_ntt_dif(uint32_t* tile, uint32_t tstride, co
 // small_tw[j] = w_1024^j (forward or inverse table), scale = N^-1 as a twiddle record, or null.
 __global__ void __launch_bounds__(256) ntt_small(fr_t* __restrict__ data, size_t stride, uint32_t k,
                                                   const tw29_t* __restrict__ small_tw, const tw29_t* scale) {
-  const uint32_t N = 1u << k, tstride = N;
+  const uint32_t N = 1u << k, tstride = (N + 1) & ~1u;
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
   fr_t* base = data + (size_t)blockIdx.x * stride;
   for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) lds_st29(tile, tstride, i, fr29_from_sat(load_fr(&base[i])));
   lds_fill_stage_twiddles(tw, k, small_tw);
   __syncthreads();
-  lds_ntt_dif(tile, tstride, tw, k, 0, 1);
+  lds_ntt_dif<false>(tile, tstride, tw, small_tw, k, 0, 1);
   fr29 sc;
   if (scale) sc = load_tw29(scale);
   for (uint32_t e = threadIdx.x; e < N; e += blockDim.x) {
@@ -222,11 +257,12 @@ __global__ void __launch_bounds__(256) ntt_make_pass_table(const tw29_t* __restr
 // Strided pass (every pass but the last).  grid.x = tiles, grid.y = batch.
 //   l      digit width, s = bits below the digit, mlog = l + s, k = log2 N
 //   element (hi, d, r): address hi * 2^mlog + d * 2^s + r; tile = all d x C consecutive r.
-__global__ void __launch_bounds__(512) ntt_pass_strided(const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride,
-                                                         uint32_t k, uint32_t l, uint32_t s, uint32_t cl,
-                                                         const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo,
-                                                         const tw29_t* __restrict__ tw_hi, uint32_t h, const tw29_t* __restrict__ tw_full) {
-  const uint32_t C = 1u << cl, CP = C == 1 ? C : C + 1;        // a single column needs no row pad
+template <bool SWZ>
+__device__ __forceinline__ void ntt_pass_strided_body(const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride,
+                                                      uint32_t k, uint32_t l, uint32_t s, uint32_t cl,
+                                                      const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo,
+                                                      const tw29_t* __restrict__ tw_hi, uint32_t h, const tw29_t* __restrict__ tw_full) {
+  const uint32_t C = 1u << cl, CP = SWZ || C == 1 ? C : C + 1;        // a single column needs no row pad
   const uint32_t L = 1u << l, mlog = l + s, tstride = (L * CP + 1) & ~1u;      // even: the limb-pair arrays stay 8-byte aligned
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
@@ -236,15 +272,15 @@ __global__ void __launch_bounds__(512) ntt_pass_strided(const fr_t* src, fr_t* d
   const size_t base = ((size_t)hi << mlog) + r0;
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t c = x & (C - 1), d = x >> cl;
-    lds_st29(tile, tstride, d * CP + c, fr29_from_sat(load_fr(&src[soff + base + ((size_t)d << s) + c])));
+    lds_st29(tile, tstride, tile_at<SWZ>(d, c, CP), fr29_from_sat(load_fr(&src[soff + base + ((size_t)d << s) + c])));
   }
   lds_fill_stage_twiddles(tw, l, small_tw);
   __syncthreads();
-  lds_ntt_dif(tile, tstride, tw, l, cl, CP);
+  lds_ntt_dif<SWZ>(tile, tstride, tw, small_tw, l, cl, CP);
   const uint32_t tshift = k - mlog;                 // w_M^x = w_N^(x << tshift)
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t c = x & (C - 1), e = x >> cl;
-    fr29 v = lds_ld29(tile, tstride, bitrev(e, l) * CP + c);
+    fr29 v = lds_ld29(tile, tstride, tile_at<SWZ>(bitrev(e, l), c, CP));
     if (tw_full) {                                             // precomputed w_M^(e r): one product (uniform branch)
       v = fr29_mul(v, load_tw29(&tw_full[((size_t)e << s) + r0 + c]));
     } else {
@@ -254,15 +290,25 @@ __global__ void __launch_bounds__(512) ntt_pass_strided(const fr_t* src, fr_t* d
     store_fr(&dst[doff + base + ((size_t)e << s) + c], fr29_to_sat_canonical(v));
   }
 }
+#define BP_NTT_STRIDED_ARGS const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride, uint32_t k, uint32_t l, uint32_t s, uint32_t cl, \
+    const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo, const tw29_t* __restrict__ tw_hi, uint32_t h, const tw29_t* __restrict__ tw_full
+__global__ void __launch_bounds__(512) ntt_pass_strided(BP_NTT_STRIDED_ARGS) {
+  ntt_pass_strided_body<false>(src, dst, src_stride, dst_stride, k, l, s, cl, small_tw, tw_lo, tw_hi, h, tw_full);
+}
+// 2^l x 8 tiles, l <= 7, unpadded: 256 lanes, four workgroups per CU = four waves per SIMD (at most 128 registers)
+__global__ void __launch_bounds__(256, 4) ntt_pass_strided_swz(BP_NTT_STRIDED_ARGS) {
+  ntt_pass_strided_body<true>(src, dst, src_stride, dst_stride, k, l, s, cl, small_tw, tw_lo, tw_hi, h, tw_full);
+}
 
 // Last pass: contiguous rows of length L = 2^l (l = l_P); tile = C rows with consecutive e_1.
 // Row (e_1, mid): src address (e_1 * 2^(s1 - l) + mid) * L + d, s1 = k - l_1.
 // Output index = e_1 + 2^(l_1) * rev_digits(mid) + 2^(k - l) * e_P, where mid = (e_2..e_{P-1}) is re-ordered
 // digit by digit (least significant output digit first).
-__global__ void __launch_bounds__(512) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
-                                                      size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
+template <bool SWZ>
+__device__ __forceinline__ void ntt_pass_last_body(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
+                                                   size_t dst_stride, const NttPlan& plan, const tw29_t* __restrict__ small_tw) {
   const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l;
-  const uint32_t cl = plan.cl[P - 1], C = 1u << cl, CP = C == 1 ? C : C + 1, tstride = (L * CP + 1) & ~1u;
+  const uint32_t cl = plan.cl[P - 1], C = 1u << cl, CP = SWZ || C == 1 ? C : C + 1, tstride = (L * CP + 1) & ~1u;
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
   const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
@@ -272,11 +318,11 @@ __global__ void __launch_bounds__(512) ntt_pass_last(const fr_t* __restrict__ sr
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t d = x % L, c = x / L;
     const size_t row = ((size_t)(e1_0 + c) << midbits) + mid;
-    lds_st29(tile, tstride, d * CP + c, fr29_from_sat(load_fr(&src[soff + (row << l) + d])));
+    lds_st29(tile, tstride, tile_at<SWZ>(d, c, CP), fr29_from_sat(load_fr(&src[soff + (row << l) + d])));
   }
   lds_fill_stage_twiddles(tw, l, small_tw);
   __syncthreads();
-  lds_ntt_dif(tile, tstride, tw, l, cl, CP);
+  lds_ntt_dif<SWZ>(tile, tstride, tw, small_tw, l, cl, CP);
   // digit-reverse mid: mid = e_2 * 2^(l_3+..+l_{P-1}) + ... + e_{P-1}; output wants e_2 lowest.
   uint32_t mid_out = 0, shift_out = 0, rem = midbits;
   for (uint32_t i = 1; i + 1 < P; i++) {
@@ -288,9 +334,17 @@ __global__ void __launch_bounds__(512) ntt_pass_last(const fr_t* __restrict__ sr
   const size_t obase = ((size_t)mid_out << l1) + e1_0;
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t c = x & (C - 1), e = x >> cl;
-    fr29 v = lds_ld29(tile, tstride, bitrev(e, l) * CP + c);
+    fr29 v = lds_ld29(tile, tstride, tile_at<SWZ>(bitrev(e, l), c, CP));
     store_fr(&dst[doff + obase + ((size_t)e << (k - l)) + c], fr29_to_sat_canonical(v));
   }
+}
+__global__ void __launch_bounds__(512) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
+                                                     size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
+  ntt_pass_last_body<false>(src, dst, src_stride, dst_stride, plan, small_tw);
+}
+__global__ void __launch_bounds__(256, 4) ntt_pass_last_swz(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
+                                                            size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
+  ntt_pass_last_body<true>(src, dst, src_stride, dst_stride, plan, small_tw);
 }
 
 // ---- element-wise helpers used by the Polynomial layer (src/polynomial.rs) -------------------------
