@@ -136,7 +136,7 @@ int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, si
     // ping-pong: pass 1 data -> tmp, middle passes in tmp, last pass tmp -> data
     fr_t* tmp;
     BP_TRY(ws_get(ctx, "ntt.tmp", batch * N * sizeof(fr_t), (void**)&tmp));
-    // 2^l x 8 tiles with l <= 7 run unpadded with swizzled rows (39 KiB at l = 7: four workgroups per CU); BP_NTT_SWIZZLE=0: padded
+    // 2^l x 8 tiles with l <= 7 run unpadded with swizzled rows (39 KiB at l = 7, bank-conflict-free drain); BP_NTT_SWIZZLE=0: padded
     const bool swz_on = env_ntt("BP_NTT_SWIZZLE", 1) != 0;
     auto swizzled = [&](uint32_t l, uint32_t cl) { return swz_on && cl == 3 && l <= 7 && l >= 2; };
     auto tile_lds = [&](uint32_t l, uint32_t cl) {

@@ -119,8 +119,9 @@ __device__ __forceinline__ void fr29_butterfly_notwiddle(fr29& u, fr29& v) {
 //            rows; a stage: rows j, j + 1, .. of one block, or -- last stage pairs -- rows 4 or 8 apart; the drain: rows in
 //            bit-reversed order, i.e. 64, 32, 96 apart) then spreads the 8-element groups of the lanes of one LDS cycle over
 //            different banks, which the one-element pad does not do for the drain (row pitch 72 B: rows 16 apart collide).
-//            Without the pad a 2^7 x 8 tile plus its stage twiddles is 39 KiB: FOUR workgroups per CU, so the 1 024 tiles of a
-//            2^20 pass run as one full round instead of three per CU and a last round of one per CU.
+//            Without the pad a 2^7 x 8 tile plus its stage twiddles is 39 KiB (four would fit a CU; the butterflies' 129 registers
+//            allow three workgroups = three waves per SIMD, and tools/ntt_occupancy_probe.sh shows the pass time does not depend on
+//            the residency: T = 10 us + 11 us per tile per CU with one, three or four resident -- the VALU is the bound).
 template <bool SWZ>
 __device__ __forceinline__ uint32_t tile_at(uint32_t row, uint32_t c, uint32_t CP) {
   if (SWZ) {
@@ -171,6 +172,7 @@ __device__ __forceinline__ void ntt_stage_pair(uint32_t* tile, uint32_t tstride,
       lds_st29(tile, tstride, i2, a2);
       lds_st29(tile, tstride, i3, a3);
     } else {
+#ifdef BP_NTT_PLAIN_BUTTERFLIES
       fr29_butterfly(a0, a2, GLOBAL0 ? load_tw29(&small_tw[j << g0]) : lds_ld29(tw, twn, tw0 - 2 * half + j));
       fr29 a1 = lds_ld29(tile, tstride, i1), a3 = lds_ld29(tile, tstride, i3);
       fr29_butterfly(a1, a3, GLOBAL0 ? load_tw29(&small_tw[(j + quarter) << g0]) : lds_ld29(tw, twn, tw0 - 2 * half + j + quarter));
@@ -181,6 +183,24 @@ __device__ __forceinline__ void ntt_stage_pair(uint32_t* tile, uint32_t tstride,
       fr29_butterfly(a2, a3, w);
       lds_st29(tile, tstride, i2, a2);
       lds_st29(tile, tstride, i3, a3);
+#else
+      // fr29_radix4 written out so that every value dies as early as possible (the kernels live within 128 registers):
+      // first-stage sums stay unreduced (limbs < 2^30), their sum is reduced once, their difference enters the product over 8q
+      fr29 a1 = lds_ld29(tile, tstride, i1), a3 = lds_ld29(tile, tstride, i3);
+      fr29 s02, s13;
+#pragma unroll
+      for (int i = 0; i < N29; i++) { s02.l[i] = a0.l[i] + a2.l[i]; s13.l[i] = a1.l[i] + a3.l[i]; }
+      fr29 d02 = fr29_mul(fr29_sub_lazy(a0, a2), GLOBAL0 ? load_tw29(&small_tw[j << g0]) : lds_ld29(tw, twn, tw0 - 2 * half + j));
+      fr29 d13 = fr29_mul(fr29_sub_lazy(a1, a3), GLOBAL0 ? load_tw29(&small_tw[(j + quarter) << g0]) : lds_ld29(tw, twn, tw0 - 2 * half + j + quarter));
+      const fr29 w = lds_ld29(tw, twn, tw0 - 2 * quarter + j);
+      lds_st29(tile, tstride, i2, fr29_add_lazy(d02, d13));
+      lds_st29(tile, tstride, i3, fr29_mul(fr29_sub_lazy(d02, d13), w));
+      fr29 x, d;
+#pragma unroll
+      for (int i = 0; i < N29; i++) { x.l[i] = s02.l[i] + s13.l[i]; d.l[i] = s02.l[i] + (Q29::eight_q_spread(i) - s13.l[i]); }
+      lds_st29(tile, tstride, i0, fr29_reduce8(x));
+      lds_st29(tile, tstride, i1, fr29_mul(d, w));
+#endif
     }
   }
 }
@@ -295,8 +315,8 @@ __device__ __forceinline__ void ntt_pass_strided_body(const fr_t* src, fr_t* dst
 __global__ void __launch_bounds__(512) ntt_pass_strided(BP_NTT_STRIDED_ARGS) {
   ntt_pass_strided_body<false>(src, dst, src_stride, dst_stride, k, l, s, cl, small_tw, tw_lo, tw_hi, h, tw_full);
 }
-// 2^l x 8 tiles, l <= 7, unpadded: 256 lanes, four workgroups per CU = four waves per SIMD (at most 128 registers)
-__global__ void __launch_bounds__(256, 4) ntt_pass_strided_swz(BP_NTT_STRIDED_ARGS) {
+// 2^l x 8 tiles, l <= 7, unpadded with swizzled rows: 256 lanes, three workgroups per CU
+__global__ void __launch_bounds__(256, 3) ntt_pass_strided_swz(BP_NTT_STRIDED_ARGS) {
   ntt_pass_strided_body<true>(src, dst, src_stride, dst_stride, k, l, s, cl, small_tw, tw_lo, tw_hi, h, tw_full);
 }
 
@@ -342,7 +362,7 @@ __global__ void __launch_bounds__(512) ntt_pass_last(const fr_t* __restrict__ sr
                                                      size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
   ntt_pass_last_body<false>(src, dst, src_stride, dst_stride, plan, small_tw);
 }
-__global__ void __launch_bounds__(256, 4) ntt_pass_last_swz(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
+__global__ void __launch_bounds__(256, 3) ntt_pass_last_swz(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
                                                             size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
   ntt_pass_last_body<true>(src, dst, src_stride, dst_stride, plan, small_tw);
 }

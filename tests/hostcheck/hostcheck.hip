@@ -85,6 +85,9 @@ void hc_g1_28_identity(uint32_t* r) { g1_proj out = g1_proj_from_28(g1_identity2
 }
 
 // ---- unsaturated 9 x 29 scalar field (fr29.hpp) ----
+#include <stdio.h>
+#include <stdlib.h>
+#define BP_FR29_CHECK(cond) do { if (!(cond)) { fprintf(stderr, "fr29 bound violated: %s\n", #cond); abort(); } } while (0)
 #include "../../baby_plonk_rust_amd/csrc/fr29.hpp"
 extern "C" {
 // (u, v) in the reference's Montgomery form, w in Montgomery form; outputs canonical Montgomery: u+v, (u-v)*w after `reps` chained butterflies
@@ -94,6 +97,24 @@ void hc_fr29_butterfly(uint32_t* ru, uint32_t* rv, const uint32_t* u_in, const u
   for (int i = 0; i < reps; i++) fr29_butterfly(a, b, t);
   fr_t x = fr29_to_sat_canonical(a), y = fr29_to_sat_canonical(b);
   memcpy(ru, &x, 32); memcpy(rv, &y, 32);
+}
+// radix-4 group: a[4] any 256-bit values < 2q (NOT necessarily canonical), w[3] Montgomery twiddles; lazy != 0: fr29_radix4, else four
+// fr29_butterfly calls; outputs canonical
+void hc_fr29_radix4(uint32_t* out, const uint32_t* a_in, const uint32_t* w_in, int lazy) {
+  fr29 a[4], w[3];
+  for (int i = 0; i < 4; i++) { fr_t t; memcpy(&t, a_in + 8 * i, 32); a[i] = fr29_from_sat(t); }
+  for (int i = 0; i < 3; i++) { fr_t t; memcpy(&t, w_in + 8 * i, 32); w[i] = fr29_twiddle_from_mont(t); }
+  if (lazy) {
+    fr29_radix4(a[0], a[1], a[2], a[3], w[0], w[1], w[2]);
+  } else {
+    fr29_butterfly(a[0], a[2], w[0]); fr29_butterfly(a[1], a[3], w[1]);
+    fr29_butterfly(a[0], a[1], w[2]); fr29_butterfly(a[2], a[3], w[2]);
+  }
+  for (int i = 0; i < 4; i++) {
+    for (int j = 0; j < N29; j++) BP_FR29_CHECK(a[i].l[j] <= MASK29);          // normalised, and below 2q:
+    fr29 t; BP_FR29_CHECK(fr29_sub_exact(t, a[i], [](int k) { return Q29::two_q(k); }) == 1);
+    fr_t z = fr29_to_sat_canonical(a[i]); memcpy(out + 8 * i, &z, 32);
+  }
 }
 void hc_fr29_roundtrip(uint32_t* r, const uint32_t* a_in) { fr_t a; memcpy(&a, a_in, 32); fr_t z = fr29_to_sat_canonical(fr29_from_sat(a)); memcpy(r, &z, 32); }
 }

@@ -195,3 +195,33 @@ def test_fr29_lazy_butterflies(hc):
             for _ in range(reps):
                 eu, ev = O.fr_bin("fr_add", eu, ev), O.fr_bin("fr_mul", O.fr_bin("fr_sub", eu, ev), w)
             assert (ru.view(np.uint64) == eu).all() and (rv.view(np.uint64) == ev).all()
+
+
+def test_fr29_radix4_group_lazy_sums(hc):
+    """fr29_radix4 (two stages on four elements, first-stage sums left unreduced) against big integers and against four
+    fr29_butterfly calls, on inputs anywhere in [0, 2q) -- the kernels' inter-stage invariant -- including the extremes; the
+    host build aborts if a limb or value bound of fr29_mul is violated (BP_FR29_CHECK)"""
+    rnd = random.Random(29)
+    fn = hc.hc_fr29_radix4
+    fn.restype, fn.argtypes = None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    top = 2 * Q - 1
+    # limb-extreme values below 2q: all 29-bit limbs full below the top one
+    full = [(k << 232) - 1 for k in (1, 2, (2 * Q) >> 232)] + [((2 * Q) >> 232 << 232) + 5]
+    special = [0, 1, Q - 1, Q, Q + 1, top, top - 1, 2 ** 255, 2 ** 254 - 1] + [v for v in full if v < 2 * Q]
+    cases = [[top] * 4, [0] * 4, [top, 0, top, 0], [0, top, 0, top], [top, top, 0, 0], [0, 0, top, top], [Q, Q, Q, Q], [full[0]] * 4]
+    cases += [[rnd.choice(special) for _ in range(4)] for _ in range(150)]
+    cases += [[rnd.randrange(2 * Q) for _ in range(4)] for _ in range(150)]
+    wsp = [1, Q - 1, 2, (Q + 1) // 2, 2 ** 254]
+    for a in cases:
+        w = [rnd.choice(wsp) if rnd.random() < 0.3 else rnd.randrange(1, Q) for _ in range(3)]          # true twiddle values
+        a_arr = np.array([[(v >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for v in a], dtype=np.uint32)
+        w_arr = np.array([[((x << 256) % Q >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for x in w], dtype=np.uint32)   # Montgomery form
+        got = {}
+        for lazy in (1, 0):
+            out = np.zeros((4, 8), dtype=np.uint32)
+            fn(out.ctypes.data, a_arr.ctypes.data, w_arr.ctypes.data, lazy)
+            got[lazy] = [sum(int(out[i, j]) << (32 * j) for j in range(8)) for i in range(4)]
+        d02, d13 = (a[0] - a[2]) * w[0], (a[1] - a[3]) * w[1]
+        want = [(a[0] + a[1] + a[2] + a[3]) % Q, ((a[0] + a[2]) - (a[1] + a[3])) * w[2] % Q, (d02 + d13) % Q, (d02 - d13) * w[2] % Q]
+        assert got[1] == want, (a, w)
+        assert got[0] == want, (a, w)
