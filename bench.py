@@ -104,6 +104,10 @@ def self_launch(args):
     return 0
 
 
+BARE_ADDS_PER_S = 7.343e9     # register-only g1_add_mixed28, whole chip (profiles/r02_ubench_valu_floor.txt)
+BARE_BUTTERFLIES_PER_S = 1024 * 64 / 1311.0 * 2.4e9      # register-only fr29_butterfly: 1 311 clk per wave-butterfly per SIMD, 1 024 SIMDs
+
+
 def profile_lookup(name, key):
     """numbers that need a separate profiler pass (PMC counters, static instruction mix) come from committed files under
     profiles/; None when the running configuration is not the profiled one"""
@@ -133,14 +137,23 @@ def msm_roofline(n, acc_s, adds, window_bits, tables, traffic_key=None):
                  "valu_per_addition": {"quarter_rate": mix["quarter_rate"], "full_rate": mix["full_rate"], "v_mad_u64_u32": mix.get("v_mad_u64_u32")},
                  "note": "additions counted by the kernel pipeline (non-zero digits) x static instruction classes of the loop body "
                          "(tools/instr_mix.py on the shipped code object) at the issue rates tools/ubench_int.hip measured "
-                         "(quarter-rate 57, full-rate 90 lanes/clk/CU, 256 CU, 2.4 GHz), over the measured kernel time"}
+                         "(quarter-rate 57, full-rate 90 lanes/clk/CU, 256 CU, 2.4 GHz), over the measured kernel time",
+                 "bare_kernel_peak": {"value": BARE_ADDS_PER_S, "frac": adds / acc_s / BARE_ADDS_PER_S,
+                                      "source": "tools/ubench_g1add.hip: the same g1_add_mixed28 on registers only, two waves per SIMD "
+                                                "(profiles/r02_ubench_valu_floor.txt)"}}
     return hbm, issue
 
 
 def ntt_roofline(nn, ntt_s, passes, traffic_key=None):
     achieved = NTT_BYTES_PER_UNIT * nn / ntt_s / 1e9
     traffic = profile_lookup("r02_hbm_traffic.json", traffic_key) if traffic_key else None
-    return {"bound": "hbm", "kernel": "ntt_pass_* (all %d passes of one transform)" % passes, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    butterflies = (nn // 2) * (nn.bit_length() - 1)
+    return {"valu": {"bound": "valu", "achieved": butterflies / ntt_s, "peak": BARE_BUTTERFLIES_PER_S, "unit": "butterflies/s",
+                     "frac": butterflies / ntt_s / BARE_BUTTERFLIES_PER_S,
+                     "note": "N/2 log2 N radix-2 butterflies over the kernel time, against fr29_butterfly on registers only (tools/ubench_fr29.hip: "
+                             "1 311 clk per 64 butterflies per SIMD at four waves); the passes also convert limbs, apply inter-pass twiddles and "
+                             "pay ~10 us of ramp each (profiles/r02_ntt_radix4_ab.txt)"},
+            "bound": "hbm", "kernel": "ntt_pass_* (all %d passes of one transform)" % passes, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
             "traffic_source": traffic.get("source") if traffic else None, "kernel_ms": ntt_s * 1e3,
             "algorithmic_bytes_per_launch": NTT_BYTES_PER_UNIT * nn}

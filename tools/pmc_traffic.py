@@ -8,7 +8,7 @@ FETCH.csv / WRITE.csv are the *_counter_collection.csv files of two separate run
   rocprofv3 --pmc WRITE_SIZE  -- (same)
 Counter values are KB per dispatch.  Corrections (MI355X_MICROARCH.md, HBM section, calibrated in round 1 on known byte counts):
 FETCH_SIZE tallies a 128-B coalesced read request at 64 B, so kernels that stream 16 B per lane in >= 128-B runs are doubled;
-sector gathers (msm_accumulate: 16 B per lane from random 112-B points) and 64-B runs (the strided NTT pass at 2^10 x 2 columns)
+sector gathers (msm_accumulate: 16 B per lane from random 112-B points) and 64-B runs (the strided NTT pass of 2^19: 2^10 x 2 columns)
 are counted exactly; WRITE_SIZE is exact."""
 import argparse
 import collections
@@ -25,7 +25,7 @@ def per_kernel(path, counter):
     with open(path) as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] == counter:
-                name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").replace("bp::", "")
+                name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").replace("bp::", "").replace("_swz", "")   # swizzled tile variants count as their pass
                 acc[name].append((float(row["Counter_Value"]), int(row["Grid_Size"])))
     return acc
 
@@ -69,10 +69,10 @@ def main():
         if f is None or w is None:
             continue
         n_str = len([1 for v, g in fetch[name] if g == max(r[1] for r in fetch[name])])
-        factor = 1 if (name == "ntt_pass_strided" and log_n <= 20 and log_n > 18) else 2
+        factor = 1 if (name == "ntt_pass_strided" and log_n == 19) else 2        # 2^19 = 10 + 9: 2^10 x 2-column tiles read 64-B runs
         per = (f * factor + w) * 1024
         # a three-pass transform launches the strided kernel twice per transform
-        mult = 2 if (name == "ntt_pass_strided" and log_n > 20) else 1
+        mult = 2 if (name == "ntt_pass_strided" and log_n >= 20) else 1
         passes[name] = {"fetch_kb_raw": f, "fetch_factor": factor, "write_kb": w, "hbm_bytes_per_launch": int(per), "launches_per_transform": mult}
         total += per * mult
     if passes:
