@@ -307,7 +307,9 @@ __device__ __forceinline__ void ntt_pass_strided_body(const fr_t* src, fr_t* dst
       const uint64_t E = ((uint64_t)e * (r0 + c)) << tshift;
       v = fr29_mul(v, twiddle_lookup(tw_lo, tw_hi, h, E));   // tw_hi may carry the folded N^-1 (first pass of an inverse)
     }
-    store_fr(&dst[doff + base + ((size_t)e << s) + c], fr29_to_sat_canonical(v));
+    // dst is the transform's own intermediate buffer: the value (< 2q < 2^256 after the product) is only packed, not brought
+    // below q -- the next pass accepts anything below 2q; the last pass writes canonical residues
+    store_fr(&dst[doff + base + ((size_t)e << s) + c], fr29_pack(v));
   }
 }
 #define BP_NTT_STRIDED_ARGS const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride, uint32_t k, uint32_t l, uint32_t s, uint32_t cl, \
