@@ -219,7 +219,7 @@ class Context:
     def ntt_stats(self):
         ms, p = C.c_float(), C.c_uint32()
         self.check(self._lib.bp_ntt_last_stats(self._h, C.byref(ms), C.byref(p)), "bp_ntt_last_stats")
-        return {"device_ms": ms.value, "passes": p.value}
+        return {"device_ms": ms.value, "passes": p.value, "members": self._lib.bp_ntt_last_members(self._h)}
 
     def synthetic_scalars_device(self, ptr, n, seed):
         """fill HBM at `ptr` with n synthetic Montgomery scalars (the same stream the CPU baseline uses)"""

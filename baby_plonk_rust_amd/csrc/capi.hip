@@ -890,7 +890,84 @@ static int ntt_columns_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, 
   }
   ctx->ntt_ms = ms;
   ctx->ntt_passes = sh[0]->ntt_passes;
+  ctx->ntt_members = (uint32_t)std::min(R, batch);
   return rc;
+}
+
+// Group context, ONE large transform from host memory (NTT option ii): N = 2^(l_1 + s).  Member g uploads the
+// columns r in its slice of [0, 2^s) -- every member over its own PCIe link -- and runs pass 1 on them; the members then swap
+// blocks of the intermediate buffer (member g' collects the rows e_1 of its slice: R - 1 peer copies of N / R^2 elements each,
+// over xGMI), run the remaining passes on their e_1 and download their outputs (index = e_1 mod 2^(l_1): runs of 2^(l_1) / R
+// elements).  Buffers keep the full N-element layout on every member, so the kernels address exactly as on one GPU.
+// Returns BP_ERR_UNSUPPORTED-like (1) when the shape does not split; the caller then runs the transform on the leader.  Host data
+// is written only after every member has finished, so a failure half way leaves it intact for that fallback.
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* v = getenv(name);
+  return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+static int ntt_one_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, int inverse, int scalar_fmt) {
+  const std::vector<bp_ctx*> sh = shards_of(ctx);
+  const uint32_t R = (uint32_t)sh.size();
+  if (!ntt_split_ok(log_n, R)) return 1;
+  uint32_t l1 = 0;
+  ntt_split_shape(log_n, &l1);
+  const size_t N = (size_t)1 << log_n, S = (size_t)1 << (log_n - l1), L1 = (size_t)1 << l1;     // rows of pass 1 x row length
+  const size_t cols = S / R, rows = L1 / R, esz = sizeof(fr_t);
+  std::vector<fr_t*> dbuf(R, nullptr), tbuf(R, nullptr);
+  int rc = BP_OK;
+  auto sync_all = [&]() {
+    for (uint32_t g = 0; g < R; g++) {
+      DeviceGuard guard(sh[g]->device);
+      hipError_t e = hipStreamSynchronize(sh[g]->stream);
+      if (e != hipSuccess && rc == BP_OK) rc = fail(ctx, BP_ERR_HIP, "NTT over the members", e, __FILE__, __LINE__);
+    }
+  };
+  for (uint32_t g = 0; g < R && rc == BP_OK; g++) {            // upload the column slice, pass 1
+    bp_ctx* m = sh[g];
+    DeviceGuard guard(m->device);
+    rc = lift(ctx, m, ws_get(m, "io.ntt", N * esz, (void**)&dbuf[g]));
+    if (rc == BP_OK) rc = lift(ctx, m, ntt_tmp_buffer(m, log_n, &tbuf[g]));
+    if (rc != BP_OK) break;
+    hipError_t e = hipMemcpy2DAsync(dbuf[g] + g * cols, S * esz, data + g * cols * esz, S * esz, cols * esz, L1, hipMemcpyHostToDevice, m->stream);
+    if (e != hipSuccess) { rc = fail(ctx, BP_ERR_HIP, "NTT column-slice upload", e, __FILE__, __LINE__); break; }
+    if (scalar_fmt == BP_FR_BYTES_LE) rc = lift(ctx, m, fr_convert_run(m, dbuf[g], N, 0));      // other columns: unused memory, converted and ignored
+    if (rc == BP_OK) rc = lift(ctx, m, ntt_run_part(m, dbuf[g], log_n, inverse, 1, N, 0, g, R));
+  }
+  sync_all();
+  for (uint32_t to = 0; to < R && rc == BP_OK; to++) {         // member `to` collects rows [to * rows, (to + 1) * rows) of everybody's columns
+    DeviceGuard guard(sh[to]->device);
+    for (uint32_t from = 0; from < R && rc == BP_OK; from++) {
+      if (from == to) continue;
+      const size_t off = (size_t)to * rows * S + (size_t)from * cols;
+      hipError_t e = hipMemcpy2DAsync(tbuf[to] + off, S * esz, tbuf[from] + off, S * esz, cols * esz, rows, hipMemcpyDeviceToDevice, sh[to]->stream);
+      if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "NTT block exchange", e, __FILE__, __LINE__);
+    }
+  }
+  for (uint32_t g = 0; g < R && rc == BP_OK; g++) {            // remaining passes on the member's e_1
+    bp_ctx* m = sh[g];
+    DeviceGuard guard(m->device);
+    rc = lift(ctx, m, ntt_run_part(m, dbuf[g], log_n, inverse, 1, N, 1, g, R));
+    if (rc == BP_OK && scalar_fmt == BP_FR_BYTES_LE) rc = lift(ctx, m, fr_convert_run(m, dbuf[g], N, 1));
+  }
+  sync_all();
+  for (uint32_t g = 0; g < R && rc == BP_OK; g++) {            // outputs e_1 + 2^(l_1) m, e_1 in the member's slice
+    DeviceGuard guard(sh[g]->device);
+    hipError_t e = hipMemcpy2DAsync(data + g * rows * esz, L1 * esz, dbuf[g] + g * rows, L1 * esz, rows * esz, S, hipMemcpyDeviceToHost, sh[g]->stream);
+    if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "NTT output download", e, __FILE__, __LINE__);
+  }
+  sync_all();
+  if (rc != BP_OK) return rc;
+  float ms0 = 0, ms1 = 0;
+  for (uint32_t g = 0; g < R; g++) {
+    DeviceGuard guard(sh[g]->device);
+    float a = 0, b = 0;
+    if (hipEventElapsedTime(&a, sh[g]->ev[0], sh[g]->ev[1]) == hipSuccess) ms0 = std::max(ms0, a);
+    if (hipEventElapsedTime(&b, sh[g]->ev[2], sh[g]->ev[3]) == hipSuccess) ms1 = std::max(ms1, b);
+  }
+  ctx->ntt_ms = ms0 + ms1;                                      // kernels only (slowest member of each phase); the exchange is not in it
+  ctx->ntt_passes = sh[0]->ntt_passes;
+  ctx->ntt_members = R;
+  return BP_OK;
 }
 
 int bp_ntt_fr(bp_ctx* ctx, void* data, uint32_t log_n, int inverse, int scalar_fmt, size_t batch, size_t stride) {
@@ -901,7 +978,12 @@ int bp_ntt_fr(bp_ctx* ctx, void* data, uint32_t log_n, int inverse, int scalar_f
   if (batch > 1 && stride < N) return fail(ctx, BP_ERR_INVALID_ARG, "NTT stride < N", hipSuccess, __FILE__, __LINE__);
   if (batch > 65535) return fail(ctx, BP_ERR_TOO_LARGE, "NTT batch > 65535", hipSuccess, __FILE__, __LINE__);
   if (is_group(ctx) && batch > 1) return ntt_columns_over_members(ctx, (uint8_t*)data, log_n, inverse, scalar_fmt, batch, stride);
+  if (is_group(ctx) && log_n >= env_u32("BP_NTT_GROUP_SPLIT_FROM", 22)) {     // one large transform: every member's PCIe link and a share of the work
+    const int rc = ntt_one_over_members(ctx, (uint8_t*)data, log_n, inverse, scalar_fmt);
+    if (rc == BP_OK) return BP_OK;                                             // otherwise (shape does not split, or a copy failed): on the leader
+  }
   DeviceGuard guard(ctx->device);
+  ctx->ntt_members = 1;
   const size_t span = (batch - 1) * stride + N;
   fr_t* d;
   BP_TRY(upload_fr(ctx, "io.ntt", data, span, span, scalar_fmt, &d));
@@ -917,6 +999,7 @@ int bp_ntt_last_stats(bp_ctx* ctx, float* device_ms, uint32_t* passes) {
   if (passes) *passes = ctx->ntt_passes;
   return BP_OK;
 }
+int bp_ntt_last_members(bp_ctx* ctx) { return ctx ? (int)ctx->ntt_members : BP_ERR_INVALID_ARG; }
 
 // utils.rs:39-43: ROOT_OF_UNITY.pow([2^32 / group_order, 0, 0, 0]) -- integer division, as written
 static bool host_root_of_unity(fr_t& out, uint64_t group_order) {

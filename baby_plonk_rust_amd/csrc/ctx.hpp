@@ -89,6 +89,7 @@ struct bp_ctx {
   float prove_ms[6] = {0, 0, 0, 0, 0, 0};            // host wall clock of rounds 1..5 and of the whole bp_prove
   float ntt_ms = 0;
   uint32_t ntt_passes = 0;
+  uint32_t ntt_members = 1;       // members of a group context that took part in the last host transform
   void* pinned = nullptr;                          // small pinned staging buffer (window sums etc.)
   size_t pinned_cap = 0;
 };
@@ -157,6 +158,11 @@ int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_
 int srs_to28_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28** d_out);
 int ntt_init_tables(bp_ctx* ctx);
 int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t log_n, int inverse, size_t batch, size_t stride);
+// one transform in two phases over the members of a group context (ntt.hip)
+bool ntt_split_ok(uint32_t log_n, uint32_t parts);
+void ntt_split_shape(uint32_t log_n, uint32_t* l1);
+int ntt_tmp_buffer(bp_ctx* ctx, uint32_t log_n, fr_t** out);
+int ntt_run_part(bp_ctx* ctx, fr_t* d_data, uint32_t log_n, int inverse, size_t batch, size_t stride, int phase, uint32_t part, uint32_t parts);
 int fr_convert_run(bp_ctx* ctx, fr_t* d, size_t n, int dir);
 int fr_binary_run(bp_ctx* ctx, const fr_t* a, size_t na, const fr_t* b, size_t nb, fr_t* out, size_t n, int op);
 int fr_scalar_run(bp_ctx* ctx, const fr_t* a, const fr_t& s, fr_t* out, size_t n, int op);

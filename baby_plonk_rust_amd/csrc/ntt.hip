@@ -115,19 +115,46 @@ static int get_tables(bp_ctx* ctx, uint32_t k, int inverse, NttTables** out) {
   return BP_OK;
 }
 
-int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, size_t stride) {
+// One transform cut in two phases for a group context (NTT option ii; capi.hip ntt_one_over_members): with the
+// digits N = 2^(l_1 + s), phase 0 is pass 1 on the tiles of a COLUMN slice (all d_1, r in the part's range), phase 1 the passes
+// 2 .. P on the slice of e_1 (each e_1 owns 2^s contiguous elements of the intermediate buffer).  Between the phases the members
+// exchange blocks of the intermediate buffer.  Every member keeps buffers in the full N-element layout, so addresses are the
+// single-GPU ones and a part is just a range of tiles: [part, part + 1) * tiles / parts in every pass (e_1 is the most
+// significant part of every later pass's tile index).
+bool ntt_split_ok(uint32_t k, uint32_t parts) {
+  if (k <= NTT_SMALL_MAX_LOG || parts < 2 || (parts & (parts - 1)) || parts > 8) return false;
+  NttPlan plan;
+  make_ntt_plan(plan, k);
+  uint32_t lg = 0;
+  while ((1u << lg) < parts) lg++;
+  const uint32_t s0 = k - plan.l[0];
+  if (s0 < plan.cl[0] + lg) return false;                                    // pass 1: whole tiles of columns per part
+  if (plan.l[0] < plan.cl[plan.P - 1] + lg) return false;                    // last pass: whole tiles of e_1 per part
+  return true;
+}
+void ntt_split_shape(uint32_t k, uint32_t* l1) {
+  NttPlan plan;
+  make_ntt_plan(plan, k);
+  *l1 = plan.l[0];
+}
+int ntt_tmp_buffer(bp_ctx* ctx, uint32_t k, fr_t** out) { return ws_get(ctx, "ntt.tmp", ((size_t)1 << k) * sizeof(fr_t), (void**)out); }
+
+// phase -1: the whole transform; 0 / 1: see above (batch must be 1)
+int ntt_run_part(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, size_t stride, int phase, uint32_t part, uint32_t parts) {
   if (k > 28) return fail(ctx, BP_ERR_TOO_LARGE, "NTT length > 2^28", hipSuccess, __FILE__, __LINE__);
   if (batch == 0) return BP_OK;
   if (batch > 65535) return fail(ctx, BP_ERR_TOO_LARGE, "NTT batch > 65535", hipSuccess, __FILE__, __LINE__);
   const size_t N = (size_t)1 << k;
   if (batch > 1 && stride < N) return fail(ctx, BP_ERR_INVALID_ARG, "NTT stride < N", hipSuccess, __FILE__, __LINE__);
+  if (phase >= 0 && (batch != 1 || !ntt_split_ok(k, parts) || part >= parts))
+    return fail(ctx, BP_ERR_INVALID_ARG, "NTT phase", hipSuccess, __FILE__, __LINE__);
   NttPlan plan;
   make_ntt_plan(plan, k);
   NttTables* tab;
   BP_TRY(get_tables(ctx, k, inverse, &tab));
   hipStream_t st = ctx->stream;
   const tw29_t* small = ctx->small_tw[inverse ? 1 : 0];
-  BP_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+  BP_HIP(ctx, hipEventRecord(ctx->ev[phase == 1 ? 2 : 0], st));
   if (plan.P == 1) {
     const size_t lds = (((N + 1) & ~(size_t)1) + ntt_tw_slots(k)) * N29 * 4 + 16;
     hipLaunchKernelGGL(ntt_small, dim3((unsigned)batch), dim3(256), lds, st, d_data, stride, k, small,
@@ -143,10 +170,15 @@ int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, si
       const uint32_t C = 1u << cl, tstride = ((1u << l) * (swizzled(l, cl) || C == 1 ? C : C + 1) + 1) & ~1u;
       return ((size_t)tstride + ntt_tw_slots(l)) * N29 * 4 + 16;
     };
+    auto tile_range = [&](unsigned tiles, unsigned* first, unsigned* count) {           // the part's share of a pass's tiles
+      *first = phase < 0 ? 0u : tiles / parts * part;
+      *count = phase < 0 ? tiles : tiles / parts;
+    };
     uint32_t s = k;
     for (uint32_t i = 0; i + 1 < plan.P; i++) {
       const uint32_t l = plan.l[i], cl = plan.cl[i];
       s -= l;
+      if ((phase == 0 && i > 0) || (phase == 1 && i == 0)) continue;
       const size_t lds = tile_lds(l, cl);
       const tw29_t* hi = (inverse && i == 0) ? tab->hi_scaled : tab->hi;   // N^-1 rides on the first twiddle
       if (tab->full[i] && tab->full_ls[i] != ((l << 8) | s)) {
@@ -162,19 +194,28 @@ int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, si
                            tab->full[i]);
         BP_HIP(ctx, hipGetLastError());
       }
-      hipLaunchKernelGGL(swizzled(l, cl) ? ntt_pass_strided_swz : ntt_pass_strided, dim3((unsigned)(N >> (l + cl)), (unsigned)batch),
+      unsigned first, count;
+      tile_range((unsigned)(N >> (l + cl)), &first, &count);
+      hipLaunchKernelGGL(swizzled(l, cl) ? ntt_pass_strided_swz : ntt_pass_strided, dim3(count, (unsigned)batch),
                          dim3(pass_threads(l, cl)), lds, st, i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp, tmp, i == 0 ? stride : N, N, k, l, s,
-                         cl, small, tab->lo, hi, tab->h, tab->full[i]);
+                         cl, small, tab->lo, hi, tab->h, tab->full[i], first);
     }
-    const uint32_t l = plan.l[plan.P - 1], cl = plan.cl[plan.P - 1];
-    const size_t lds = tile_lds(l, cl);
-    hipLaunchKernelGGL(swizzled(l, cl) ? ntt_pass_last_swz : ntt_pass_last, dim3((unsigned)(N >> (l + cl)), (unsigned)batch),
-                       dim3(pass_threads(l, cl)), lds, st, (const fr_t*)tmp, d_data, N, stride, plan, small);
+    if (phase != 0) {
+      const uint32_t l = plan.l[plan.P - 1], cl = plan.cl[plan.P - 1];
+      const size_t lds = tile_lds(l, cl);
+      unsigned first, count;
+      tile_range((unsigned)(N >> (l + cl)), &first, &count);
+      hipLaunchKernelGGL(swizzled(l, cl) ? ntt_pass_last_swz : ntt_pass_last, dim3(count, (unsigned)batch),
+                         dim3(pass_threads(l, cl)), lds, st, (const fr_t*)tmp, d_data, N, stride, plan, small, first);
+    }
   }
   BP_HIP(ctx, hipGetLastError());
-  BP_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+  BP_HIP(ctx, hipEventRecord(ctx->ev[phase == 1 ? 3 : 1], st));
   ctx->ntt_passes = plan.P;
   return BP_OK;
+}
+int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batch, size_t stride) {
+  return ntt_run_part(ctx, d_data, k, inverse, batch, stride, -1, 0, 1);
 }
 
 int fr_convert_run(bp_ctx* ctx, fr_t* d, size_t n, int dir) {

@@ -281,14 +281,15 @@ template <bool SWZ>
 __device__ __forceinline__ void ntt_pass_strided_body(const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride,
                                                       uint32_t k, uint32_t l, uint32_t s, uint32_t cl,
                                                       const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo,
-                                                      const tw29_t* __restrict__ tw_hi, uint32_t h, const tw29_t* __restrict__ tw_full) {
+                                                      const tw29_t* __restrict__ tw_hi, uint32_t h, const tw29_t* __restrict__ tw_full, uint32_t tile0) {
   const uint32_t C = 1u << cl, CP = SWZ || C == 1 ? C : C + 1;        // a single column needs no row pad
+  const uint32_t bx = blockIdx.x + tile0;           // tile0: first tile of this launch (a member of a group context runs a slice of the tiles)
   const uint32_t L = 1u << l, mlog = l + s, tstride = (L * CP + 1) & ~1u;      // even: the limb-pair arrays stay 8-byte aligned
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
   const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
   const uint32_t tiles_per_hi = 1u << (s - cl);
-  const uint32_t hi = blockIdx.x / tiles_per_hi, r0 = (blockIdx.x % tiles_per_hi) << cl;
+  const uint32_t hi = bx / tiles_per_hi, r0 = (bx % tiles_per_hi) << cl;
   const size_t base = ((size_t)hi << mlog) + r0;
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t c = x & (C - 1), d = x >> cl;
@@ -313,13 +314,14 @@ __device__ __forceinline__ void ntt_pass_strided_body(const fr_t* src, fr_t* dst
   }
 }
 #define BP_NTT_STRIDED_ARGS const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride, uint32_t k, uint32_t l, uint32_t s, uint32_t cl, \
-    const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo, const tw29_t* __restrict__ tw_hi, uint32_t h, const tw29_t* __restrict__ tw_full
+    const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo, const tw29_t* __restrict__ tw_hi, uint32_t h, const tw29_t* __restrict__ tw_full, \
+    uint32_t tile0
 __global__ void __launch_bounds__(512) ntt_pass_strided(BP_NTT_STRIDED_ARGS) {
-  ntt_pass_strided_body<false>(src, dst, src_stride, dst_stride, k, l, s, cl, small_tw, tw_lo, tw_hi, h, tw_full);
+  ntt_pass_strided_body<false>(src, dst, src_stride, dst_stride, k, l, s, cl, small_tw, tw_lo, tw_hi, h, tw_full, tile0);
 }
 // 2^l x 8 tiles, l <= 7, unpadded with swizzled rows: 256 lanes, three workgroups per CU
 __global__ void __launch_bounds__(256, 3) ntt_pass_strided_swz(BP_NTT_STRIDED_ARGS) {
-  ntt_pass_strided_body<true>(src, dst, src_stride, dst_stride, k, l, s, cl, small_tw, tw_lo, tw_hi, h, tw_full);
+  ntt_pass_strided_body<true>(src, dst, src_stride, dst_stride, k, l, s, cl, small_tw, tw_lo, tw_hi, h, tw_full, tile0);
 }
 
 // Last pass: contiguous rows of length L = 2^l (l = l_P); tile = C rows with consecutive e_1.
@@ -328,15 +330,15 @@ __global__ void __launch_bounds__(256, 3) ntt_pass_strided_swz(BP_NTT_STRIDED_AR
 // digit by digit (least significant output digit first).
 template <bool SWZ>
 __device__ __forceinline__ void ntt_pass_last_body(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
-                                                   size_t dst_stride, const NttPlan& plan, const tw29_t* __restrict__ small_tw) {
-  const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l;
+                                                   size_t dst_stride, const NttPlan& plan, const tw29_t* __restrict__ small_tw, uint32_t tile0) {
+  const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l, bx = blockIdx.x + tile0;
   const uint32_t cl = plan.cl[P - 1], C = 1u << cl, CP = SWZ || C == 1 ? C : C + 1, tstride = (L * CP + 1) & ~1u;
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
   const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
   const uint32_t midbits = k - l1 - l;              // bits of (e_2 .. e_{P-1})
   // blockIdx.x enumerates (e1_tile, mid): e_1 = e1_tile * C + c
-  const uint32_t mid = blockIdx.x & ((1u << midbits) - 1u), e1_0 = (blockIdx.x >> midbits) << cl;
+  const uint32_t mid = bx & ((1u << midbits) - 1u), e1_0 = (bx >> midbits) << cl;
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t d = x % L, c = x / L;
     const size_t row = ((size_t)(e1_0 + c) << midbits) + mid;
@@ -361,12 +363,12 @@ __device__ __forceinline__ void ntt_pass_last_body(const fr_t* __restrict__ src,
   }
 }
 __global__ void __launch_bounds__(512) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
-                                                     size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
-  ntt_pass_last_body<false>(src, dst, src_stride, dst_stride, plan, small_tw);
+                                                     size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw, uint32_t tile0) {
+  ntt_pass_last_body<false>(src, dst, src_stride, dst_stride, plan, small_tw, tile0);
 }
 __global__ void __launch_bounds__(256, 3) ntt_pass_last_swz(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
-                                                            size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw) {
-  ntt_pass_last_body<true>(src, dst, src_stride, dst_stride, plan, small_tw);
+                                                            size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw, uint32_t tile0) {
+  ntt_pass_last_body<true>(src, dst, src_stride, dst_stride, plan, small_tw, tile0);
 }
 
 // ---- element-wise helpers used by the Polynomial layer (src/polynomial.rs) -------------------------

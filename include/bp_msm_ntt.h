@@ -163,6 +163,12 @@ int  bp_ntt_fr(bp_ctx* ctx, void* data, uint32_t log_n, int inverse, int scalar_
 int  bp_ntt_fr_device(bp_ctx* ctx, void* d_data, uint32_t log_n, int inverse, size_t batch, size_t stride);
 /* HIP-event duration of all kernels of the last bp_ntt_fr_device call. */
 int  bp_ntt_last_stats(bp_ctx* ctx, float* device_ms, uint32_t* passes);
+/* Group contexts (bp_init_multi) and host data: batch > 1 deals the columns round-robin to the members (option i);
+ * ONE transform of 2^22 elements or more (BP_NTT_GROUP_SPLIT_FROM) is cut over the members (option ii): each uploads a slice
+ * of the columns of the first pass over its own PCIe link, the members swap blocks of the intermediate buffer (peer copies),
+ * run the remaining passes on their share and download their outputs.  A member count that is not 2, 4 or 8, or a shape
+ * that does not divide, runs on the first device.  Number of members that took part in the last bp_ntt_fr call: */
+int  bp_ntt_last_members(bp_ctx* ctx);
 /* root_of_unity(n) (utils.rs:39-43) and roots_of_unity(n) (utils.rs:45-52), output in scalar_fmt. */
 int  bp_root_of_unity(uint64_t group_order, int scalar_fmt, uint8_t out32[32]);
 int  bp_roots_of_unity(bp_ctx* ctx, uint64_t group_order, int scalar_fmt, void* out);

@@ -128,6 +128,32 @@ def test_group_context_ntt_columns_and_prove():
     assert len(blobs[0]) == 624 and all(b == blobs[0] for b in blobs)
 
 
+@pytest.mark.parametrize("members", [2, 4, 8])
+def test_group_context_one_large_transform(members, monkeypatch):
+    """SURVEY 8e, NTT option ii: ONE transform over the members of a group context -- column slices up, pass 1, block exchange,
+    remaining passes on slices of e_1, outputs down.  (Members on one card here: the copies between them are device-local.)"""
+    monkeypatch.setenv("BP_NTT_GROUP_SPLIT_FROM", "11")
+    one, many = bp.Context(0), bp.Context([0] * members)
+    for log_n in (11, 12, 13, 16, 19, 20, 21):
+        x = O.splitmix_scalars(1 << log_n, 0xA110 + log_n)
+        want = O.ntt_fast(x) if log_n <= 16 else one.ntt(x)
+        got = many.ntt(x)
+        assert (got == want).all(), (members, log_n)
+        assert many.ntt_stats()["members"] == (1 if (log_n, members) == (11, 8) else members), (members, log_n)    # 2^11 = 2^6 x 2^5: four column tiles
+        assert (many.ntt(got, inverse=True) == x).all(), (members, log_n)
+    # canonical little-endian bytes in and out (Scalar::to_bytes), and a shape that does not split (falls back to the leader)
+    ints = [random.Random(5).randrange(Q) for _ in range(1 << 12)]
+    le = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in ints), dtype=np.uint8).reshape(-1, 32)
+    got = many.ntt(le.view(np.uint64).reshape(-1, 4), fmt=bp.FR_BYTES_LE)
+    assert (got == one.ntt(le.view(np.uint64).reshape(-1, 4), fmt=bp.FR_BYTES_LE)).all()
+    monkeypatch.setenv("BP_NTT_SPLIT", "11:9,2,0")
+    x = O.splitmix_scalars(1 << 11, 0xA1FF)
+    assert (many.ntt(x) == O.ntt_fast(x)).all()
+    assert one.ntt_stats()["members"] == 1
+    many.close()
+    one.close()
+
+
 def test_blob_records_one_gather_one_copy():
     """what every rank of the one-process-per-GPU path does, here with three 'ranks' on one card: records written to HBM,
     gathered (a concatenated device tensor stands in for the RCCL all-gather), ONE copy to the host, combined"""
