@@ -476,6 +476,27 @@ def main():
                                       "how": "one bp_init_multi context in rank 0's process: SRS and the nine MSMs of a proof sharded by point "
                                              "range over the %d GPUs (peer copies of the scalar slices, partial sums added on the host), "
                                              "polynomial rounds on GPU 0" % world}
+                    # ONE host-to-host NTT through the same context (SURVEY 8e option ii): column slices over every GPU's PCIe link,
+                    # block exchange between the GPUs, outputs back; beside it the same call on this rank's single-GPU context
+                    if args.strong_log_n >= 22 and world in (2, 4, 8):
+                        try:
+                            hx = synthetic(1 << args.strong_log_n, 0xF40000 + args.strong_log_n).cpu().numpy().view(np.uint64).reshape(-1, 4)
+                            ms = {}
+                            for name, c in (("one_gpu", ctx), ("all_gpus", gctx)):
+                                best = None
+                                for _ in range(3):
+                                    t0 = time.perf_counter()
+                                    hy = c.ntt(hx)
+                                    dt = time.perf_counter() - t0
+                                    best = dt if best is None or dt < best else best
+                                ms[name] = {"ms_host_to_host": 1e3 * best, "kernel_ms": c.ntt_stats()["device_ms"], "members": c.ntt_stats()["members"],
+                                            "sha": hashlib.sha256(hy.tobytes()).hexdigest()[:16]}
+                            ms["same_output"] = ms["one_gpu"]["sha"] == ms["all_gpus"]["sha"]
+                            ms["log_n"] = args.strong_log_n
+                            prove["group"]["one_ntt_over_all_gpus"] = ms
+                            del hx, hy
+                        except Exception as e:
+                            prove["group"]["one_ntt_over_all_gpus"] = {"error": repr(e)[:300]}
                     gctx.close()
                 except Exception as e:                            # never lose the line over the optional leg
                     prove["group"] = {"n_gpus": world, "error": repr(e)[:300]}
