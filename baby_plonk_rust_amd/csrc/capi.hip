@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -914,55 +915,66 @@ static int ntt_one_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, int 
   const size_t N = (size_t)1 << log_n, S = (size_t)1 << (log_n - l1), L1 = (size_t)1 << l1;     // rows of pass 1 x row length
   const size_t cols = S / R, rows = L1 / R, esz = sizeof(fr_t);
   std::vector<fr_t*> dbuf(R, nullptr), tbuf(R, nullptr);
-  int rc = BP_OK;
-  auto sync_all = [&]() {
-    for (uint32_t g = 0; g < R; g++) {
-      DeviceGuard guard(sh[g]->device);
-      hipError_t e = hipStreamSynchronize(sh[g]->stream);
-      if (e != hipSuccess && rc == BP_OK) rc = fail(ctx, BP_ERR_HIP, "NTT over the members", e, __FILE__, __LINE__);
-    }
+  std::vector<int> rcs(R, BP_OK);
+  for (uint32_t g = 0; g < R; g++) {
+    DeviceGuard guard(sh[g]->device);
+    BP_TRY(lift(ctx, sh[g], ws_get(sh[g], "io.ntt", N * esz, (void**)&dbuf[g])));
+    BP_TRY(lift(ctx, sh[g], ntt_tmp_buffer(sh[g], log_n, &tbuf[g])));
+  }
+  // copies from and to pageable host memory are staged by the calling thread: one host thread per member keeps every PCIe link busy
+  auto over_members = [&](const std::function<int(uint32_t)>& work) {
+    std::vector<std::thread> workers;
+    for (uint32_t g = 1; g < R; g++) workers.emplace_back([&, g]() { rcs[g] = work(g); });
+    rcs[0] = work(0);
+    for (auto& t : workers) t.join();
+    for (uint32_t g = 0; g < R; g++)
+      if (rcs[g] != BP_OK) return lift(ctx, sh[g], rcs[g]);
+    return (int)BP_OK;
   };
-  for (uint32_t g = 0; g < R && rc == BP_OK; g++) {            // upload the column slice, pass 1
+  int rc = over_members([&](uint32_t g) -> int {               // column slice up, pass 1
     bp_ctx* m = sh[g];
     DeviceGuard guard(m->device);
-    rc = lift(ctx, m, ws_get(m, "io.ntt", N * esz, (void**)&dbuf[g]));
-    if (rc == BP_OK) rc = lift(ctx, m, ntt_tmp_buffer(m, log_n, &tbuf[g]));
-    if (rc != BP_OK) break;
     hipError_t e = hipMemcpy2DAsync(dbuf[g] + g * cols, S * esz, data + g * cols * esz, S * esz, cols * esz, L1, hipMemcpyHostToDevice, m->stream);
-    if (e != hipSuccess) { rc = fail(ctx, BP_ERR_HIP, "NTT column-slice upload", e, __FILE__, __LINE__); break; }
-    if (scalar_fmt == BP_FR_BYTES_LE) rc = lift(ctx, m, fr_convert_run(m, dbuf[g], N, 0));      // other columns: unused memory, converted and ignored
-    if (rc == BP_OK) rc = lift(ctx, m, ntt_run_part(m, dbuf[g], log_n, inverse, 1, N, 0, g, R));
-  }
-  sync_all();
-  for (uint32_t to = 0; to < R && rc == BP_OK; to++) {         // member `to` collects rows [to * rows, (to + 1) * rows) of everybody's columns
-    DeviceGuard guard(sh[to]->device);
+    if (e != hipSuccess) return fail(m, BP_ERR_HIP, "NTT column-slice upload", e, __FILE__, __LINE__);
+    if (scalar_fmt == BP_FR_BYTES_LE) BP_TRY(fr_convert_run(m, dbuf[g], N, 0));      // other columns: unused memory, converted and ignored
+    BP_TRY(ntt_run_part(m, dbuf[g], log_n, inverse, 1, N, 0, g, R));
+    BP_HIP(m, hipStreamSynchronize(m->stream));
+    return BP_OK;
+  });
+  if (rc != BP_OK) return rc;
+  for (uint32_t to = 0; to < R && rc == BP_OK; to++) {         // member `to` collects rows [to * rows, (to + 1) * rows) of everybody's columns,
+    bp_ctx* m = sh[to];                                        // then runs the remaining passes on its e_1
+    DeviceGuard guard(m->device);
     for (uint32_t from = 0; from < R && rc == BP_OK; from++) {
       if (from == to) continue;
       const size_t off = (size_t)to * rows * S + (size_t)from * cols;
-      hipError_t e = hipMemcpy2DAsync(tbuf[to] + off, S * esz, tbuf[from] + off, S * esz, cols * esz, rows, hipMemcpyDeviceToDevice, sh[to]->stream);
+      hipError_t e = hipMemcpy2DAsync(tbuf[to] + off, S * esz, tbuf[from] + off, S * esz, cols * esz, rows, hipMemcpyDeviceToDevice, m->stream);
       if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "NTT block exchange", e, __FILE__, __LINE__);
     }
+    if (rc == BP_OK) rc = lift(ctx, m, ntt_run_part(m, dbuf[to], log_n, inverse, 1, N, 1, to, R));
+    if (rc == BP_OK && scalar_fmt == BP_FR_BYTES_LE) rc = lift(ctx, m, fr_convert_run(m, dbuf[to], N, 1));
   }
-  for (uint32_t g = 0; g < R && rc == BP_OK; g++) {            // remaining passes on the member's e_1
+  for (uint32_t g = 0; g < R; g++) {                           // every member, also after a failure elsewhere
+    DeviceGuard guard(sh[g]->device);
+    hipError_t e = hipStreamSynchronize(sh[g]->stream);
+    if (e != hipSuccess && rc == BP_OK) rc = fail(ctx, BP_ERR_HIP, "NTT over the members", e, __FILE__, __LINE__);
+  }
+  if (rc != BP_OK) return rc;
+  rc = over_members([&](uint32_t g) -> int {                   // outputs e_1 + 2^(l_1) m, e_1 in the member's slice
     bp_ctx* m = sh[g];
     DeviceGuard guard(m->device);
-    rc = lift(ctx, m, ntt_run_part(m, dbuf[g], log_n, inverse, 1, N, 1, g, R));
-    if (rc == BP_OK && scalar_fmt == BP_FR_BYTES_LE) rc = lift(ctx, m, fr_convert_run(m, dbuf[g], N, 1));
-  }
-  sync_all();
-  for (uint32_t g = 0; g < R && rc == BP_OK; g++) {            // outputs e_1 + 2^(l_1) m, e_1 in the member's slice
-    DeviceGuard guard(sh[g]->device);
-    hipError_t e = hipMemcpy2DAsync(data + g * rows * esz, L1 * esz, dbuf[g] + g * rows, L1 * esz, rows * esz, S, hipMemcpyDeviceToHost, sh[g]->stream);
-    if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "NTT output download", e, __FILE__, __LINE__);
-  }
-  sync_all();
+    hipError_t e = hipMemcpy2DAsync(data + g * rows * esz, L1 * esz, dbuf[g] + g * rows, L1 * esz, rows * esz, S, hipMemcpyDeviceToHost, m->stream);
+    if (e != hipSuccess) return fail(m, BP_ERR_HIP, "NTT output download", e, __FILE__, __LINE__);
+    BP_HIP(m, hipStreamSynchronize(m->stream));
+    return BP_OK;
+  });
   if (rc != BP_OK) return rc;
   float ms0 = 0, ms1 = 0;
   for (uint32_t g = 0; g < R; g++) {
     DeviceGuard guard(sh[g]->device);
-    float a = 0, b = 0;
+    float a = 0, b2 = 0;
     if (hipEventElapsedTime(&a, sh[g]->ev[0], sh[g]->ev[1]) == hipSuccess) ms0 = std::max(ms0, a);
-    if (hipEventElapsedTime(&b, sh[g]->ev[2], sh[g]->ev[3]) == hipSuccess) ms1 = std::max(ms1, b);
+    if (hipEventElapsedTime(&b2, sh[g]->ev[2], sh[g]->ev[3]) == hipSuccess) ms1 = std::max(ms1, b2);
   }
   ctx->ntt_ms = ms0 + ms1;                                      // kernels only (slowest member of each phase); the exchange is not in it
   ctx->ntt_passes = sh[0]->ntt_passes;
