@@ -948,7 +948,7 @@ static int ntt_one_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, int 
     for (uint32_t from = 0; from < R && rc == BP_OK; from++) {
       if (from == to) continue;
       const size_t off = (size_t)to * rows * S + (size_t)from * cols;
-      hipError_t e = hipMemcpy2DAsync(tbuf[to] + off, S * esz, tbuf[from] + off, S * esz, cols * esz, rows, hipMemcpyDeviceToDevice, m->stream);
+      hipError_t e = hipMemcpy2DAsync(tbuf[to] + off, S * esz, tbuf[from] + off, S * esz, cols * esz, rows, hipMemcpyDefault, m->stream);   // the runtime finds the two devices
       if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "NTT block exchange", e, __FILE__, __LINE__);
     }
     if (rc == BP_OK) rc = lift(ctx, m, ntt_run_part(m, dbuf[to], log_n, inverse, 1, N, 1, to, R));
