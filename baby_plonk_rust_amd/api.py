@@ -147,7 +147,7 @@ class Context:
 
     def srs_precompute(self, handle, window_bits=0):
         """fixed-base window tables T[w][i] = 2^(c w) P_i for an SRS that serves many MSMs (0 = auto width,
-        SRS_TABLES_OFF drops them)"""
+        SRS_TABLES_OFF drops them; 256 + w = tables of every bit position for width-w NAF digits)"""
         self.check(self._lib.bp_srs_precompute(self._h, handle, window_bits), "bp_srs_precompute")
         return self.srs_table_info(handle)
 

@@ -67,8 +67,9 @@ void host_horner(g1_proj& out, const g1_proj* window_sums, uint32_t W, uint32_t 
 }
 
 // planes[w * c + 0] = A_w, planes[w * c + 1 + j] = T_{w,j} (j < c - 1):
-//   out = sum_w 2^(c w) (A_w + sum_j 2^j T_{w,j}),  one pass from the top bit position down
-void host_plane_horner(g1_proj& out, const g1_proj* planes, uint32_t W, uint32_t c) {
+//   out = sum_w 2^(c w) (A_w + sum_j 2^j T_{w,j}),  one pass from the top bit position down (bucket b holds digit b + 1);
+//   odd_digits (NAF tables, one window): bucket b holds digit 2b + 1, out = A + 2 sum_j 2^j T_j
+void host_plane_horner(g1_proj& out, const g1_proj* planes, uint32_t W, uint32_t c, bool odd_digits) {
   g1_proj acc = g1_identity();
   for (uint32_t w = W; w-- > 0;) {
     const g1_proj* p = planes + (size_t)w * c;
@@ -76,6 +77,7 @@ void host_plane_horner(g1_proj& out, const g1_proj* planes, uint32_t W, uint32_t
       g1_double(acc, acc);
       if (j + 1 < c) g1_add(acc, acc, p[1 + j]);           // bit position c - 1 of the window carries no plane
     }
+    if (odd_digits) g1_double(acc, acc);
     g1_add(acc, acc, p[0]);
   }
   out = acc;
@@ -552,8 +554,10 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
       c = lg > 8 ? lg - 4 : 4;        // reduction tree has c - 1 levels -- measured optimum 2^10: 6, 2^12: 8
     }
   }
-  if (c != BP_SRS_TABLES_OFF && (c < 4 || c > 24))
-    return fail(ctx, BP_ERR_INVALID_ARG, "window_bits must be 0 (auto), 1 (off) or 4..24", hipSuccess, __FILE__, __LINE__);
+  const bool naf = (c & MSM_NAF_FLAG) != 0;
+  if (naf ? ((c & 0xffu) < 6 || (c & 0xffu) > 22 || (c >> 9)) : (c != BP_SRS_TABLES_OFF && (c < 4 || c > 24)))
+    return fail(ctx, BP_ERR_INVALID_ARG, "window_bits must be 0 (auto), 1 (off), 4..24, or 256 + w (w = 6..22: every-position tables)", hipSuccess,
+                __FILE__, __LINE__);
   const std::vector<bp_ctx*> sh = shards_of(ctx);
   const std::vector<uint64_t> hs = lead->member_handle;
   for (size_t r = 0; r < sh.size(); r++) BP_TRY(lift(ctx, sh[r], srs_precompute_one(sh[r], hs.empty() ? srs_handle : hs[r], c)));
@@ -599,7 +603,7 @@ static int msm_shard_launch(bp_ctx* m, SrsEntry* e, size_t local_first, const vo
     d_scalars = d;
   }
   // fixed-base tables pay once the bucket adds outweigh the fixed 2^table_c reduction
-  const bool tables = e->d_table && 8 * (uint64_t)n >= (1ull << e->table_c);
+  const bool tables = e->d_table && 8 * (uint64_t)n >= (1ull << ((e->table_c & MSM_NAF_FLAG) ? (e->table_c & 0xffu) - 2 : e->table_c));
   if (tables) return msm_launch(m, e->d_table + local_first, n, d_scalars, fmt, e->table_c, e->n, slot, d_blob, pend);
   return msm_launch(m, e->d_points28 + local_first, n, d_scalars, fmt, 0, 0, slot, d_blob, pend);
 }

@@ -18,6 +18,9 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+// SrsEntry::table_c = MSM_NAF_FLAG | w: tables of every bit position (MSM_NAF_ROWS rows) for width-w NAF digits (msm_kernels.hpp MsmPlan::naf)
+constexpr uint32_t MSM_NAF_FLAG = 0x100u, MSM_NAF_ROWS = 256;
+
 struct SrsEntry {
   g1_affine* d_points = nullptr;        // 96 B/point, reference Montgomery limbs (export, generic kernels)
   g1_affine28* d_points28 = nullptr;    // 112 B/point, 14 x 28-bit limbs, R' = 2^392 (bucket accumulation)
@@ -136,7 +139,8 @@ int pinned_get(bp_ctx* ctx, size_t bytes, void** out);
 // MSM_SLOTS result areas in the pinned staging buffer; launches on one stream reuse the device workspaces in stream order.
 constexpr int MSM_SLOTS = 4;
 struct MsmPending {
-  bool empty = true, tables = false, blob = false;
+  bool empty = true, blob = false;
+  uint32_t tables = 0;                  // 0: per-window buckets; 1: fixed-base window tables; 2: every-position tables (odd NAF digits)
   uint32_t c = 0, Wr = 0, n_planes = 0;
   uint64_t adds = 0;
   const void* h_windows = nullptr;      // pinned: n_planes accumulator slots + the status word
@@ -190,7 +194,7 @@ void transcript_test_vector(uint8_t out32[32]);
 
 // ---- host-side helpers (host.cpp part of capi.hip) ---------------------------------------------------
 void host_horner(g1_proj& out, const g1_proj* window_sums, uint32_t W, uint32_t c);
-void host_plane_horner(g1_proj& out, const g1_proj* planes, uint32_t W, uint32_t c);
+void host_plane_horner(g1_proj& out, const g1_proj* planes, uint32_t W, uint32_t c, bool odd_digits = false);
 void host_encode96(uint8_t out96[96], const g1_proj& p);
 bool host_decode96(g1_proj& out, const uint8_t in96[96]);
 void host_compress48(uint8_t out48[48], const g1_proj& p);

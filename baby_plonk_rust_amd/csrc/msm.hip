@@ -26,6 +26,27 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
 static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_stride) {
   memset(&plan, 0, sizeof plan);
   plan.n = (uint32_t)n;
+  if (table_c & MSM_NAF_FLAG) {         // every-position tables: odd NAF digits of width w, 2^(w-2) buckets, one bucket set
+    const uint32_t w = table_c & 0xffu;
+    plan.naf = w;
+    plan.c = w - 1;
+    plan.W = 255 / w + 1;               // digit slots per scalar (most scalars fill 256 / (w + 1) of them)
+    plan.B = 1u << (w - 2);
+    plan.total = plan.B;
+    plan.wbuckets = 0;
+    plan.wpoints = (uint32_t)table_stride;
+    plan.parts = plan.B <= (1u << MSM_HIST_LOG) ? 1 : plan.B >> MSM_HIST_LOG;
+    // digits of a uniform scalar: 256 / (w + 1) + ~0.45 (measured 15.49 / 13.91 / 12.71 at w = 16 / 18 / 20); the lanes must not spill
+    // into a third wave round, so the chunk is sized for 0.7 above the asymptote
+    const uint64_t expected = ((uint64_t)n * 2560 / (w + 1) + (uint64_t)n * 7) / 10 + 1;
+    uint32_t chunk = (uint32_t)((expected + 262143) / 262144);
+    if (chunk < 4) chunk = 4;
+    if (chunk > 1024) chunk = 1024;
+    plan.chunk = env_u32("BP_MSM_CHUNK", chunk);
+    plan.slices = 1;
+    plan.seg = 1;
+    return;
+  }
   uint32_t c = n < 32 ? 4 : ilog2_floor(n) - 3;
   if (c < 4) c = 4;
   if (c > MSM_MAX_C) c = MSM_MAX_C;
@@ -111,6 +132,7 @@ int srs_to28_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28** d_o
 }
 
 uint32_t msm_table_windows(uint32_t c) {
+  if (c & MSM_NAF_FLAG) return MSM_NAF_ROWS;
   MsmPlan plan;
   make_plan(plan, 1, c, 1);
   return plan.W;
@@ -126,7 +148,7 @@ int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_
   BP_HIP(ctx, hipMalloc((void**)&t, (size_t)W * (n ? n : 1) * sizeof(g1_affine28)));
   if (n) {
     BP_HIP(ctx, hipMemcpyAsync(t, d_points28, n * sizeof(g1_affine28), hipMemcpyDeviceToDevice, ctx->stream));
-    hipLaunchKernelGGL(srs_window_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_points, n, c, W, t);
+    hipLaunchKernelGGL(srs_window_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_points, n, (c & MSM_NAF_FLAG) ? 1u : c, W, t);
   }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -196,7 +218,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   int16_t* digits = nullptr;
   uint32_t *counts, *offsets, *cursors, *sorted;
   proj28_slot *bucket_sum, *partial, *block_out, *window_sum;
-  if (plan.parts == 1) BP_TRY(ws_get(ctx, "msm.digits", max_entries * sizeof(int16_t), (void**)&digits));
+  if (plan.parts == 1 && !plan.naf) BP_TRY(ws_get(ctx, "msm.digits", max_entries * sizeof(int16_t), (void**)&digits));
   BP_TRY(ws_get(ctx, "msm.counts", (size_t)total * 4 + 8, (void**)&counts));       // + [0] long-bucket counter, [1] scalar status: one memset
   BP_TRY(ws_get(ctx, "msm.offsets", ((size_t)total + 1) * 4, (void**)&offsets));
   BP_TRY(ws_get(ctx, "msm.cursors", (size_t)total * 4, (void**)&cursors));
@@ -227,7 +249,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   // Bucket sort.  c <= 16: the one-histogram counting sort (msm_count / msm_scatter).  Wider windows: the partitioned (radix)
   // sort -- every store coalesced or L2-merged.  (At c = 16 the two cost the same, 0.34 vs 0.35 ms at 2^20: the radix sort
   // moves 8-byte records three times.)  BP_MSM_SORT=1 forces the radix sort everywhere (tests, A/B).
-  const bool radix = plan.parts > 1 || env_u32("BP_MSM_SORT", 0) == 1;
+  const bool radix = plan.parts > 1 || plan.naf || env_u32("BP_MSM_SORT", 0) == 1;
   if (radix) {
     uint32_t kb = 0;
     while ((1ull << kb) < total) kb++;
@@ -258,7 +280,10 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
     BP_TRY(ws_get(ctx, "msm.run_long", ((size_t)n_final + 2) * 4, (void**)&rlong));
     BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4 + 8, st));     // bucket sizes of long runs + long-bucket counter + scalar status
     BP_HIP(ctx, hipMemsetAsync(rlong, 0, 4, st));
-    hipLaunchKernelGGL(msm_digit_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, keys[0], vals[0], long_count + 1);
+    if (plan.naf)
+      hipLaunchKernelGGL(msm_naf_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, keys[0], vals[0], long_count + 1);
+    else
+      hipLaunchKernelGGL(msm_digit_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, keys[0], vals[0], long_count + 1);
     uint32_t runs = 1, shift = kb, side = 0;
     for (int level = 0; level < 2 && lv[level]; level++) {
       const uint32_t bits = lv[level], nd = 1u << bits, n_sub = runs * nd;
@@ -355,7 +380,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
     hdr.c = plan.c;
     hdr.Wr = Wr;
     hdr.n_planes = n_planes;
-    hdr.tables = table_c != 0;
+    hdr.tables = plan.naf ? 2u : (table_c != 0 ? 1u : 0u);
     hipLaunchKernelGGL(msm_write_blob, dim3(1), dim3(256), 0, st, window_sum, hdr, (uint8_t*)d_blob);
     BP_HIP(ctx, hipGetLastError());
   } else {
@@ -363,7 +388,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   }
   BP_HIP(ctx, hipEventRecord(ctx->ev[3], st));
   out->empty = false;
-  out->tables = table_c != 0;
+  out->tables = plan.naf ? 2u : (table_c != 0 ? 1u : 0u);
   out->c = plan.c;
   out->Wr = Wr;
   out->n_planes = n_planes;
@@ -385,8 +410,8 @@ int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out) {
   BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   BP_HIP(ctx, hipEventElapsedTime(&ctx->msm_accumulate_ms, ctx->ev[1], ctx->ev[2]));
   BP_HIP(ctx, hipEventElapsedTime(&ctx->msm_total_ms, ctx->ev[0], ctx->ev[3]));
-  ctx->msm_c = pend.c;
-  ctx->msm_tables = pend.tables;
+  ctx->msm_c = pend.tables == 2 ? (MSM_NAF_FLAG | (pend.c + 1)) : pend.c;       // as given to bp_srs_precompute
+  ctx->msm_tables = pend.tables != 0;
   ctx->msm_adds = pend.adds;
   if (pend.blob) {                      // the result stayed in HBM (bp_msm_g1_blob_device); its status word travels in the record
     if (host_out) *host_out = g1_identity();
@@ -399,7 +424,7 @@ int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out) {
   ctx->msm_adds = tail[1];             // entries of the bucket-sorted list = non-zero digits = bucket additions performed
   std::vector<g1_proj> windows(n_planes);
   for (uint32_t w = 0; w < n_planes; w++) windows[w] = slot_to_proj(&h_windows[w]);
-  if (pend.tables) host_plane_horner(*host_out, windows.data(), pend.Wr, pend.c);
+  if (pend.tables) host_plane_horner(*host_out, windows.data(), pend.Wr, pend.c, pend.tables == 2);
   else host_horner(*host_out, windows.data(), pend.Wr, pend.c);
   return BP_OK;
 }
@@ -434,7 +459,7 @@ int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out) {
       for (uint32_t w = 0; w < h.n_planes; w++) g1_add(sum[w], sum[w], slot_to_proj(&sk[w]));
     }
     g1_proj part;
-    if (h.tables) host_plane_horner(part, sum.data(), h.Wr, h.c);
+    if (h.tables) host_plane_horner(part, sum.data(), h.Wr, h.c, h.tables == 2);
     else host_horner(part, sum.data(), h.Wr, h.c);
     g1_add(total, total, part);
   }

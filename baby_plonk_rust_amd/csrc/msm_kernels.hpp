@@ -58,6 +58,11 @@ struct MsmPlan {
   // Windows wider than 16 bits (fixed-base tables only): one window's 2^(c-1) buckets no longer fit one LDS histogram
   // (parts > 1); those MSMs take the partitioned (radix) bucket sort, section 4c.
   uint32_t parts;      // 1, or B >> 15
+  // Fixed-base tables of EVERY bit position (T[p][i] = 2^p P_i, 256 rows: the 288 GB of HBM pay for it up to ~2^21 points) carry
+  // the scalar's width-`naf` non-adjacent form: odd digits |d| < 2^(naf-1) at arbitrary positions, at most one per `naf`
+  // positions -- 256 / (naf + 1) bucket additions per scalar on average instead of 256 / c, with only 2^(naf-2) buckets
+  // (bucket (|d| - 1) / 2).  Then c = naf - 1 (so that B = 2^(c-1) as everywhere), W = digit slots per scalar.
+  uint32_t naf;        // 0, or the NAF width
 };
 
 // ---------------------------------------------------------------- 1. digits
@@ -288,6 +293,60 @@ __global__ void __launch_bounds__(256) msm_digit_records(const fr_t* __restrict_
     keys[at] = d == 0 ? RADIX_EMPTY : w * plan.wbuckets + digit_bucket(d);
     vals[at] = (i + w * plan.wpoints) | (d < 0 ? 0x80000000u : 0u);
   }
+}
+
+// Width-w NAF records of every scalar (plan.naf = w): slot s of scalar i at [s * n + i].  With E = (k >> pos) + carry:
+// E even -> next position; E odd -> e = E mod 2^w, digit d = e (carry 0) or e - 2^w (carry 1) when e >= 2^(w-1), pos += w.
+// k < 2^255, so every digit sits at a position <= 255 and there are at most 255 / w + 1 of them (= plan.W slots).
+__global__ void __launch_bounds__(256) msm_naf_records(const fr_t* __restrict__ scalars, int fmt, MsmPlan plan, uint32_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ vals, uint32_t* __restrict__ status) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= plan.n) return;
+  fr_t k = scalars[i];
+  if (fmt == 1) {
+    Fr::from_mont(k, k);
+  } else {
+    fr_t t;
+    if (!big_sub(t, k, Fr::modulus())) atomicOr(status, 1u);
+  }
+  uint32_t kw[10];
+#pragma unroll
+  for (int j = 0; j < 8; j++) kw[j] = k.l[j];
+  kw[8] = 0;
+  kw[9] = 0;
+  const uint32_t w = plan.naf, mask = (1u << w) - 1u, half = 1u << (w - 1);
+  uint32_t pos = 0, carry = 0, slot = 0;
+  while (pos < 256 && slot < plan.W) {
+    // next position >= pos whose bit differs from the carry (there E is odd); none below 256: the rest of E is zero
+    const uint32_t flip = carry ? 0xffffffffu : 0u;
+    uint32_t word = pos >> 5, x = ((kw[word] ^ flip) >> (pos & 31));
+    uint32_t p = pos;
+    if (x) {
+      p += __ffs(x) - 1;
+    } else {
+      p = (word + 1) << 5;
+      for (word++; word < 8 && (kw[word] ^ flip) == 0; word++) p += 32;
+      if (word >= 8) {
+        if (!carry) break;                    // carry == 0: k has no bits left.  carry == 1 reaches here only past bit 255 (bit 255 of k is 0)
+        p = 256;
+      } else {
+        p += __ffs(kw[word] ^ flip) - 1;
+      }
+    }
+    if (p >= 256) break;
+    const uint32_t wd = p >> 5, sh = p & 31;
+    const uint64_t two = (uint64_t)kw[wd] | ((uint64_t)kw[wd + 1] << 32);
+    const uint32_t e = ((uint32_t)(two >> sh) & mask) + carry;        // odd, < 2^w
+    const bool neg = e >= half;
+    const uint32_t mag = neg ? (1u << w) - e : e;                     // |d|, odd, < 2^(w-1)
+    carry = neg ? 1u : 0u;
+    const size_t at = (size_t)slot * plan.n + i;
+    keys[at] = (mag - 1) >> 1;
+    vals[at] = (i + p * plan.wpoints) | (neg ? 0x80000000u : 0u);
+    slot++;
+    pos = p + w;
+  }
+  for (; slot < plan.W; slot++) keys[(size_t)slot * plan.n + i] = RADIX_EMPTY;
 }
 
 // run r = records [run_off[r], run_off[r + 1]); the workgroups blockIdx.x, blockIdx.x + gridDim.x, ... take its slices

@@ -104,7 +104,10 @@ int  bp_srs_free(bp_ctx* ctx, uint64_t srs_handle);
  * MSM feeds one shared bucket set, so the bucket reduction and the Horner epilogue shrink from `windows`
  * passes to one; results are the same group element.  window_bits: 0 = chosen from srs_len (16 at 2^20 points, 20 -- thirteen
  * windows -- from 2^22 points), BP_SRS_TABLES_OFF = drop the tables, else 4..24 (above 16 the bucket sort is partitioned).  MSMs shorter than 2^window_bits / 8 scalars keep
- * using the table-free path.  The reference has no counterpart (its MSM recomputes from the raw points). */
+ * using the table-free path.  The reference has no counterpart (its MSM recomputes from the raw points).
+ * window_bits = 256 + w (w = 6..22): tables of EVERY bit position, T[p][i] = 2^p * P_i for p < 256 (256 x srs_len x 112 bytes:
+ * 28 GiB at 2^20 points), used with the scalars' width-w non-adjacent form: ~256 / (w + 1) + 0.5 bucket additions per scalar
+ * and 2^(w-2) buckets.  Measured slower than the 16-bit windows at 2^20 as shipped; never chosen by 0. */
 #define BP_SRS_TABLES_OFF 1u
 int  bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits);
 /* window_bits / windows / bytes of the tables of an SRS (all 0 without tables). */

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import baby_plonk_rust_amd as bp
+from baby_plonk_rust_amd._lib import MSM_BLOB_BYTES
 from oracle import oracle as O
 from tests import bigint_model as M
 from tests.gpu_common import NTHREADS, Q, closed_form, oracle_dot, progression_bytes
@@ -225,3 +226,64 @@ def test_windows_wider_than_16_bits(ctx, c, log_n):
     if small is not None:                                       # 16-bit witness-like values: only the low windows are populated
         assert ctx.msm(h, small) == M.enc96(M.ec_mul(oracle_dot(small, a, d)))
     ctx.srs_free(h)
+
+
+@pytest.mark.parametrize("w,log_n", [(6, 9), (8, 12), (11, 13), (14, 15), (16, 16), (18, 17), (19, 17), (22, 17)])
+def test_every_position_tables_naf_digits(ctx, w, log_n):
+    """bp_srs_precompute(handle, 256 + w): tables of EVERY bit position (256 rows, T[p][i] = 2^p P_i) carry the scalars' width-w
+    non-adjacent form -- odd signed digits at arbitrary positions, 2^(w-2) buckets holding digit 2b + 1, one bucket set.
+    Same bytes as the closed form and the other paths; every row probed alone; edge and skewed scalars; prefixes and offsets;
+    canonical-bytes scalars and their rejection; records of two shards combined."""
+    n, a, d = (1 << log_n) + 7, Q - 424242, 0x1A2B3C4D5E6F7081
+    h = ctx.srs_generate_progression(n, a, d)
+    sc = O.splitmix_scalars(n, 0x5EED1000 + w)
+    want = M.enc96(M.ec_mul(oracle_dot(sc, a, d)))
+    assert ctx.msm(h, sc) == want and not ctx.msm_stats()["tables"]
+    info = ctx.srs_precompute(h, 256 + w)
+    assert info == {"window_bits": 256 + w, "windows": 256, "bytes": 256 * n * 112}
+    assert ctx.msm(h, sc) == want
+    st = ctx.msm_stats()
+    assert st["tables"] and st["window_bits"] == 256 + w
+    assert 0 < st["mixed_adds"] <= (255 // w + 1) * n and st["mixed_adds"] < n * (256 / (w + 1) + 1.5)     # the NAF's density
+    assert bp.sum_partials(ctx.msm_partial(h, sc[: n // 2 + 3])) == M.enc96(M.ec_mul(oracle_dot(sc[: n // 2 + 3], a, d)))
+    assert bp.sum_partials(ctx.msm_partial(h, sc[: n - 101], first=101)) == M.enc96(M.ec_mul(oracle_dot(sc[: n - 101], a + 101 * d, d)))
+    for p in list(range(0, 255, 17)) + [253, 254]:               # rows alone: scalar 2^p (digit 1 at position p) and 3 * 2^p
+        one_hot = np.zeros((n, 4), dtype=np.uint64)
+        j = (977 * (p + 1)) % n
+        one_hot[j] = bp.scalar_from_int((1 << p) % Q)
+        assert ctx.msm(h, one_hot) == M.enc96(M.ec_mul(((a + j * d) << p) % Q)), p
+    for val in (Q - 1, Q - 2, 1, 2, 3, 0, (1 << 254) + 1, (1 << 254) - 1,
+                0x123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF % Q, int("55" * 31, 16), int("AA" * 31, 16) % Q):
+        same = np.tile(bp.scalar_from_int(val % Q), (n, 1))
+        k = (val % Q) * ((n * a + d * (n * (n - 1) // 2)) % Q) % Q
+        assert ctx.msm(h, same) == M.enc96(M.ec_mul(k)), hex(val)
+    small = bp.scalars_from_ints([(i * 7919) % 65536 for i in range(n)])
+    assert ctx.msm(h, small) == M.enc96(M.ec_mul(oracle_dot(small, a, d)))
+    ints = bp.scalars_to_ints(sc[:200])
+    le = np.frombuffer(b"".join(s.to_bytes(32, "little") for s in ints), dtype=np.uint8).reshape(-1, 32)
+    assert ctx.msm(h, le, fmt=bp.FR_BYTES_LE) == M.enc96(M.ec_mul(oracle_dot(sc[:200], a, d)))
+    bad = le.copy()
+    bad[5] = np.frombuffer(Q.to_bytes(32, "little"), dtype=np.uint8)
+    with pytest.raises(bp.BpError) as e:
+        ctx.msm(h, bad, fmt=bp.FR_BYTES_LE)
+    assert e.value.code == -4
+    # two point-range shards as device records, combined on the host (bp_msm_blobs_combine: the records say "odd digits")
+    import torch
+    t = torch.from_numpy(sc.view(np.int64)).cuda()
+    rec = torch.zeros(2 * MSM_BLOB_BYTES, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    half = n // 2
+    ctx.msm_blob_device(h, rec.data_ptr(), None, first=0, device_ptr=t.data_ptr(), n=half)
+    ctx.msm_blob_device(h, rec.data_ptr() + MSM_BLOB_BYTES, None, first=half, device_ptr=t.data_ptr() + 32 * half, n=n - half)
+    assert bp.combine_blobs(rec.cpu().numpy().tobytes()) == want
+    with pytest.raises(bp.BpError):
+        ctx.srs_precompute(h, 256 + 5)
+    with pytest.raises(bp.BpError):
+        ctx.srs_precompute(h, 256 + 23)
+    ctx.srs_free(h)
+    many = bp.Context([0, 0, 0])                                  # the same through a three-shard context
+    hm = many.srs_generate_progression(n, a, d)
+    many.srs_precompute(hm, 256 + w)
+    assert many.msm(hm, sc) == want
+    assert many.msm_stats()["tables"] == (8 * (n // 3) >= (1 << (w - 2)))      # short shards keep to the plain points
+    many.close()
