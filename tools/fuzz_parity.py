@@ -25,6 +25,8 @@ args = ap.parse_args()
 rnd = random.Random(args.seed)
 ctx = bp.default_context()
 group = bp.Context([0, 0, 0])          # the same library calls through a three-shard context (bp_init_multi) on this one card
+group4 = bp.Context([0, 0, 0, 0])      # four members: one host NTT is cut over them (BP_NTT_GROUP_SPLIT_FROM lowered below)
+os.environ["BP_NTT_GROUP_SPLIT_FROM"] = "11"
 t_end = time.time() + args.seconds
 counts = {"msm": 0, "ntt": 0, "poly": 0}
 
@@ -58,7 +60,9 @@ while time.time() < t_end:
         mode = rnd.choice(["plain", "tables", "tables"])
         c_plain = rnd.choice([None, 4, 7, 10, 13, 16])
         if mode == "tables":        # widths above 16 take the partitioned sort (only when 8 n >= 2^width, else the plain path answers)
-            ctx.srs_precompute(h, rnd.choice([0, 0, 4, 6, 9, 12, 15, 16, 17, 18, 19, 20]))
+            # 256 + w: tables of every bit position, width-w NAF digits (256 rows: kept to short SRS here)
+            naf_ok = srs_len <= 40000
+            ctx.srs_precompute(h, rnd.choice([0, 0, 4, 6, 9, 12, 15, 16, 17, 18, 19, 20] + ([256 + 6, 256 + 9, 256 + 13, 256 + 16, 256 + 19] if naf_ok else [])))
         os.environ.pop("BP_MSM_C", None)
         if c_plain:
             os.environ["BP_MSM_C"] = str(c_plain)
@@ -81,9 +85,10 @@ while time.time() < t_end:
         k = rnd.randrange(0, 19)
         x = scalars(1 << k, rnd.choice(["random", "small", "edges"]))
         inv = rnd.random() < 0.5
-        got = ctx.ntt(x, inverse=inv)
+        nctx = group4 if rnd.random() < 0.3 else ctx
+        got = nctx.ntt(x, inverse=inv)
         if not (got == O.ntt_fast(x, inverse=inv)).all():
-            print("NTT MISMATCH", dict(k=k, inverse=inv, seed=args.seed))
+            print("NTT MISMATCH", dict(k=k, inverse=inv, seed=args.seed, members=nctx.ntt_stats()["members"]))
             sys.exit(1)
         batch = rnd.randrange(1, 5)
         if k <= 14:
