@@ -108,6 +108,7 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   // latency regime (<= 2^20 entries, e.g. 2^16 points): one wave per SIMD with chains of 16 leaves two partials per bucket instead
   // of eight for the fix-up (2^16 with tables: 0.531 -> 0.482 ms; 2^14 keeps 4)
   if (table_c && entries <= (1u << 20) && chunk < (uint32_t)(entries >> 16)) chunk = (uint32_t)(entries >> 16);
+  else if (table_c && entries <= (1u << 21) && chunk < (uint32_t)(entries >> 17)) chunk = (uint32_t)(entries >> 17);    // 2^17 points: 0.723 -> 0.675 ms
   if (chunk < 4) chunk = 4;
   if (chunk > chunk_cap) chunk = chunk_cap;
   plan.chunk = env_u32("BP_MSM_CHUNK", chunk);
