@@ -100,15 +100,17 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   plan.parts = plan.B <= (1u << MSM_HIST_LOG) ? 1 : plan.B >> MSM_HIST_LOG;
   const uint64_t entries = (uint64_t)W * n;
   // entries per lane: the kernel runs 2 waves per SIMD = 131072 lanes at a time and every lane does the same work, so the
-  // lane count should land just under a whole number of such rounds -- 262144 lanes = two rounds.  (A power-of-two chunk
-  // wasted up to a third of the second round whenever windows * n was not a power of two: 13 or 15 windows.)
-  // tables: B buckets hold all W * n entries, so chunks grow with n; per-window buckets are short, cap the chunk at 64.
-  uint32_t chunk = (uint32_t)((entries + 262143) / 262144);
+  // lane count should land just under a whole number of such rounds.  (A power-of-two chunk wasted up to a third of the last
+  // round whenever windows * n was not a power of two: 13 or 15 windows.)  Measured with tables (r02_chunk_rounds_ab.txt):
+  //   up to 2^20 entries (2^16 points): half a round -- chains of 16 leave two partials per bucket instead of eight (0.531 -> 0.482 ms);
+  //   up to 2^24 entries (2^20 points): ONE round (2^20: 3.13 -> 3.03 ms, 2^18 1.004 -> 0.979, 2^17 0.723 -> 0.675);
+  //   beyond: two rounds (2^21 .. 2^24 are equal or 1-3 % better with two: the second round evens out the lanes' finish times).
+  // Per-window buckets (no tables) are short: cap the chunk at 64.
   const uint32_t chunk_cap = table_c ? 1024u : 64u;
-  // latency regime (<= 2^20 entries, e.g. 2^16 points): one wave per SIMD with chains of 16 leaves two partials per bucket instead
-  // of eight for the fix-up (2^16 with tables: 0.531 -> 0.482 ms; 2^14 keeps 4)
-  if (table_c && entries <= (1u << 20) && chunk < (uint32_t)(entries >> 16)) chunk = (uint32_t)(entries >> 16);
-  else if (table_c && entries <= (1u << 21) && chunk < (uint32_t)(entries >> 17)) chunk = (uint32_t)(entries >> 17);    // 2^17 points: 0.723 -> 0.675 ms
+  uint32_t chunk;
+  if (table_c && entries <= (1u << 20)) chunk = (uint32_t)(entries >> 16);
+  else if (table_c && entries <= (1u << 24)) chunk = (uint32_t)((entries + 131071) / 131072);
+  else chunk = (uint32_t)((entries + 262143) / 262144);
   if (chunk < 4) chunk = 4;
   if (chunk > chunk_cap) chunk = chunk_cap;
   plan.chunk = env_u32("BP_MSM_CHUNK", chunk);
