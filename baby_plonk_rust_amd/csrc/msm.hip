@@ -103,13 +103,13 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   // lane count should land just under a whole number of such rounds.  (A power-of-two chunk wasted up to a third of the last
   // round whenever windows * n was not a power of two: 13 or 15 windows.)  Measured with tables (r02_chunk_rounds_ab.txt):
   //   up to 2^20 entries (2^16 points): half a round -- chains of 16 leave two partials per bucket instead of eight (0.531 -> 0.482 ms);
-  //   up to 2^24 entries (2^20 points): ONE round (2^20: 3.13 -> 3.03 ms, 2^18 1.004 -> 0.979, 2^17 0.723 -> 0.675);
+  //   up to 2*10^7 entries (2^20 points and the prover's 2^20 + 6): ONE round (2^20: 3.13 -> 3.03 ms, 2^18 1.004 -> 0.979, 2^17 0.723 -> 0.675);
   //   beyond: two rounds (2^21 .. 2^24 are equal or 1-3 % better with two: the second round evens out the lanes' finish times).
   // Per-window buckets (no tables) are short: cap the chunk at 64.
   const uint32_t chunk_cap = table_c ? 1024u : 64u;
   uint32_t chunk;
   if (table_c && entries <= (1u << 20)) chunk = (uint32_t)(entries >> 16);
-  else if (table_c && entries <= (1u << 24)) chunk = (uint32_t)((entries + 131071) / 131072);
+  else if (table_c && entries <= 20000000u) chunk = (uint32_t)((entries + 131071) / 131072);      // 2^24 and a little more: the prover's SRS has n + 6 points
   else chunk = (uint32_t)((entries + 262143) / 262144);
   if (chunk < 4) chunk = 4;
   if (chunk > chunk_cap) chunk = chunk_cap;
