@@ -66,6 +66,7 @@ SIGNATURES = {
     "bp_msm_last_stats": (_int, [_vp, _pp(C.c_float), _pp(C.c_float), _pp(_u64), _pp(_u32)]),
     "bp_ntt_fr": (_int, [_vp, _vp, _u32, _int, _int, _sz, _sz]),
     "bp_ntt_fr_device": (_int, [_vp, _vp, _u32, _int, _sz, _sz]),
+    "bp_ntt_fr_device_async": (_int, [_vp, _vp, _u32, _int, _sz, _sz]),
     "bp_ntt_last_stats": (_int, [_vp, _pp(C.c_float), _pp(_u32)]),
     "bp_ntt_last_members": (_int, [_vp]),
     "bp_fr_convert": (_int, [_vp, _sz, _int, _int, _vp]),

@@ -216,6 +216,11 @@ class Context:
         self.check(self._lib.bp_ntt_fr_device(self._h, ptr, log_n, int(inverse), batch, stride if stride else (1 << log_n)),
                    "bp_ntt_fr_device")
 
+    def ntt_device_async(self, ptr, log_n, inverse=False, batch=1, stride=None):
+        """enqueue only (bp_ntt_fr_device_async); synchronize() waits"""
+        self.check(self._lib.bp_ntt_fr_device_async(self._h, ptr, log_n, int(inverse), batch, stride if stride else (1 << log_n)),
+                   "bp_ntt_fr_device_async")
+
     def ntt_stats(self):
         ms, p = C.c_float(), C.c_uint32()
         self.check(self._lib.bp_ntt_last_stats(self._h, C.byref(ms), C.byref(p)), "bp_ntt_last_stats")

@@ -91,6 +91,7 @@ struct bp_ctx {
   bool msm_tables = false;
   float prove_ms[6] = {0, 0, 0, 0, 0, 0};            // host wall clock of rounds 1..5 and of the whole bp_prove
   float ntt_ms = 0;
+  bool ntt_async_pending = false;  // bp_ntt_fr_device_async enqueued a transform whose events have not been read yet
   uint32_t ntt_passes = 0;
   uint32_t ntt_members = 1;       // members of a group context that took part in the last host transform
   void* pinned = nullptr;                          // small pinned staging buffer (window sums etc.)

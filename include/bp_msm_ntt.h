@@ -164,7 +164,10 @@ int  bp_msm_last_used_tables(bp_ctx* ctx);
 int  bp_ntt_fr(bp_ctx* ctx, void* data, uint32_t log_n, int inverse, int scalar_fmt, size_t batch, size_t stride);
 /* Same on HBM-resident Montgomery data. */
 int  bp_ntt_fr_device(bp_ctx* ctx, void* d_data, uint32_t log_n, int inverse, size_t batch, size_t stride);
-/* HIP-event duration of all kernels of the last bp_ntt_fr_device call. */
+/* Same, enqueued only: returns once the kernels are on the context's stream (the one given to bp_set_stream, or the context's own);
+ * bp_synchronize or any blocking entry point of this context waits for them.  d_data must stay valid until then. */
+int  bp_ntt_fr_device_async(bp_ctx* ctx, void* d_data, uint32_t log_n, int inverse, size_t batch, size_t stride);
+/* HIP-event duration of all kernels of the last bp_ntt_fr_device / _async call (0 while an enqueued one is still running). */
 int  bp_ntt_last_stats(bp_ctx* ctx, float* device_ms, uint32_t* passes);
 /* Group contexts (bp_init_multi) and host data: batch > 1 deals the columns round-robin to the members (option i);
  * ONE transform of 2^22 elements or more (BP_NTT_GROUP_SPLIT_FROM) is cut over the members (option ii): each uploads a slice

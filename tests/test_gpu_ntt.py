@@ -104,3 +104,20 @@ def test_2p24_round_trip_and_spot_checks(ctx):
     ctx.ntt_device(t.data_ptr(), logn, inverse=True)
     assert (t.cpu().numpy().view(np.uint64) == a).all()
     assert ctx.ntt_stats()["passes"] == 3
+
+
+def test_async_transforms_back_to_back(ctx):
+    """bp_ntt_fr_device_async: transforms enqueued on the context's stream without a host wait in between"""
+    import torch
+    x = O.splitmix_scalars(1 << 14, 0xA5)
+    t = torch.from_numpy(x.view(np.int64).copy()).cuda()
+    torch.cuda.synchronize()
+    ctx.ntt_device_async(t.data_ptr(), 14)                       # forward, inverse, forward: ends as one forward transform
+    ctx.ntt_device_async(t.data_ptr(), 14, inverse=True)
+    ctx.ntt_device_async(t.data_ptr(), 14)
+    ctx.synchronize()
+    assert (t.cpu().numpy().view(np.uint64).reshape(-1, 4) == O.ntt_fast(x)).all()
+    st = ctx.ntt_stats()
+    assert st["device_ms"] > 0 and st["passes"] == 2
+    ctx.ntt_device(t.data_ptr(), 14, inverse=True)               # a blocking call after enqueued ones
+    assert (t.cpu().numpy().view(np.uint64).reshape(-1, 4) == x).all()
