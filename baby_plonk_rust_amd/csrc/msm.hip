@@ -43,6 +43,7 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
     if (chunk < 4) chunk = 4;
     if (chunk > 1024) chunk = 1024;
     plan.chunk = env_u32("BP_MSM_CHUNK", chunk);
+    plan.lanes = getenv("BP_MSM_CHUNK") ? 0u : (uint32_t)(((uint64_t)plan.W * n + plan.chunk - 1) / plan.chunk);
     plan.slices = 1;
     plan.seg = 1;
     return;
@@ -114,6 +115,7 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   if (chunk < 4) chunk = 4;
   if (chunk > chunk_cap) chunk = chunk_cap;
   plan.chunk = env_u32("BP_MSM_CHUNK", chunk);
+  plan.lanes = getenv("BP_MSM_CHUNK") ? 0u : (uint32_t)((entries + plan.chunk - 1) / plan.chunk);      // = the host's n_chunks
   // count/scatter workgroups per window: each flushes its whole LDS histogram with global atomics, so fewer, fatter
   // slices are cheaper (~32 Ki points each) as long as >= 256 workgroups remain to fill the CUs (measured: 2^16, 2^20, 2^24)
   uint32_t slices = (uint32_t)(n >> 15), lo = 256 / W, hi = 1024 / W;

@@ -44,7 +44,10 @@ struct MsmPlan {
   uint32_t c;          // window bits
   uint32_t W;          // windows
   uint32_t B;          // buckets per window = 2^(c-1)
-  uint32_t chunk;      // entries per lane in msm_accumulate
+  uint32_t chunk;      // entries per lane in msm_accumulate when every digit is non-zero (sizes the lane count and the partial slots)
+  uint32_t lanes;      // 0: the chunk is fixed (BP_MSM_CHUNK).  Else the lanes of msm_accumulate = ceil(W n / chunk): the kernels cut
+                       // the sorted list into ceil(M / lanes) entries per lane from the ACTUAL entry count M (zero digits are
+                       // not entries: small or sparse scalars keep every lane busy with short chains instead of a few lanes with long ones)
   uint32_t slices;     // workgroups per window in count/scatter
   uint32_t seg;        // buckets per lane in msm_reduce
   uint32_t bias[9];    // sum_{w < W-1} 2^(c-1) * 2^(c*w)   (the top window is unsigned)
@@ -673,6 +676,15 @@ __global__ void __launch_bounds__(256) srs_window_tables(const g1_affine* __rest
   }
 }
 
+// entries per lane for a sorted list of M entries (<= plan.chunk, so the lanes and partial slots sized by the host suffice)
+__device__ __forceinline__ uint32_t msm_lane_chunk(const MsmPlan& plan, uint32_t M) {
+  if (!plan.lanes) return plan.chunk;
+  // not below a quarter of the full chunk (nor below 32): a bucket that holds most of a skewed input (scalars 0 / 1: one bucket of n / 2 entries)
+  // is cut into entries / chunk partials, which ONE workgroup of msm_fixup_long adds up -- chains of 4 made that 5 ms at 2^20
+  const uint32_t c = (uint32_t)(((uint64_t)M + plan.lanes - 1) / plan.lanes);
+  const uint32_t small = plan.chunk < 32 ? plan.chunk : 32u, floor_c = plan.chunk / 4 > small ? plan.chunk / 4 : small;
+  return c < floor_c ? floor_c : c;
+}
 // largest g in [0, total) with offsets[g] <= p   (offsets is non-decreasing, offsets[0] = 0)
 __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offsets, uint32_t total, uint32_t p) {
   uint32_t lo = 0, hi = total;                 // invariant: offsets[lo] <= p < offsets[hi]
@@ -691,10 +703,11 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
   const uint32_t total = plan.total;
   const uint32_t M = offsets[total];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t p0_64 = (uint64_t)t * plan.chunk;
+  const uint32_t chunk = msm_lane_chunk(plan, M);
+  const uint64_t p0_64 = (uint64_t)t * chunk;
   if (p0_64 >= M) return;
   const uint32_t p0 = (uint32_t)p0_64;
-  const uint32_t p1 = (uint64_t)p0 + plan.chunk < M ? p0 + plan.chunk : M;
+  const uint32_t p1 = (uint64_t)p0 + chunk < M ? p0 + chunk : M;
 
   uint32_t g = bucket_of(offsets, total, p0);
   uint32_t g_end = offsets[g + 1];
@@ -824,7 +837,8 @@ msm_fixup(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __res
   if (g >= total) return;                         // every exit below is uniform over the G lanes of a bucket
   const uint32_t a = offsets[g], b = offsets[g + 1];
   if (a == b) return;
-  const uint32_t t_lo = a / plan.chunk, t_hi = (b - 1) / plan.chunk;
+  const uint32_t chunk = msm_lane_chunk(plan, offsets[total]);
+  const uint32_t t_lo = a / chunk, t_hi = (b - 1) / chunk;
   if (t_lo == t_hi) return;                       // the whole bucket sat inside one chunk: already stored
   if (t_hi - t_lo >= FIXUP_LONG * G) {
     uint32_t k = 0;
@@ -838,7 +852,7 @@ msm_fixup(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __res
   g1_proj28 acc = g1_identity28();
   bool first = true;
   for (uint32_t t = t_lo + sub; t <= t_hi; t += G) {
-    g1_proj28 q = load_proj28(&partial[2 * (size_t)t + partial_slot(a, t, plan.chunk)]);
+    g1_proj28 q = load_proj28(&partial[2 * (size_t)t + partial_slot(a, t, chunk)]);
     if (first) acc = q; else g1_add28(acc, acc, q);
     first = false;
   }
@@ -861,10 +875,11 @@ msm_fixup_long(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* 
   for (uint32_t k = blockIdx.x; k < n_long; k += gridDim.x) {
     const uint32_t g = long_list[k];
     const uint32_t a = offsets[g], b = offsets[g + 1];
-    const uint32_t t_lo = a / plan.chunk, t_hi = (b - 1) / plan.chunk;
+    const uint32_t chunk = msm_lane_chunk(plan, offsets[plan.total]);
+    const uint32_t t_lo = a / chunk, t_hi = (b - 1) / chunk;
     g1_proj28 acc = g1_identity28();
     for (uint32_t t = t_lo + threadIdx.x; t <= t_hi; t += blockDim.x) {
-      g1_proj28 q = load_proj28(&partial[2 * (size_t)t + partial_slot(a, t, plan.chunk)]);
+      g1_proj28 q = load_proj28(&partial[2 * (size_t)t + partial_slot(a, t, chunk)]);
       g1_add28(acc, acc, q);
     }
     g1_proj28 tot = block_tree_sum28(acc, blockDim.x);
