@@ -703,7 +703,7 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
   const uint32_t total = plan.total;
   const uint32_t M = offsets[total];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t chunk = msm_lane_chunk(plan, M);
+  const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)msm_lane_chunk(plan, M));     // the same in every lane: keep it scalar
   const uint64_t p0_64 = (uint64_t)t * chunk;
   if (p0_64 >= M) return;
   const uint32_t p0 = (uint32_t)p0_64;

@@ -91,6 +91,11 @@ def main():
                        "global_store": sum(1 for l in loop if l.strip().startswith(("global_store", "buffer_store")))},
         }
     result["source"] = "hipcc -O3 --offload-arch=gfx950 --cuda-device-only -S baby_plonk_rust_amd/csrc/msm.hip; hottest back-edge span of the kernel"
+    result["note"] = ("a static count of the whole span between the loop label and its back edge: it includes whatever the compiler lays out "
+                      "inside it -- the bucket-boundary block (flush + next bucket: ~100 v_mov, the stores, the offset loads), which a wave "
+                      "runs in about one of eight iterations at 2^20 points.  With that block outside the span (as an earlier build of the same "
+                      "loop had it) the count is 5 022 = 4 288 + 734; the roofline priced from this file is therefore an upper bound on the work "
+                      "per addition, by ~2 %.  The register-only microbenchmark (tools/ubench_g1add.hip) is the layout-independent reference.")
     result["quarter_rate_classes"] = list(QUARTER)
     with open(args.out, "w") as f:
         json.dump(result, f, indent=1)
