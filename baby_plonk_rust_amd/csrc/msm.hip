@@ -36,10 +36,9 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
     plan.wbuckets = 0;
     plan.wpoints = (uint32_t)table_stride;
     plan.parts = plan.B <= (1u << MSM_HIST_LOG) ? 1 : plan.B >> MSM_HIST_LOG;
-    // digits of a uniform scalar: 256 / (w + 1) + ~0.45 (measured 15.49 / 13.91 / 12.71 at w = 16 / 18 / 20); the lanes must not spill
-    // into a third wave round, so the chunk is sized for 0.7 above the asymptote
-    const uint64_t expected = ((uint64_t)n * 2560 / (w + 1) + (uint64_t)n * 7) / 10 + 1;
-    uint32_t chunk = (uint32_t)((expected + 262143) / 262144);
+    // lanes: one wave round (131 072) for the worst case of every slot filled; the kernels cut the sorted list by the actual
+    // entry count (a uniform scalar fills 256 / (w + 1) + ~0.45 of its slots: 15.49 / 13.91 / 12.71 at w = 16 / 18 / 20)
+    uint32_t chunk = (uint32_t)(((uint64_t)plan.W * n + 131071) / 131072);
     if (chunk < 4) chunk = 4;
     if (chunk > 1024) chunk = 1024;
     plan.chunk = env_u32("BP_MSM_CHUNK", chunk);
@@ -235,6 +234,10 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   uint32_t *long_count, *long_list;
   long_count = counts + total;
   BP_TRY(ws_get(ctx, "msm.long_list", (size_t)long_cap * 4, (void**)&long_list));
+  // slice sums of the buckets that take several workgroups: those have > FIXUP_LONG_SPLIT_FROM partials, so there are few of them, but the
+  // slot is addressed by the bucket's place in the list
+  proj28_slot* long_scratch;
+  BP_TRY(ws_get(ctx, "msm.long_scratch", (size_t)long_cap * FIXUP_LONG_SLICES * sizeof(proj28_slot), (void**)&long_scratch));
   uint32_t* tile_sums;
   BP_TRY(ws_get(ctx, "msm.tile_sums", 4096 * 4, (void**)&tile_sums));
   BP_TRY(ws_get(ctx, "msm.sorted", max_entries * 4, (void**)&sorted));
@@ -345,8 +348,10 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   else
     hipLaunchKernelGGL(msm_fixup<1>, dim3((total + 255) / 256), dim3(256), 0, st, offsets, plan, bucket_sum, partial, long_count, long_list,
                        long_cap);
-  hipLaunchKernelGGL(msm_fixup_long, dim3(1024), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
-                     long_count, long_list, long_cap);
+  hipLaunchKernelGGL(msm_fixup_long, dim3(1024, FIXUP_LONG_SLICES), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
+                     long_count, long_list, long_cap, long_scratch);
+  hipLaunchKernelGGL(msm_fixup_long_merge, dim3(1024), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, long_count, long_list,
+                     long_cap, long_scratch);
   if (table_c) {
     if (planes_log == 7)
       hipLaunchKernelGGL((msm_planes_block<128, 2>), dim3(blocks_per_window, Wr), dim3(128), 256 * sizeof(proj28_slot), st, offsets, plan,

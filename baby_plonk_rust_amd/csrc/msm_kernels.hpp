@@ -866,23 +866,50 @@ msm_fixup(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __res
 extern __shared__ uint4 msm_lds_tree[];
 __device__ __forceinline__ g1_proj28 block_tree_sum28(g1_proj28 v, uint32_t live);
 
-// one workgroup per queued bucket
+// Queued (long) buckets.  A bucket of up to FIXUP_LONG_SPLIT_FROM partials is summed by one workgroup; a longer one -- a bucket that
+// holds a large share of a skewed input (scalars 0 / 1: one bucket of n / 2 entries = 16 Ki partials at 2^20) -- by FIXUP_LONG_SLICES
+// workgroups, one slice of its partials each (grid.y), into `scratch`, and msm_fixup_long_merge adds the slice sums.
+// grid (x, FIXUP_LONG_SLICES): workgroup (x, y) takes slice y of the queued buckets x, x + gridDim.x, ...
+constexpr uint32_t FIXUP_LONG_SLICES = 16, FIXUP_LONG_SPLIT_FROM = 2048;
 __global__ void __launch_bounds__(256, 2)
 msm_fixup_long(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
                const proj28_slot* __restrict__ partial, const uint32_t* __restrict__ long_count,
-               const uint32_t* __restrict__ long_list, uint32_t long_cap) {
+               const uint32_t* __restrict__ long_list, uint32_t long_cap, proj28_slot* __restrict__ scratch) {
   const uint32_t n_long = *long_count < long_cap ? *long_count : long_cap;
+  const uint32_t chunk = msm_lane_chunk(plan, offsets[plan.total]);
   for (uint32_t k = blockIdx.x; k < n_long; k += gridDim.x) {
     const uint32_t g = long_list[k];
     const uint32_t a = offsets[g], b = offsets[g + 1];
-    const uint32_t chunk = msm_lane_chunk(plan, offsets[plan.total]);
-    const uint32_t t_lo = a / chunk, t_hi = (b - 1) / chunk;
+    const uint32_t t_lo = a / chunk, t_hi = (b - 1) / chunk, P = t_hi - t_lo + 1;
+    const bool split = P > FIXUP_LONG_SPLIT_FROM;                  // uniform over the workgroup (and over the bucket's workgroups)
+    if (!split && blockIdx.y != 0) continue;
+    const uint32_t per = split ? (P + FIXUP_LONG_SLICES - 1) / FIXUP_LONG_SLICES : P;
+    const uint32_t s_lo = t_lo + blockIdx.y * per, s_hi = s_lo + per - 1 < t_hi ? s_lo + per - 1 : t_hi;      // inclusive; empty when s_lo > t_hi
     g1_proj28 acc = g1_identity28();
-    for (uint32_t t = t_lo + threadIdx.x; t <= t_hi; t += blockDim.x) {
-      g1_proj28 q = load_proj28(&partial[2 * (size_t)t + partial_slot(a, t, chunk)]);
+    for (uint64_t t = (uint64_t)s_lo + threadIdx.x; t <= s_hi; t += blockDim.x) {
+      g1_proj28 q = load_proj28(&partial[2 * (size_t)t + partial_slot(a, (uint32_t)t, chunk)]);
       g1_add28(acc, acc, q);
     }
     g1_proj28 tot = block_tree_sum28(acc, blockDim.x);
+    if (threadIdx.x == 0) store_proj28(split ? &scratch[(size_t)k * FIXUP_LONG_SLICES + blockIdx.y] : &bucket_sum[g], tot);
+    __syncthreads();
+  }
+}
+// one workgroup of FIXUP_LONG_SLICES lanes' worth per split bucket: the slice sums -> the bucket sum
+__global__ void __launch_bounds__(256, 2)
+msm_fixup_long_merge(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
+                     const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list, uint32_t long_cap,
+                     const proj28_slot* __restrict__ scratch) {
+  const uint32_t n_long = *long_count < long_cap ? *long_count : long_cap;
+  const uint32_t chunk = msm_lane_chunk(plan, offsets[plan.total]);
+  for (uint32_t k = blockIdx.x; k < n_long; k += gridDim.x) {
+    const uint32_t g = long_list[k];
+    const uint32_t a = offsets[g], b = offsets[g + 1];
+    const uint32_t P = (b - 1) / chunk - a / chunk + 1;
+    if (P <= FIXUP_LONG_SPLIT_FROM) continue;                      // uniform
+    g1_proj28 v = g1_identity28();
+    if (threadIdx.x < FIXUP_LONG_SLICES) v = load_proj28(&scratch[(size_t)k * FIXUP_LONG_SLICES + threadIdx.x]);
+    g1_proj28 tot = block_tree_sum28(v, FIXUP_LONG_SLICES);
     if (threadIdx.x == 0) store_proj28(&bucket_sum[g], tot);
     __syncthreads();
   }
