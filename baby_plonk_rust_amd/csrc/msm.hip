@@ -348,9 +348,9 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   else
     hipLaunchKernelGGL(msm_fixup<1>, dim3((total + 255) / 256), dim3(256), 0, st, offsets, plan, bucket_sum, partial, long_count, long_list,
                        long_cap);
-  hipLaunchKernelGGL(msm_fixup_long, dim3(1024, FIXUP_LONG_SLICES), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
+  hipLaunchKernelGGL(msm_fixup_long, dim3(512, FIXUP_LONG_SLICES), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
                      long_count, long_list, long_cap, long_scratch);
-  hipLaunchKernelGGL(msm_fixup_long_merge, dim3(1024), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, long_count, long_list,
+  hipLaunchKernelGGL(msm_fixup_long_merge, dim3(512), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, long_count, long_list,
                      long_cap, long_scratch);
   if (table_c) {
     if (planes_log == 7)

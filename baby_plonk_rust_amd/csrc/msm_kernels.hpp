@@ -870,7 +870,7 @@ __device__ __forceinline__ g1_proj28 block_tree_sum28(g1_proj28 v, uint32_t live
 // holds a large share of a skewed input (scalars 0 / 1: one bucket of n / 2 entries = 16 Ki partials at 2^20) -- by FIXUP_LONG_SLICES
 // workgroups, one slice of its partials each (grid.y), into `scratch`, and msm_fixup_long_merge adds the slice sums.
 // grid (x, FIXUP_LONG_SLICES): workgroup (x, y) takes slice y of the queued buckets x, x + gridDim.x, ...
-constexpr uint32_t FIXUP_LONG_SLICES = 16, FIXUP_LONG_SPLIT_FROM = 2048;
+constexpr uint32_t FIXUP_LONG_SLICES = 8, FIXUP_LONG_SPLIT_FROM = 2048;
 __global__ void __launch_bounds__(256, 2)
 msm_fixup_long(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
                const proj28_slot* __restrict__ partial, const uint32_t* __restrict__ long_count,
