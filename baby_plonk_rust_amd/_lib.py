@@ -91,6 +91,7 @@ SIGNATURES = {
     "bp_roots_of_unity_device": (_int, [_vp, _u64, _vp]),
     "bp_grand_product_device": (_int, [_vp] + [_vp] * 6 + [_sz] + [_vp] * 4 + [_vp]),
     "bp_commit_device": (_int, [_vp, _u64, _vp, _sz, _int, _vp]),
+    "bp_commit_many_device": (_int, [_vp, _u64, _vp, _vp, _sz, _int, _vp]),
 }
 
 _lib = None

@@ -520,6 +520,19 @@ def commit_device(setup, poly):
     return bytes(out)
 
 
+def commit_many_device(setup, polys):
+    """several Setup::commit calls in one (bp_commit_many_device): the pipelines of the commitments overlap"""
+    c = setup.ctx
+    k = len(polys)
+    if k == 0:
+        return []
+    ptrs = (C.c_void_p * k)(*[p._ptr() for p in polys])
+    lens = (C.c_size_t * k)(*[len(p) for p in polys])
+    out = np.zeros(96 * k, dtype=np.uint8)
+    c.check(c._lib.bp_commit_many_device(c._h, setup.handle, ptrs, lens, k, polys[0].basis, out.ctypes.data), "Setup.commit (many)")
+    return [bytes(out[96 * i: 96 * (i + 1)]) for i in range(k)]
+
+
 def round_2_z_device(a, b, c, s1, s2, s3, beta, gamma, k1=None, k2=None):
     """prover.rs:279-319 on DevicePolynomial columns -> DevicePolynomial (Lagrange)"""
     ctx = a.ctx

@@ -1360,6 +1360,22 @@ int bp_commit_device(bp_ctx* ctx, uint64_t srs_handle, const void* d_coeffs, siz
   return bp_g1_partial_to_bytes96(part, out96);
 }
 
+// Several commitments against one SRS in one call (the three of prover.rs:249-251, of :483-485, the two of :640-641): their
+// pipelines are in flight together (commit_many: per-device lanes, or queued shards on a group context), so one commitment's
+// latency-bound tail runs under another's bulk kernel.
+int bp_commit_many_device(bp_ctx* ctx, uint64_t srs_handle, const void* const* d_coeffs, const size_t* n, size_t count, int basis,
+                          uint8_t* out96) {
+  if (!ctx || !basis_ok(basis) || (count && (!d_coeffs || !n || !out96))) return BP_ERR_INVALID_ARG;
+  if (basis != BP_BASIS_MONOMIAL) return fail(ctx, BP_ERR_BASIS, "commit needs the Monomial basis (setup.rs:34)", hipSuccess, __FILE__, __LINE__);
+  if (count > 64) return fail(ctx, BP_ERR_TOO_LARGE, "more than 64 commitments in one call", hipSuccess, __FILE__, __LINE__);
+  for (size_t i = 0; i < count; i++)
+    if (n[i] && !d_coeffs[i]) return BP_ERR_INVALID_ARG;
+  std::vector<g1_proj> cm(count);
+  BP_TRY(commit_many(ctx, srs_handle, reinterpret_cast<const fr_t* const*>(d_coeffs), n, (int)count, cm.data()));
+  for (size_t i = 0; i < count; i++) host_encode96(out96 + 96 * i, cm[i]);
+  return BP_OK;
+}
+
 int bp_grand_product(bp_ctx* ctx, const void* a, const void* b, const void* c, const void* s1, const void* s2, const void* s3, size_t n,
                      const void* beta32, const void* gamma32, const void* k1_32, const void* k2_32, int scalar_fmt, void* z_out) {
   if (!ctx || !fmt_ok(scalar_fmt) || !beta32 || !gamma32 || !k1_32 || !k2_32 || (n && (!a || !b || !c || !s1 || !s2 || !s3 || !z_out)))

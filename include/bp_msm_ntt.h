@@ -232,6 +232,10 @@ int  bp_grand_product_device(bp_ctx* ctx, const void* d_a, const void* d_b, cons
                              const void* d_s3, size_t n, const void* beta32, const void* gamma32, const void* k1_32,
                              const void* k2_32, void* d_z);
 int  bp_commit_device(bp_ctx* ctx, uint64_t srs_handle, const void* d_coeffs, size_t n, int basis, uint8_t out96[96]);
+/* `count` commitments against one SRS (prover.rs:249-251, 483-485, 640-641 commit two or three polynomials in a row): polynomial i
+ * = n[i] Montgomery coefficients in HBM at d_coeffs[i]; out96 receives count x 96 bytes.  The pipelines run together. */
+int  bp_commit_many_device(bp_ctx* ctx, uint64_t srs_handle, const void* const* d_coeffs, const size_t* n, size_t count, int basis,
+                           uint8_t* out96);
 
 /* Setup::commit (setup.rs:32-37): asserts Monomial basis, MSM of the coefficients against the SRS. */
 int  bp_commit(bp_ctx* ctx, uint64_t srs_handle, const void* coeffs, size_t n, int basis, int scalar_fmt,

@@ -254,3 +254,40 @@ def test_group_context_edges():
     assert many.srs_export(hm, 100, 0) == b""
     many.close()
     one.close()
+
+
+def test_commit_many_device():
+    """bp_commit_many_device: several Setup::commit calls of one prover round in one call -- same bytes as one at a time, on a
+    single-device and on a group context, with polynomials of different lengths (longer than the SRS: zip truncation), an empty one,
+    and the Lagrange-basis assertion of setup.rs:34"""
+    import time
+    for ctx in (bp.Context(0), bp.Context([0, 0, 0])):
+        n = 5000
+        setup = bp.Setup.generate_srs(n, 0xABCDEF, ctx)
+        polys = [bp.DevicePolynomial(O.splitmix_scalars(m, 0xC0 + m), bp.BASIS_MONOMIAL, ctx) for m in (n, n - 6, 17, n + 9, 1)]
+        one_by_one = [bp.commit_device(setup, p) for p in polys]
+        assert bp.commit_many_device(setup, polys) == one_by_one
+        assert bp.commit_many_device(setup, polys[:1]) == one_by_one[:1] and bp.commit_many_device(setup, []) == []
+        with pytest.raises(bp.BpError):
+            bp.commit_many_device(setup, [bp.DevicePolynomial(O.splitmix_scalars(8, 1), bp.BASIS_LAGRANGE, ctx)])
+        ctx.close()
+    # what it buys at 2^20: three commitments together against three in a row
+    ctx = bp.Context(0)
+    n = 1 << 20
+    setup = bp.Setup.generate_srs(n, 0x1234, ctx)
+    t = torch.empty((3, n, 4), dtype=torch.int64, device="cuda")
+    for j in range(3):
+        ctx.synthetic_scalars_device(t[j].data_ptr(), n, 0x77 + j)
+    torch.cuda.synchronize()
+    polys = [bp.DevicePolynomial(t[j], bp.BASIS_MONOMIAL, ctx) for j in range(3)]
+    want = [bp.commit_device(setup, p) for p in polys]
+    assert bp.commit_many_device(setup, polys) == want
+    t0 = time.perf_counter()
+    for _ in range(3):
+        [bp.commit_device(setup, p) for p in polys]
+    t1 = time.perf_counter()
+    for _ in range(3):
+        bp.commit_many_device(setup, polys)
+    t2 = time.perf_counter()
+    print("three 2^20 commitments: one at a time %.2f ms, together %.2f ms" % (1e3 * (t1 - t0) / 3, 1e3 * (t2 - t1) / 3))
+    ctx.close()
