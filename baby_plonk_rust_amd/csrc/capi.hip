@@ -5,7 +5,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -171,6 +173,79 @@ static int download_fr(bp_ctx* ctx, fr_t* d, void* host, size_t n, int fmt) {
   return BP_OK;
 }
 
+// ---- group contexts: one persistent host thread per member ----------------------------------------------------------
+// Copies from and to pageable host memory are staged by the thread that issues them, and a stream is waited for by the thread
+// that calls hipStreamSynchronize: a single-threaded caller (the reference's Setup::commit, setup.rs:32-37) would serialise the
+// members' PCIe transfers and host epilogues.  Each member beyond the first therefore owns a worker thread, parked on a
+// condition variable between calls.
+namespace bp {
+struct MemberWorker {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, done = true, stop = false;
+  std::thread th;
+  MemberWorker() : th([this] { loop(); }) {}
+  ~MemberWorker() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    th.join();
+  }
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return has_job || stop; });
+      if (stop) return;
+      std::function<void()> j = std::move(job);
+      has_job = false;
+      lk.unlock();
+      j();
+      lk.lock();
+      done = true;
+      cv.notify_all();
+    }
+  }
+  void submit(std::function<void()> j) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = std::move(j);
+      has_job = true;
+      done = false;
+    }
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return done; });
+  }
+};
+}  // namespace bp
+
+// work(r) for every member r for which use(r) holds: member 0 on the calling thread, the others on their own threads, all at once;
+// returns when every one has finished.  A plain context (or a call that concerns one member) runs inline.
+static void over_members(bp_ctx* ctx, size_t R, const std::function<bool(size_t)>& use, const std::function<void(size_t)>& work) {
+  bp_ctx* lead = ctx->leader ? ctx->leader : ctx;
+  std::vector<size_t> sent;
+  for (size_t r = 1; r < R; r++) {
+    if (!use(r)) continue;
+    if (r - 1 < lead->workers.size()) {
+      lead->workers[r - 1]->submit([&work, r] { work(r); });
+      sent.push_back(r);
+    } else {
+      work(r);
+    }
+  }
+  if (R > 0 && use(0)) work(0);
+  for (size_t r : sent) lead->workers[r - 1]->wait();
+}
+static bool force_peer_copies() {      // test hook: take the GPU-to-GPU copy branches even when both ends are the same device
+  static const bool on = [] { const char* v = getenv("BP_FORCE_PEER_COPIES"); return v && *v && *v != '0'; }();
+  return on;
+}
+
 // contiguous point range [lo, hi) of shard r of R over n points; the first n % R shards get one extra point
 static void shard_range(size_t n, size_t r, size_t R, size_t* lo, size_t* hi) {
   const size_t base = n / R, extra = n % R;
@@ -255,7 +330,10 @@ int bp_init_multi(bp_ctx** out, const int* device_ids, int n_devices) {
       }
     }
     m[0]->members = m;
-    for (int r = 1; r < n_devices; r++) m[r]->leader = m[0];
+    for (int r = 1; r < n_devices; r++) {
+      m[r]->leader = m[0];
+      m[0]->workers.push_back(new MemberWorker());
+    }
   }
   *out = m[0];
   return BP_OK;
@@ -270,6 +348,8 @@ int bp_ctx_devices(bp_ctx* ctx, int* device_ids, int cap) {
 
 void bp_destroy(bp_ctx* ctx) {
   if (!ctx) return;
+  for (MemberWorker* w : ctx->workers) delete w;
+  ctx->workers.clear();
   for (size_t r = 1; r < ctx->members.size(); r++) {
     ctx->members[r]->leader = nullptr;
     bp_destroy(ctx->members[r]);
@@ -597,7 +677,7 @@ static int msm_shard_launch(bp_ctx* m, SrsEntry* e, size_t local_first, const vo
       BP_HIP(m, hipMemcpyAsync(d, scalars, n * sizeof(fr_t), hipMemcpyHostToDevice, m->stream));
     } else {
       BP_HIP(m, hipStreamWaitEvent(m->stream, ready, 0));
-      if (src_device == m->device) BP_HIP(m, hipMemcpyAsync(d, scalars, n * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream));
+      if (src_device == m->device && !force_peer_copies()) BP_HIP(m, hipMemcpyAsync(d, scalars, n * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream));
       else BP_HIP(m, hipMemcpyPeerAsync(d, m->device, scalars, src_device, n * sizeof(fr_t), m->stream));
     }
     d_scalars = d;
@@ -628,19 +708,38 @@ static int msm_all_shards_launch(bp_ctx* ctx, uint64_t srs_handle, size_t first,
   }
   sp->pend.assign(sh.size(), MsmPending());
   sp->used.assign(sh.size(), false);
-  int rc = BP_OK;
-  for (size_t r = 0; r < sh.size() && rc == BP_OK; r++) {
+  // every shard's range, then the launches: scalars already in HBM are enqueued by this thread (asynchronous copies and kernels);
+  // host scalars go through the members' own threads, so that the uploads -- staged by the issuing thread when the memory is
+  // pageable, as a Rust Vec<Scalar> is -- run on all PCIe links at once instead of one after another
+  struct Part { SrsEntry* e; size_t local_first, cnt; const uint8_t* sc; };
+  std::vector<Part> part(sh.size(), Part{nullptr, 0, 0, nullptr});
+  std::vector<int> rcs(sh.size(), BP_OK);
+  std::vector<bool> take(sh.size(), false);
+  for (size_t r = 0; r < sh.size(); r++) {
     SrsEntry* e;
-    rc = lift(ctx, sh[r], srs_find(sh[r], hs.empty() ? srs_handle : hs[r], &e));
-    if (rc != BP_OK) break;
+    BP_TRY(lift(ctx, sh[r], srs_find(sh[r], hs.empty() ? srs_handle : hs[r], &e)));
     const size_t lo = std::max(first, e->first), hi = std::min(first + n, e->first + e->n);
     if (lo >= hi && !(sh.size() == 1)) continue;
-    const size_t cnt = lo < hi ? hi - lo : 0;
-    const uint8_t* sc = (const uint8_t*)scalars + (lo < hi ? (lo - first) * sizeof(fr_t) : 0);
+    part[r] = Part{e, lo < hi ? lo - e->first : 0, lo < hi ? hi - lo : 0, (const uint8_t*)scalars + (lo < hi ? (lo - first) * sizeof(fr_t) : 0)};
+    take[r] = true;
+  }
+  auto launch_one = [&](size_t r) {
     const int where = !scalars_on_device ? 0 : (r == 0 ? 1 : 2);
-    rc = lift(ctx, sh[r], msm_shard_launch(sh[r], e, lo < hi ? lo - e->first : 0, sc, cnt, scalar_fmt, where, ctx->device, ctx->ev[4], slot, nullptr,
-                                           &sp->pend[r]));
-    sp->used[r] = rc == BP_OK;
+    rcs[r] = msm_shard_launch(sh[r], part[r].e, part[r].local_first, part[r].sc, part[r].cnt, scalar_fmt, where, ctx->device, ctx->ev[4], slot, nullptr,
+                              &sp->pend[r]);
+  };
+  if (!scalars_on_device && sh.size() > 1) {
+    over_members(ctx, sh.size(), [&](size_t r) { return (bool)take[r]; }, launch_one);
+  } else {
+    for (size_t r = 0; r < sh.size(); r++)
+      if (take[r]) launch_one(r);
+  }
+  int rc = BP_OK;
+  for (size_t r = 0; r < sh.size(); r++) {
+    if (!take[r]) continue;
+    sp->used[r] = rcs[r] == BP_OK;             // a shard that failed to launch has nothing to wait for
+    const int rc1 = lift(ctx, sh[r], rcs[r]);
+    if (rc == BP_OK) rc = rc1;
   }
   return rc;               // the caller still finishes whatever was launched
 }
@@ -649,25 +748,15 @@ static int msm_all_shards_finish(bp_ctx* ctx, const ShardedPending& sp, int rc, 
   const std::vector<MsmPending>& pend = sp.pend;
   const std::vector<bool>& used = sp.used;
   if (pend.size() != sh.size()) return rc != BP_OK ? rc : BP_ERR_INVALID_ARG;      // nothing was launched (bad handle / offset)
-  // every launched shard is waited for, also after a failure elsewhere.  With three or more shards the waits and the host
-  // epilogues (window sums -> Horner, ~0.1 ms each) run on one host thread per shard: eight in sequence would cost more than
-  // the shards' GPU time of a 2^20-point MSM split eight ways.
+  // every launched shard is waited for, also after a failure elsewhere.  In a group the waits and the host epilogues (window
+  // sums -> Horner, ~0.1 ms each) run on the members' own threads: eight in sequence would cost more than the shards' GPU time
+  // of a 2^20-point MSM split eight ways.
   std::vector<g1_proj> part(sh.size());
   std::vector<int> rcs(sh.size(), BP_OK);
-  auto finish_one = [&](size_t r) {
+  over_members(ctx, sh.size(), [&](size_t r) { return (bool)used[r]; }, [&](size_t r) {
     DeviceGuard guard(sh[r]->device);
     rcs[r] = msm_finish(sh[r], pend[r], &part[r]);
-  };
-  {
-    std::vector<std::thread> workers;
-    size_t n_used = 0;
-    for (size_t r = 0; r < sh.size(); r++) n_used += used[r] ? 1 : 0;
-    for (size_t r = 1; r < sh.size(); r++)
-      if (used[r] && n_used >= 3) workers.emplace_back(finish_one, r);
-    for (size_t r = 0; r < sh.size(); r++)
-      if (used[r] && (r == 0 || n_used < 3)) finish_one(r);
-    for (auto& t : workers) t.join();
-  }
+  });
   g1_proj acc = g1_identity();
   float acc_ms = 0, dev_ms = 0;
   uint64_t adds = 0;
@@ -879,25 +968,29 @@ static int ntt_columns_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, 
   const size_t N = (size_t)1 << log_n, R = sh.size();
   std::vector<fr_t*> dbuf(R, nullptr);
   std::vector<size_t> cnt(R, 0);
-  int rc = BP_OK;
-  for (size_t r = 0; r < R && rc == BP_OK; r++) {
+  // one host thread per member: the column copies from and to pageable memory are staged by the thread that issues them
+  std::vector<int> rcs(R, BP_OK);
+  for (size_t r = 0; r < R; r++) cnt[r] = batch / R + (r < batch % R ? 1 : 0);
+  over_members(ctx, R, [&](size_t r) { return cnt[r] != 0; }, [&](size_t r) {
     bp_ctx* m = sh[r];
-    cnt[r] = batch / R + (r < batch % R ? 1 : 0);
-    if (cnt[r] == 0) continue;
     DeviceGuard guard(m->device);
-    rc = lift(ctx, m, ws_get(m, "io.ntt", cnt[r] * N * sizeof(fr_t), (void**)&dbuf[r]));
+    int rc = ws_get(m, "io.ntt", cnt[r] * N * sizeof(fr_t), (void**)&dbuf[r]);
     for (size_t j = 0; j < cnt[r] && rc == BP_OK; j++) {
       hipError_t e = hipMemcpyAsync(dbuf[r] + j * N, data + (r + j * R) * stride * sizeof(fr_t), N * sizeof(fr_t), hipMemcpyHostToDevice, m->stream);
-      if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "NTT column upload", e, __FILE__, __LINE__);
+      if (e != hipSuccess) rc = fail(m, BP_ERR_HIP, "NTT column upload", e, __FILE__, __LINE__);
     }
-    if (rc == BP_OK && scalar_fmt == BP_FR_BYTES_LE) rc = lift(ctx, m, fr_convert_run(m, dbuf[r], cnt[r] * N, 0));
-    if (rc == BP_OK) rc = lift(ctx, m, ntt_run(m, dbuf[r], log_n, inverse, cnt[r], N));
-    if (rc == BP_OK && scalar_fmt == BP_FR_BYTES_LE) rc = lift(ctx, m, fr_convert_run(m, dbuf[r], cnt[r] * N, 1));
+    if (rc == BP_OK && scalar_fmt == BP_FR_BYTES_LE) rc = fr_convert_run(m, dbuf[r], cnt[r] * N, 0);
+    if (rc == BP_OK) rc = ntt_run(m, dbuf[r], log_n, inverse, cnt[r], N);
+    if (rc == BP_OK && scalar_fmt == BP_FR_BYTES_LE) rc = fr_convert_run(m, dbuf[r], cnt[r] * N, 1);
     for (size_t j = 0; j < cnt[r] && rc == BP_OK; j++) {
       hipError_t e = hipMemcpyAsync(data + (r + j * R) * stride * sizeof(fr_t), dbuf[r] + j * N, N * sizeof(fr_t), hipMemcpyDeviceToHost, m->stream);
-      if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "NTT column download", e, __FILE__, __LINE__);
+      if (e != hipSuccess) rc = fail(m, BP_ERR_HIP, "NTT column download", e, __FILE__, __LINE__);
     }
-  }
+    rcs[r] = rc;
+  });
+  int rc = BP_OK;
+  for (size_t r = 0; r < R; r++)
+    if (rc == BP_OK) rc = lift(ctx, sh[r], rcs[r]);
   float ms = 0;
   for (size_t r = 0; r < R; r++) {                       // wait for every member, also after a failure elsewhere
     if (cnt[r] == 0) continue;
@@ -918,8 +1011,9 @@ static int ntt_columns_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, 
 // blocks of the intermediate buffer (member g' collects the rows e_1 of its slice: R - 1 peer copies of N / R^2 elements each,
 // over xGMI), run the remaining passes on their e_1 and download their outputs (index = e_1 mod 2^(l_1): runs of 2^(l_1) / R
 // elements).  Buffers keep the full N-element layout on every member, so the kernels address exactly as on one GPU.
-// Returns BP_ERR_UNSUPPORTED-like (1) when the shape does not split; the caller then runs the transform on the leader.  Host data
-// is written only after every member has finished, so a failure half way leaves it intact for that fallback.
+// Returns 1 (not an error code of the ABI) when the shape does not split; only then does the caller run the transform on the
+// leader.  Any other failure is returned as it is: the download phase writes `data` from every member at once, so after a
+// failed copy the buffer may be part input, part output, and must not be transformed again.
 static uint32_t env_u32(const char* name, uint32_t dflt) {
   const char* v = getenv(name);
   return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
@@ -940,22 +1034,20 @@ static int ntt_one_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, int 
     BP_TRY(lift(ctx, sh[g], ntt_tmp_buffer(sh[g], log_n, &tbuf[g])));
   }
   // copies from and to pageable host memory are staged by the calling thread: one host thread per member keeps every PCIe link busy
-  auto over_members = [&](const std::function<int(uint32_t)>& work) {
-    std::vector<std::thread> workers;
-    for (uint32_t g = 1; g < R; g++) workers.emplace_back([&, g]() { rcs[g] = work(g); });
-    rcs[0] = work(0);
-    for (auto& t : workers) t.join();
+  auto on_members = [&](const std::function<int(uint32_t)>& work) {
+    over_members(ctx, R, [](size_t) { return true; }, [&](size_t g) { rcs[g] = work((uint32_t)g); });
     for (uint32_t g = 0; g < R; g++)
       if (rcs[g] != BP_OK) return lift(ctx, sh[g], rcs[g]);
     return (int)BP_OK;
   };
-  int rc = over_members([&](uint32_t g) -> int {               // column slice up, pass 1
+  int rc = on_members([&](uint32_t g) -> int {                 // column slice up, pass 1
     bp_ctx* m = sh[g];
     DeviceGuard guard(m->device);
     hipError_t e = hipMemcpy2DAsync(dbuf[g] + g * cols, S * esz, data + g * cols * esz, S * esz, cols * esz, L1, hipMemcpyHostToDevice, m->stream);
     if (e != hipSuccess) return fail(m, BP_ERR_HIP, "NTT column-slice upload", e, __FILE__, __LINE__);
     if (scalar_fmt == BP_FR_BYTES_LE) BP_TRY(fr_convert_run(m, dbuf[g], N, 0));      // other columns: unused memory, converted and ignored
     BP_TRY(ntt_run_part(m, dbuf[g], log_n, inverse, 1, N, 0, g, R));
+    BP_HIP(m, hipEventRecord(m->ev[4], m->stream));               // pass 1 of this member is behind this event: the exchange waits for it
     BP_HIP(m, hipStreamSynchronize(m->stream));
     return BP_OK;
   });
@@ -966,7 +1058,9 @@ static int ntt_one_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, int 
     for (uint32_t from = 0; from < R && rc == BP_OK; from++) {
       if (from == to) continue;
       const size_t off = (size_t)to * rows * S + (size_t)from * cols;
-      hipError_t e = hipMemcpy2DAsync(tbuf[to] + off, S * esz, tbuf[from] + off, S * esz, cols * esz, rows, hipMemcpyDefault, m->stream);   // the runtime finds the two devices
+      // stream order, not the host wait above, is what ties the copy to `from`'s pass 1 (the event was recorded on from's stream)
+      hipError_t e = hipStreamWaitEvent(m->stream, sh[from]->ev[4], 0);
+      if (e == hipSuccess) e = hipMemcpy2DAsync(tbuf[to] + off, S * esz, tbuf[from] + off, S * esz, cols * esz, rows, hipMemcpyDefault, m->stream);   // the runtime finds the two devices
       if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "NTT block exchange", e, __FILE__, __LINE__);
     }
     if (rc == BP_OK) rc = lift(ctx, m, ntt_run_part(m, dbuf[to], log_n, inverse, 1, N, 1, to, R));
@@ -978,7 +1072,7 @@ static int ntt_one_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, int 
     if (e != hipSuccess && rc == BP_OK) rc = fail(ctx, BP_ERR_HIP, "NTT over the members", e, __FILE__, __LINE__);
   }
   if (rc != BP_OK) return rc;
-  rc = over_members([&](uint32_t g) -> int {                   // outputs e_1 + 2^(l_1) m, e_1 in the member's slice
+  rc = on_members([&](uint32_t g) -> int {                     // outputs e_1 + 2^(l_1) m, e_1 in the member's slice
     bp_ctx* m = sh[g];
     DeviceGuard guard(m->device);
     hipError_t e = hipMemcpy2DAsync(data + g * rows * esz, L1 * esz, dbuf[g] + g * rows, L1 * esz, rows * esz, S, hipMemcpyDeviceToHost, m->stream);
@@ -1010,8 +1104,8 @@ int bp_ntt_fr(bp_ctx* ctx, void* data, uint32_t log_n, int inverse, int scalar_f
   if (is_group(ctx) && batch > 1) return ntt_columns_over_members(ctx, (uint8_t*)data, log_n, inverse, scalar_fmt, batch, stride);
   if (is_group(ctx) && log_n >= env_u32("BP_NTT_GROUP_SPLIT_FROM", 22)) {     // one large transform: every member's PCIe link and a share of the work
     const int rc = ntt_one_over_members(ctx, (uint8_t*)data, log_n, inverse, scalar_fmt);
-    if (rc == BP_OK) return BP_OK;                                             // otherwise (shape does not split, or a copy failed): on the leader
-  }
+    if (rc != 1) return rc;                 // done, or a real failure (reported, never papered over: host data may be partly written);
+  }                                         // 1 = the shape does not split over this many members: on the leader
   DeviceGuard guard(ctx->device);
   ctx->ntt_members = 1;
   const size_t span = (batch - 1) * stride + N;

@@ -47,6 +47,8 @@ struct CircuitEntry {
   fr_t zh_inv[4];             // 1 / (X^n - 1) on the coset (period 4)
 };
 
+struct MemberWorker;     // persistent host thread of one member of a group context (capi.hip)
+
 struct tw29_t;
 struct NttTables {       // per (log_n, inverse); entries are 48-byte 29-bit-limb twiddle records (fr29.hpp)
   tw29_t* lo = nullptr;        // w_N^j, j < 2^h
@@ -70,6 +72,9 @@ struct bp_ctx {
   // Every member is a full single-device context (own stream, workspaces, NTT tables) driven by the leader's host thread.
   std::vector<bp_ctx*> members;
   bp_ctx* leader = nullptr;                        // set on members[1..]
+  // leader only: workers[r - 1] is the host thread that drives member r whenever the members work from or to host memory, or
+  // wait for their streams: created once in bp_init_multi, reused by every call (no thread is spawned per MSM or per transform)
+  std::vector<bp::MemberWorker*> workers;
   // Extra single-device contexts on THIS device (own stream + workspaces, created on first use): independent commitments of
   // one caller -- the three of prover rounds 1 and 3, the two of round 5, the verifier's eight -- run on them concurrently,
   // so one MSM's latency-bound tail (bucket tree, fix-up, scans) overlaps another's bulk kernel.

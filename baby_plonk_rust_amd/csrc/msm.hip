@@ -14,9 +14,14 @@ static uint32_t ilog2_floor(size_t n) {
   while ((n >> (l + 1)) != 0) l++;
   return l;
 }
-static uint32_t env_u32(const char* name, uint32_t dflt) {
+// Experiment knobs (A/B runs, tests): read from the environment, and taken only inside [lo, hi] -- a stray or mistyped
+// variable in the embedding process leaves the default in place instead of changing kernel shapes or dividing by zero.
+static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo = 0, uint32_t hi = 0xffffffffu) {
   const char* v = getenv(name);
-  return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+  if (!v || !*v) return dflt;
+  char* end = nullptr;
+  const unsigned long x = strtoul(v, &end, 10);
+  return (end == v || *end || x < lo || x > hi) ? dflt : (uint32_t)x;
 }
 
 // Window width: minimise W * (n + 2 * 2^(c-1)) (bucket adds + reduction adds).  Per-window bucket sets (any point set) are
@@ -41,8 +46,8 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
     uint32_t chunk = (uint32_t)(((uint64_t)plan.W * n + 131071) / 131072);
     if (chunk < 4) chunk = 4;
     if (chunk > 1024) chunk = 1024;
-    plan.chunk = env_u32("BP_MSM_CHUNK", chunk);
-    plan.lanes = getenv("BP_MSM_CHUNK") ? 0u : (uint32_t)(((uint64_t)plan.W * n + plan.chunk - 1) / plan.chunk);
+    plan.chunk = env_u32("BP_MSM_CHUNK", chunk, 1, 1024);
+    plan.lanes = env_u32("BP_MSM_CHUNK", 0, 1, 1024) ? 0u : (uint32_t)(((uint64_t)plan.W * n + plan.chunk - 1) / plan.chunk);
     plan.slices = 1;
     plan.seg = 1;
     return;
@@ -50,7 +55,7 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   uint32_t c = n < 32 ? 4 : ilog2_floor(n) - 3;
   if (c < 4) c = 4;
   if (c > MSM_MAX_C) c = MSM_MAX_C;
-  c = env_u32("BP_MSM_C", c);
+  c = env_u32("BP_MSM_C", c, 2, MSM_MAX_C);
   if (c > (uint32_t)MSM_MAX_C) c = MSM_MAX_C;          // per-window bucket sets: one LDS histogram per window
   if (table_c) c = table_c;                          // tables: up to MSM_MAX_TABLE_C through the partitioned sort
   if (c < 2) c = 2;
@@ -113,8 +118,8 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   else chunk = (uint32_t)((entries + 262143) / 262144);
   if (chunk < 4) chunk = 4;
   if (chunk > chunk_cap) chunk = chunk_cap;
-  plan.chunk = env_u32("BP_MSM_CHUNK", chunk);
-  plan.lanes = getenv("BP_MSM_CHUNK") ? 0u : (uint32_t)((entries + plan.chunk - 1) / plan.chunk);      // = the host's n_chunks
+  plan.chunk = env_u32("BP_MSM_CHUNK", chunk, 1, 1024);
+  plan.lanes = env_u32("BP_MSM_CHUNK", 0, 1, 1024) ? 0u : (uint32_t)((entries + plan.chunk - 1) / plan.chunk);      // = the host's n_chunks
   // count/scatter workgroups per window: each flushes its whole LDS histogram with global atomics, so fewer, fatter
   // slices are cheaper (~32 Ki points each) as long as >= 256 workgroups remain to fill the CUs (measured: 2^16, 2^20, 2^24)
   uint32_t slices = (uint32_t)(n >> 15), lo = 256 / W, hi = 1024 / W;
@@ -122,10 +127,10 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   if (slices > hi) slices = hi;
   if (slices < 1) slices = 1;
   while (slices > 1 && n / slices < 1024) slices >>= 1;
-  plan.slices = env_u32("BP_MSM_SLICES", slices);
+  plan.slices = env_u32("BP_MSM_SLICES", slices, 1, 4096);
   uint32_t seg = 1;
   while (seg < 32 && plan.total / seg > 65536) seg <<= 1;
-  plan.seg = env_u32("BP_MSM_SEG", seg);
+  plan.seg = env_u32("BP_MSM_SEG", seg, 1, 1024);
 }
 
 // 112-byte unsaturated copy of an SRS (allocated here, owned by the SRS entry)
@@ -178,16 +183,19 @@ static g1_proj slot_to_proj(const proj28_slot* slot) {
 
 // dynamic-LDS limits are per function AND per device: set them for every context at creation (bp_init), after hipSetDevice
 int msm_init_device(bp_ctx* ctx) {
-  // a full-window histogram at c = 16 needs 128 KiB of dynamic LDS, the plane tree 88 KiB
-  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_planes_block<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_planes_block<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // a full-window histogram at c = 16 needs 128 KiB of dynamic LDS
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_count, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   // these two also hold a few KiB of static LDS: the dynamic limit must leave room for it
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_final, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_long_count, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_long_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_final<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_final<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_long_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_long_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_long_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_long_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_part_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_part_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   return BP_OK;
 }
 
@@ -216,23 +224,24 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   const uint32_t W = plan.W, B = plan.B, total = plan.total, Wr = table_c ? 1 : W;   // Wr: windows left after accumulation
   const uint64_t max_entries = (uint64_t)W * n;
   const uint64_t n_chunks = (max_entries + plan.chunk - 1) / plan.chunk;
-  // bucket reduction: running sums per window, or (tables: one bucket set) the bit-plane tree in two stages of l1 + l2 levels
-  const uint32_t planes_log = env_u32("BP_MSM_PLANES_LOG", plan.c > 16 ? 7 : PLANES_BLOCK_LOG) == 7 ? 7 : PLANES_BLOCK_LOG;
-  const uint32_t l1 = plan.c - 1 < planes_log ? plan.c - 1 : planes_log, l2 = plan.c - 1 - l1;
-  const uint32_t blocks_per_window = table_c ? 1u << l2 : ((B + plan.seg - 1) / plan.seg + 255) / 256;
-  const uint32_t per_block = table_c ? l1 + 1 : 1, per_window = table_c ? plan.c : 1;     // slots
+  // bucket reduction: running sums per window (msm_reduce), or (tables: one bucket set) the bit-plane tree
+  const uint32_t blocks_per_window = table_c ? 0 : ((B + plan.seg - 1) / plan.seg + 255) / 256;
+  const uint32_t per_window = table_c ? plan.c : 1;     // slots per window that go to the host
 
   int16_t* digits = nullptr;
   uint32_t *counts, *offsets, *cursors, *sorted;
   proj28_slot *bucket_sum, *partial, *block_out, *window_sum;
-  if (plan.parts == 1 && !plan.naf) BP_TRY(ws_get(ctx, "msm.digits", max_entries * sizeof(int16_t), (void**)&digits));
-  BP_TRY(ws_get(ctx, "msm.counts", (size_t)total * 4 + 8, (void**)&counts));       // + [0] long-bucket counter, [1] scalar status: one memset
-  BP_TRY(ws_get(ctx, "msm.offsets", ((size_t)total + 1) * 4, (void**)&offsets));
-  BP_TRY(ws_get(ctx, "msm.cursors", (size_t)total * 4, (void**)&cursors));
   // a bucket is "long" when it spans >= FIXUP_LONG chunks, so at most n_chunks / FIXUP_LONG + 1 buckets can be long
   const uint32_t long_cap = (uint32_t)(n_chunks / FIXUP_LONG + 1);
-  uint32_t *long_count, *long_list;
-  long_count = counts + total;
+  // control words, zeroed by ONE memset per MSM: [0] long-bucket counter, [1] scalar status, [2] long-run counter of the sort,
+  // [4] ticket + [5 ..] partition sizes of msm_part_count, then one ticket per queued long bucket (msm_fixup_long)
+  uint32_t* ctl;
+  const size_t ctl_words = 8 + PART_MAX + long_cap;
+  BP_TRY(ws_get(ctx, "msm.ctl", ctl_words * 4, (void**)&ctl));
+  BP_TRY(ws_get(ctx, "msm.counts", (size_t)total * 4, (void**)&counts));        // bucket sizes (histogram sort; long runs of the other two)
+  BP_TRY(ws_get(ctx, "msm.offsets", ((size_t)total + 1) * 4, (void**)&offsets));
+  BP_TRY(ws_get(ctx, "msm.cursors", (size_t)total * 4, (void**)&cursors));
+  uint32_t *long_count = ctl, *long_list, *long_ticket = ctl + 8 + PART_MAX;
   BP_TRY(ws_get(ctx, "msm.long_list", (size_t)long_cap * 4, (void**)&long_list));
   // slice sums of the buckets that take several workgroups: those have > FIXUP_LONG_SPLIT_FROM partials, so there are few of them, but the
   // slot is addressed by the bucket's place in the list
@@ -245,7 +254,8 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   BP_TRY(ws_get(ctx, "msm.partial", 2 * n_chunks * sizeof(proj28_slot), (void**)&partial));
   const uint32_t n_planes = Wr * per_window;        // tables: A and the c - 1 bit planes; else one sum per window
   if (n_planes > (uint32_t)MSM_MAX_WINDOWS) return fail(ctx, BP_ERR_TOO_LARGE, "MSM windows", hipSuccess, __FILE__, __LINE__);
-  BP_TRY(ws_get(ctx, "msm.block_out", (size_t)Wr * blocks_per_window * per_block * sizeof(proj28_slot), (void**)&block_out));
+  block_out = nullptr;
+  if (!table_c) BP_TRY(ws_get(ctx, "msm.block_out", (size_t)Wr * blocks_per_window * sizeof(proj28_slot), (void**)&block_out));
   BP_TRY(ws_get(ctx, "msm.window_sum", (size_t)n_planes * sizeof(proj28_slot) + 16, (void**)&window_sum));     // + the status word
   // pinned staging: MSM_SLOTS result areas of the largest possible size, so earlier pending results stay where they are
   constexpr size_t slot_bytes = (size_t)MSM_MAX_WINDOWS * sizeof(proj28_slot) + 16;
@@ -257,20 +267,74 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   const size_t hist_bytes = (size_t)B * 4;
   const unsigned hist_threads = B >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
   const uint32_t n_tiles = (total + SCAN_TILE - 1) / SCAN_TILE;      // <= 4096 (total <= 2^24)
-  // Bucket sort.  c <= 16: the one-histogram counting sort (msm_count / msm_scatter).  Wider windows: the partitioned (radix)
-  // sort -- every store coalesced or L2-merged.  (At c = 16 the two cost the same, 0.34 vs 0.35 ms at 2^20: the radix sort
-  // moves 8-byte records three times.)  BP_MSM_SORT=1 forces the radix sort everywhere (tests, A/B).
-  const bool radix = plan.parts > 1 || plan.naf || env_u32("BP_MSM_SORT", 0) == 1;
-  if (radix) {
-    uint32_t kb = 0;
-    while ((1ull << kb) < total) kb++;
-    uint32_t pb = 0;
-    while (pb < kb && (max_entries >> (pb + 1)) >= 12288) pb++;             // final runs of ~12-24 Ki entries
-    pb = env_u32("BP_MSM_RADIX_BITS", pb);
-    if (pb + MSM_HIST_LOG < kb) pb = kb - MSM_HIST_LOG;                   // a final run's buckets must fit one LDS histogram
-    if (pb > kb) pb = kb;
-    if (pb > 16) pb = 16;
-    const uint32_t lv[2] = {pb <= 8 ? pb : pb - pb / 2, pb <= 8 ? 0 : pb / 2}, rbits = kb - pb, n_final = 1u << pb;
+  // Bucket sort, three builds: the partition sort (default wherever its 2^pb <= 2^11 partitions leave final runs
+  // that one workgroup sorts: up to ~5 * 10^7 entries), the two-level radix sort (beyond), the one-histogram counting sort of
+  // round 1 (c <= 16 only; kept selectable for A/B: BP_MSM_SORT=0 histogram, 1 two-level, 2 partition).
+  BP_HIP(ctx, hipMemsetAsync(ctl, 0, ctl_words * 4, st));
+  uint32_t kb = 0;
+  while ((1ull << kb) < total) kb++;
+  uint32_t pb = 0;
+  while (pb < kb && (max_entries >> (pb + 1)) >= 12288) pb++;             // final runs of ~12-24 Ki entries
+  pb = env_u32("BP_MSM_RADIX_BITS", pb, 0, 16);
+  if (pb + MSM_HIST_LOG < kb) pb = kb - MSM_HIST_LOG;                   // a final run's buckets must fit one LDS histogram
+  if (pb > kb) pb = kb;
+  if (pb > 16) pb = 16;
+  const uint32_t sort_env = env_u32("BP_MSM_SORT", 2, 0, 2);
+  const bool hist_ok = plan.parts == 1 && !plan.naf;
+  const int sort_mode = (sort_env == 0 && hist_ok) ? 0 : ((sort_env == 1 || pb > PART_MAX_BITS) ? 1 : 2);
+  const uint32_t rbits = kb - pb, n_final = 1u << pb;
+  const size_t rhist = ((size_t)1 << rbits) * 4;
+  uint32_t* rlong_n = ctl + 2;
+  if (sort_mode == 2) {
+    // record form: the packed word holds the bucket's low rbits bits, the sign and the entry (point or table index)
+    const uint64_t idx_max = (uint64_t)(n - 1) + (uint64_t)(plan.naf ? 255u : W - 1) * plan.wpoints;
+    uint32_t vb = 1;
+    while ((idx_max >> (vb - 1)) != 0) vb++;                            // vb - 1 = bits of the largest entry, + 1 for the sign
+    const bool packed = rbits + vb <= 32 && env_u32("BP_MSM_PACKED", 1, 0, 1) != 0;
+    const uint32_t rec_bytes = packed ? 4 : 8;
+    // scalars per workgroup: the staging area (slice * W records) within 64 KiB, and >= 512 workgroups where n allows
+    uint32_t slice = 64;
+    while (slice < 1024 && (uint64_t)2 * slice * W * rec_bytes <= 65536 && (uint64_t)slice * 512 < n) slice <<= 1;
+    slice = env_u32("BP_MSM_PART_SLICE", slice, 64, 4096);
+    if (slice < 64 || slice > 4096 || (uint64_t)slice * W * rec_bytes > 98304) slice = 64;
+    const uint32_t cap = slice * W, n_slices = (uint32_t)((n + slice - 1) / slice);
+    const unsigned threads = slice >= 1024 ? 1024u : (slice <= 256 ? 256u : slice);
+    uint32_t *recs = nullptr, *rvals = nullptr, *roff, *cur, *rlong_list;
+    BP_TRY(ws_get(ctx, "msm.rkeys0", max_entries * 4, (void**)&recs));
+    if (!packed) BP_TRY(ws_get(ctx, "msm.rvals0", max_entries * 4, (void**)&rvals));
+    BP_TRY(ws_get(ctx, "msm.run_off", ((size_t)3 * n_final + 16) * 4, (void**)&roff));
+    BP_TRY(ws_get(ctx, "msm.run_cur", (size_t)n_final * 4, (void**)&cur));
+    BP_TRY(ws_get(ctx, "msm.run_long", ((size_t)n_final + 2) * 4, (void**)&rlong_list));
+    hipLaunchKernelGGL(msm_part_count, dim3(n_slices), dim3(threads), 0, st, d_scalars, fmt, plan, slice, pb, rbits, ctl + 4, roff, cur, long_count + 1);
+    if (packed) {
+      hipLaunchKernelGGL(msm_part_scatter<true>, dim3(n_slices), dim3(threads), (size_t)cap * 4, st, d_scalars, fmt, plan, slice, pb, rbits, vb, cap, cur,
+                         recs, rvals);
+      const RunRecords<true> rr{recs, nullptr, (1u << rbits) - 1u, vb};
+      hipLaunchKernelGGL(msm_radix_final<true>, dim3(n_final < 4096 ? n_final : 4096), dim3(1024), rhist, st, rr, roff, n_final, rbits, total, offsets,
+                         sorted, rlong_n, rlong_list, counts);
+      if (n_final > 1) {
+        const dim3 lgrid(64, n_final < 4 ? n_final : 4);
+        hipLaunchKernelGGL(msm_radix_long_count<true>, lgrid, dim3(1024), rhist, st, rr, roff, rbits, rlong_n, rlong_list, counts);
+        hipLaunchKernelGGL(msm_radix_long_prefix, dim3(n_final < 16 ? n_final : 16), dim3(1024), 0, st, roff, n_final, rbits, total, rlong_n, rlong_list,
+                           counts, offsets, cursors);
+        hipLaunchKernelGGL(msm_radix_long_scatter<true>, lgrid, dim3(1024), rhist, st, rr, roff, rbits, rlong_n, rlong_list, cursors, sorted);
+      }
+    } else {
+      hipLaunchKernelGGL(msm_part_scatter<false>, dim3(n_slices), dim3(threads), (size_t)cap * 8, st, d_scalars, fmt, plan, slice, pb, rbits, vb, cap, cur,
+                         recs, rvals);
+      const RunRecords<false> rr{recs, rvals, (1u << rbits) - 1u, 0u};
+      hipLaunchKernelGGL(msm_radix_final<false>, dim3(n_final < 4096 ? n_final : 4096), dim3(1024), rhist, st, rr, roff, n_final, rbits, total, offsets,
+                         sorted, rlong_n, rlong_list, counts);
+      if (n_final > 1) {
+        const dim3 lgrid(64, n_final < 4 ? n_final : 4);
+        hipLaunchKernelGGL(msm_radix_long_count<false>, lgrid, dim3(1024), rhist, st, rr, roff, rbits, rlong_n, rlong_list, counts);
+        hipLaunchKernelGGL(msm_radix_long_prefix, dim3(n_final < 16 ? n_final : 16), dim3(1024), 0, st, roff, n_final, rbits, total, rlong_n, rlong_list,
+                           counts, offsets, cursors);
+        hipLaunchKernelGGL(msm_radix_long_scatter<false>, lgrid, dim3(1024), rhist, st, rr, roff, rbits, rlong_n, rlong_list, cursors, sorted);
+      }
+    }
+  } else if (sort_mode == 1) {
+    const uint32_t lv[2] = {pb <= 8 ? pb : pb - pb / 2, pb <= 8 ? 0 : pb / 2};
     uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *run_off[3], *cnt, *cur;
     BP_TRY(ws_get(ctx, "msm.rkeys0", max_entries * 4, (void**)&keys[0]));
     BP_TRY(ws_get(ctx, "msm.rvals0", max_entries * 4, (void**)&vals[0]));
@@ -287,10 +351,8 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
     BP_TRY(ws_get(ctx, "msm.run_cur", (size_t)n_final * 4, (void**)&cur));
     const uint32_t whole[2] = {0u, (uint32_t)max_entries};
     BP_HIP(ctx, hipMemcpyAsync(run_off[0], whole, sizeof whole, hipMemcpyHostToDevice, st));
-    uint32_t* rlong;                                     // [0] number of long final runs, [1..] their list
-    BP_TRY(ws_get(ctx, "msm.run_long", ((size_t)n_final + 2) * 4, (void**)&rlong));
-    BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4 + 8, st));     // bucket sizes of long runs + long-bucket counter + scalar status
-    BP_HIP(ctx, hipMemsetAsync(rlong, 0, 4, st));
+    uint32_t* rlong_list;
+    BP_TRY(ws_get(ctx, "msm.run_long", ((size_t)n_final + 2) * 4, (void**)&rlong_list));
     if (plan.naf)
       hipLaunchKernelGGL(msm_naf_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, keys[0], vals[0], long_count + 1);
     else
@@ -314,19 +376,19 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
       runs = n_sub;
     }
     const uint32_t level_count = (lv[0] ? 1 : 0) + (lv[1] ? 1 : 0);
-    const size_t rhist = ((size_t)1 << rbits) * 4;
-    hipLaunchKernelGGL(msm_radix_final, dim3(runs < 4096 ? runs : 4096), dim3(1024), rhist, st, keys[side], vals[side], run_off[level_count], runs,
-                       rbits, total, offsets, sorted, rlong, rlong + 1);
+    const RunRecords<false> rr{keys[side], vals[side], (1u << rbits) - 1u, 0u};
+    hipLaunchKernelGGL(msm_radix_final<false>, dim3(runs < 4096 ? runs : 4096), dim3(1024), rhist, st, rr, run_off[level_count], runs, rbits, total, offsets,
+                       sorted, rlong_n, rlong_list, counts);
     if (runs > 1) {                 // long runs (none for uniformly random scalars beyond the top window's): slice-parallel
       const dim3 lgrid(256, runs < 16 ? runs : 16);
-      hipLaunchKernelGGL(msm_radix_long_count, lgrid, dim3(1024), rhist, st, keys[side], run_off[level_count], rbits, rlong, rlong + 1, counts);
-      hipLaunchKernelGGL(msm_radix_long_prefix, dim3(runs < 64 ? runs : 64), dim3(1024), 0, st, run_off[level_count], runs, rbits, total, rlong,
-                         rlong + 1, counts, offsets, cursors);
-      hipLaunchKernelGGL(msm_radix_long_scatter, lgrid, dim3(1024), rhist, st, keys[side], vals[side], run_off[level_count], rbits, rlong, rlong + 1,
-                         cursors, sorted);
+      hipLaunchKernelGGL(msm_radix_long_count<false>, lgrid, dim3(1024), rhist, st, rr, run_off[level_count], rbits, rlong_n, rlong_list, counts);
+      hipLaunchKernelGGL(msm_radix_long_prefix, dim3(runs < 64 ? runs : 64), dim3(1024), 0, st, run_off[level_count], runs, rbits, total, rlong_n,
+                         rlong_list, counts, offsets, cursors);
+      hipLaunchKernelGGL(msm_radix_long_scatter<false>, lgrid, dim3(1024), rhist, st, rr, run_off[level_count], rbits, rlong_n, rlong_list, cursors, sorted);
     }
   } else {
-    BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4 + 8, st));
+    BP_TRY(ws_get(ctx, "msm.digits", max_entries * sizeof(int16_t), (void**)&digits));
+    BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4, st));
     hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits, long_count + 1);
     hipLaunchKernelGGL(msm_count, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, digits, plan, counts);
     hipLaunchKernelGGL(scan_tile_sums, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums);
@@ -336,49 +398,80 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   }
   BP_HIP(ctx, hipEventRecord(ctx->ev[1], st));
   const dim3 acc_grid((unsigned)((n_chunks + 255) / 256));
-  switch (env_u32("BP_MSM_ACC_WAVES", 2)) {
+  switch (env_u32("BP_MSM_ACC_WAVES", 2, 2, 4)) {
     case 3: hipLaunchKernelGGL(msm_accumulate<3>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial); break;
     case 4: hipLaunchKernelGGL(msm_accumulate<4>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial); break;
     default: hipLaunchKernelGGL(msm_accumulate<2>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial);
   }
   BP_HIP(ctx, hipEventRecord(ctx->ev[2], st));
-  if (table_c)      // 2^15 buckets of ~8 partials each: two lanes per bucket = one wave per SIMD, half the chain
+  // fix-up of the buckets cut by chunk edges.  Long buckets (tables at c <= 17: every one of the 2^15 buckets spans several chunks):
+  // two lanes per bucket = one wave per SIMD, half the chain.  Short buckets (wide windows, per-window bucket sets): most buckets
+  // sit inside one chunk -- one lane per chunk edge.  BP_MSM_FIXUP=1 / 2 forces the per-bucket / per-edge form.
+  const uint32_t fixup_env = env_u32("BP_MSM_FIXUP", 0, 0, 2);
+  const bool by_edges = fixup_env ? fixup_env == 2 : max_entries / total < 2ull * plan.chunk;
+  if (by_edges)
+    hipLaunchKernelGGL(msm_fixup_edges, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, offsets, plan, bucket_sum, partial, long_count,
+                       long_list, long_cap);
+  else if (table_c)
     hipLaunchKernelGGL(msm_fixup<2>, dim3((unsigned)(((uint64_t)total * 2 + 255) / 256)), dim3(256), 0, st, offsets, plan, bucket_sum, partial,
                        long_count, long_list, long_cap);
   else
     hipLaunchKernelGGL(msm_fixup<1>, dim3((total + 255) / 256), dim3(256), 0, st, offsets, plan, bucket_sum, partial, long_count, long_list,
                        long_cap);
-  hipLaunchKernelGGL(msm_fixup_long, dim3(512, FIXUP_LONG_SLICES), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
-                     long_count, long_list, long_cap, long_scratch);
-  hipLaunchKernelGGL(msm_fixup_long_merge, dim3(512), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, long_count, long_list,
-                     long_cap, long_scratch);
+  hipLaunchKernelGGL(msm_fixup_long, dim3(64, FIXUP_LONG_SLICES), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
+                     long_count, long_list, long_cap, long_scratch, long_ticket);
   if (table_c) {
-    if (planes_log == 7)
-      hipLaunchKernelGGL((msm_planes_block<128, 2>), dim3(blocks_per_window, Wr), dim3(128), 256 * sizeof(proj28_slot), st, offsets, plan,
-                         bucket_sum, l1, block_out);
-    else
-      hipLaunchKernelGGL((msm_planes_block<256, 1>), dim3(blocks_per_window, Wr), dim3(256), 512 * sizeof(proj28_slot), st, offsets, plan,
-                         bucket_sum, l1, block_out);
-    // merge steps of at most 7 levels each until one node (A and the c - 1 planes) is left; c <= 16 needs one
-    uint32_t k = l1, r = l2;
-    const proj28_slot* in = block_out;
+    // The tree over the B = 2^(c-1) buckets, level by level.  A level with at least PLANES_WIDE_MIN additions is throughput
+    // bound: one addition per lane through HBM (msm_planes_level; only windows wider than 17 bits have such levels).  The rest
+    // is latency bound: up to PLANES_STEP_LOG levels per launch inside workgroups, cooperative additions (msm_planes_step).
+    // A node of 2^k buckets carries k + 1 values; the two ping-pong buffers hold at most B values (level 1).
+    const uint32_t levels = plan.c - 1;               // >= 1 (make_plan keeps c >= 2)
+    const uint64_t wide_min = env_u32("BP_MSM_PLANES_WIDE_MIN", 40000, 256, 1u << 30);
+    uint32_t k = 0, nodes = B, n_wide = 0;
+    while (n_wide < levels && (uint64_t)(B >> (n_wide + 1)) * (n_wide + 1) >= wide_min) n_wide++;
     proj28_slot* tmp[2] = {nullptr, nullptr};
-    if (r > 7) {
-      BP_TRY(ws_get(ctx, "msm.planes_tmp0", ((size_t)1 << (r - 7)) * (k + 8) * sizeof(proj28_slot), (void**)&tmp[0]));
-      if (r > 14) BP_TRY(ws_get(ctx, "msm.planes_tmp1", ((size_t)1 << (r - 14)) * (k + 15) * sizeof(proj28_slot), (void**)&tmp[1]));
+    {
+      size_t need[2] = {0, 0};
+      uint32_t kk = 0, flip = 0;
+      while (kk < levels) {
+        const uint32_t m = kk < n_wide ? 1 : (levels - kk < PLANES_STEP_LOG ? levels - kk : PLANES_STEP_LOG);
+        kk += m;
+        if (kk < levels) {
+          const size_t slots = (size_t)(B >> kk) * (kk + 1);
+          if (slots > need[flip]) need[flip] = slots;
+        }
+        flip ^= 1;
+      }
+      if (need[0]) BP_TRY(ws_get(ctx, "msm.planes_tmp0", need[0] * sizeof(proj28_slot), (void**)&tmp[0]));
+      if (need[1]) BP_TRY(ws_get(ctx, "msm.planes_tmp1", need[1] * sizeof(proj28_slot), (void**)&tmp[1]));
     }
+    const proj28_slot* in = bucket_sum;
     int flip = 0;
-    do {
-      const uint32_t m = r < 7 ? r : 7, nodes = 1u << (r - m);
-      const bool last = r == m;
-      proj28_slot* out_nodes = last ? window_sum : tmp[flip];
-      hipLaunchKernelGGL(msm_planes_window, dim3(k + 1, nodes), dim3(512), 256 * sizeof(proj28_slot), st, in, k, m, out_nodes, long_count + 1,
-                         offsets + total, last ? reinterpret_cast<uint32_t*>(window_sum + n_planes) : (uint32_t*)nullptr);
-      in = out_nodes;
+    while (k < levels) {
+      const bool leaf = k == 0;
+      if (k < n_wide) {
+        nodes >>= 1;
+        const uint64_t items = (uint64_t)nodes * (k + 1);
+        const dim3 grid((unsigned)((items + 255) / 256));
+        if (leaf) hipLaunchKernelGGL(msm_planes_level<true>, grid, dim3(256), 0, st, offsets, in, k, nodes, tmp[flip]);
+        else hipLaunchKernelGGL(msm_planes_level<false>, grid, dim3(256), 0, st, offsets, in, k, nodes, tmp[flip]);
+        in = tmp[flip];
+        k += 1;
+      } else {
+        const uint32_t m = levels - k < PLANES_STEP_LOG ? levels - k : PLANES_STEP_LOG;
+        nodes >>= m;
+        const bool last = k + m == levels;
+        proj28_slot* out_nodes = last ? window_sum : tmp[flip];
+        uint32_t* status_out = last ? reinterpret_cast<uint32_t*>(window_sum + n_planes) : (uint32_t*)nullptr;
+        const dim3 grid(nodes, k + 1);
+        const size_t lds = ((size_t)2 << m) * sizeof(proj28_slot);
+        if (leaf) hipLaunchKernelGGL(msm_planes_step<true>, grid, dim3(256), lds, st, offsets, in, k, m, out_nodes, long_count + 1, offsets + total, status_out);
+        else hipLaunchKernelGGL(msm_planes_step<false>, grid, dim3(256), lds, st, offsets, in, k, m, out_nodes, long_count + 1, offsets + total, status_out);
+        in = out_nodes;
+        k += m;
+      }
       flip ^= 1;
-      k += m;
-      r -= m;
-    } while (r > 0);
+    }
   } else {
     hipLaunchKernelGGL(msm_reduce, dim3(blocks_per_window, Wr), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
                        block_out);
@@ -452,6 +545,12 @@ int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out) {
     MsmBlobHeader h;
     memcpy(&h, blobs + i * BP_MSM_BLOB_BYTES, sizeof h);
     if (h.magic != MSM_BLOB_MAGIC || h.n_planes > (uint32_t)MSM_MAX_WINDOWS) return BP_ERR_INVALID_ARG;
+    // the Horner passes below index the slots by (Wr, c): a record whose header does not describe its own slot count (another
+    // library version on a peer rank, a truncated gather) is rejected here instead of being read past its end
+    if (h.n_planes != 0) {
+      const bool width_ok = h.tables == 2 ? (h.c >= 5 && h.c <= 21) : (h.tables <= 1 && h.c >= 2 && h.c <= (uint32_t)MSM_MAX_TABLE_C);
+      if (!width_ok || h.Wr < 1 || h.n_planes != (h.tables ? h.Wr * h.c : h.Wr)) return BP_ERR_INVALID_ARG;
+    }
     if (h.status) return BP_ERR_BAD_SCALAR;
   }
   for (size_t i = 0; i < n_blobs; i++) {

@@ -422,31 +422,52 @@ __global__ void __launch_bounds__(1024) msm_radix_scatter(const uint32_t* __rest
   }
 }
 
+// Records of the final runs come in two forms.  Two arrays (keys = bucket id, vals = entry | sign << 31): the two-level sort above
+// and every case the packed form cannot hold.  PACKED: one word per record, (bucket's low rbits bits) << vb | sign << (vb - 1) | entry
+// -- the high bits of the bucket id are the run's number, so they need not travel (msm_part_scatter; half the bytes).
+template <bool PACKED>
+struct RunRecords {
+  const uint32_t* __restrict__ keys;     // PACKED: the records
+  const uint32_t* __restrict__ vals;     // PACKED: unused
+  uint32_t mask, vb;                     // mask = 2^rbits - 1
+  __device__ __forceinline__ uint32_t load(uint32_t j) const { return keys[j]; }
+  __device__ __forceinline__ uint32_t low(uint32_t rec) const { return PACKED ? rec >> vb : rec & mask; }     // bucket inside the run
+  __device__ __forceinline__ uint32_t val(uint32_t j, uint32_t rec) const {
+    if (!PACKED) return vals[j];
+    return (rec & ((1u << (vb - 1)) - 1u)) | (((rec >> (vb - 1)) & 1u) << 31);
+  }
+};
+
 // One workgroup per final run (grid-stride).  The run's keys share their high bits; its 2^rbits buckets are
 // [run << rbits, (run + 1) << rbits).  Writes offsets[bucket] for those (only below `total`) and the run's entries in bucket
 // order; the scattered 4-byte stores stay inside the run's own ~48 KiB of `sorted`, which L2 merges into whole lines.
-// keys may still hold RADIX_EMPTY records when no partition level ran (single run): they are skipped.
+// keys may still hold RADIX_EMPTY records when no partition level ran (single run, two-array form): they are skipped.
 // Runs longer than RADIX_LONG_RUN records (skewed scalars; the narrow top window, whose few buckets collect n entries) are
-// not sorted by one workgroup: they are queued in long_list and handled slice-parallel by the msm_radix_long_* kernels.
+// not sorted by one workgroup: they are queued in long_list and handled slice-parallel by the msm_radix_long_* kernels
+// (zero_counts != null: the queueing workgroup clears the run's bucket counters for them).
 constexpr uint32_t RADIX_LONG_RUN = 1u << 16;
-__global__ void __launch_bounds__(1024) msm_radix_final(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                        const uint32_t* __restrict__ run_off, uint32_t n_runs, uint32_t rbits, uint32_t total,
-                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted,
-                                                        uint32_t* __restrict__ long_n, uint32_t* __restrict__ long_list) {
+template <bool PACKED>
+__global__ void __launch_bounds__(1024) msm_radix_final(RunRecords<PACKED> recs, const uint32_t* __restrict__ run_off, uint32_t n_runs, uint32_t rbits,
+                                                        uint32_t total, uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted,
+                                                        uint32_t* __restrict__ long_n, uint32_t* __restrict__ long_list,
+                                                        uint32_t* __restrict__ zero_counts) {
   __shared__ uint32_t scan16[16];
   __shared__ uint32_t carry;
-  const uint32_t nb = 1u << rbits, mask = nb - 1;
+  const uint32_t nb = 1u << rbits;
   for (uint32_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
     const uint32_t lo = run_off[run], hi = run_off[run + 1];
     if (hi - lo > RADIX_LONG_RUN && n_runs > 1) {          // uniform over the workgroup
       if (threadIdx.x == 0) long_list[atomicAdd(long_n, 1u)] = run;
+      if (zero_counts)
+        for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x)
+          if ((((uint64_t)run << rbits) + b) < total) zero_counts[((size_t)run << rbits) + b] = 0;
       continue;
     }
     for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) msm_lds_hist[b] = 0;
     __syncthreads();
     for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
-      const uint32_t key = keys[j];
-      if (key != RADIX_EMPTY) atomicAdd(&msm_lds_hist[key & mask], 1u);
+      const uint32_t key = recs.load(j);
+      if (PACKED || key != RADIX_EMPTY) atomicAdd(&msm_lds_hist[recs.low(key)], 1u);
     }
     __syncthreads();
     // exclusive prefix over the nb bucket sizes, 1024 at a time; the prefix replaces the size in LDS (it becomes the cursor).
@@ -467,8 +488,8 @@ __global__ void __launch_bounds__(1024) msm_radix_final(const uint32_t* __restri
     }
     if (run == n_runs - 1 && threadIdx.x == 0) offsets[total] = lo + carry;
     for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
-      const uint32_t key = keys[j];
-      if (key != RADIX_EMPTY) sorted[lo + atomicAdd(&msm_lds_hist[key & mask], 1u)] = vals[j];
+      const uint32_t key = recs.load(j);
+      if (PACKED || key != RADIX_EMPTY) sorted[lo + atomicAdd(&msm_lds_hist[recs.low(key)], 1u)] = recs.val(j, key);
     }
     __syncthreads();
   }
@@ -476,17 +497,18 @@ __global__ void __launch_bounds__(1024) msm_radix_final(const uint32_t* __restri
 
 // long runs, slice-parallel: count -> prefix (offsets and cursors of the run's buckets) -> scatter.  grid (slices, lanes of the
 // list); workgroup (x, y) takes slices x, x + gridDim.x, ... of the long runs y, y + gridDim.y, ...
-__global__ void __launch_bounds__(1024) msm_radix_long_count(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ run_off, uint32_t rbits,
+template <bool PACKED>
+__global__ void __launch_bounds__(1024) msm_radix_long_count(RunRecords<PACKED> recs, const uint32_t* __restrict__ run_off, uint32_t rbits,
                                                              const uint32_t* __restrict__ long_n, const uint32_t* __restrict__ long_list,
                                                              uint32_t* __restrict__ counts) {
-  const uint32_t nb = 1u << rbits, mask = nb - 1, n_long = *long_n;
+  const uint32_t nb = 1u << rbits, n_long = *long_n;
   for (uint32_t k = blockIdx.y; k < n_long; k += gridDim.y) {
     const uint32_t run = long_list[k], lo = run_off[run], hi = run_off[run + 1];
     for (uint64_t base = lo + (uint64_t)blockIdx.x * RADIX_SLICE; base < hi; base += (uint64_t)gridDim.x * RADIX_SLICE) {
       for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) msm_lds_hist[b] = 0;
       __syncthreads();
       const uint32_t end = base + RADIX_SLICE < hi ? (uint32_t)base + RADIX_SLICE : hi;
-      for (uint32_t j = (uint32_t)base + threadIdx.x; j < end; j += blockDim.x) atomicAdd(&msm_lds_hist[keys[j] & mask], 1u);
+      for (uint32_t j = (uint32_t)base + threadIdx.x; j < end; j += blockDim.x) atomicAdd(&msm_lds_hist[recs.low(recs.load(j))], 1u);
       __syncthreads();
       for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
         const uint32_t v = msm_lds_hist[b];
@@ -525,26 +547,205 @@ __global__ void __launch_bounds__(1024) msm_radix_long_prefix(const uint32_t* __
     __syncthreads();
   }
 }
-__global__ void __launch_bounds__(1024) msm_radix_long_scatter(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                               const uint32_t* __restrict__ run_off, uint32_t rbits,
+template <bool PACKED>
+__global__ void __launch_bounds__(1024) msm_radix_long_scatter(RunRecords<PACKED> recs, const uint32_t* __restrict__ run_off, uint32_t rbits,
                                                                const uint32_t* __restrict__ long_n, const uint32_t* __restrict__ long_list,
                                                                uint32_t* __restrict__ cursors, uint32_t* __restrict__ sorted) {
-  const uint32_t nb = 1u << rbits, mask = nb - 1, n_long = *long_n;
+  const uint32_t nb = 1u << rbits, n_long = *long_n;
   for (uint32_t k = blockIdx.y; k < n_long; k += gridDim.y) {
     const uint32_t run = long_list[k], lo = run_off[run], hi = run_off[run + 1];
     for (uint64_t base = lo + (uint64_t)blockIdx.x * RADIX_SLICE; base < hi; base += (uint64_t)gridDim.x * RADIX_SLICE) {
       for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) msm_lds_hist[b] = 0;
       __syncthreads();
       const uint32_t end = base + RADIX_SLICE < hi ? (uint32_t)base + RADIX_SLICE : hi;
-      for (uint32_t j = (uint32_t)base + threadIdx.x; j < end; j += blockDim.x) atomicAdd(&msm_lds_hist[keys[j] & mask], 1u);
+      for (uint32_t j = (uint32_t)base + threadIdx.x; j < end; j += blockDim.x) atomicAdd(&msm_lds_hist[recs.low(recs.load(j))], 1u);
       __syncthreads();
       for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
         const uint32_t v = msm_lds_hist[b];
         if (v) msm_lds_hist[b] = atomicAdd(&cursors[((size_t)run << rbits) + b], v);
       }
       __syncthreads();
-      for (uint32_t j = (uint32_t)base + threadIdx.x; j < end; j += blockDim.x) sorted[atomicAdd(&msm_lds_hist[keys[j] & mask], 1u)] = vals[j];
+      for (uint32_t j = (uint32_t)base + threadIdx.x; j < end; j += blockDim.x) {
+        const uint32_t rec = recs.load(j);
+        sorted[atomicAdd(&msm_lds_hist[recs.low(rec)], 1u)] = recs.val(j, rec);
+      }
       __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------- 4d. partition sort (one level, digits recomputed, no digit or record pass)
+// The default bucket sort.  The histogram sort of section 4 pays one global atomic per (workgroup, bucket) it touches -- ~10^7 of
+// them at 2^20 points, twice -- and isolated 4-byte stores; the two-level sort of 4c moves 8-byte records three times.  Here:
+//   msm_part_count     a workgroup per slice of scalars: Montgomery -> canonical -> digits in registers, LDS histogram of the
+//                      entries' PARTITIONS (the high pb bits of the bucket id, <= 2^11), one global atomic per (workgroup,
+//                      partition); the workgroup that finishes last (a ticket) scans the 2^pb sizes = the final runs' offsets
+//   msm_part_scatter   the same slices, digits recomputed (32 B of scalar re-read instead of 128 B of records written and read):
+//                      rank in LDS, reserve the slice's range in every partition, stage sorted by partition, write each
+//                      partition's share lane-adjacent
+//   msm_radix_final    one workgroup per final run, as in 4c (packed records where they fit: RunRecords)
+// No digit array, no record arrays before the final runs, no scan launches.
+constexpr uint32_t PART_MAX_BITS = 11, PART_MAX = 1u << PART_MAX_BITS;
+
+// every (bucket id, entry | sign << 31) of scalar i, in window (or NAF slot) order.  status != null: canonical-bytes inputs are
+// range-checked (Scalar::from_bytes rejects values >= q, scalar.rs:264-288)
+template <class F>
+__device__ __forceinline__ void msm_scalar_entries(const fr_t* __restrict__ scalars, uint32_t i, int fmt, const MsmPlan& plan,
+                                                   uint32_t* __restrict__ status, F&& emit) {
+  fr_t k = scalars[i];
+  if (fmt == 1) {
+    Fr::from_mont(k, k);                           // msm.rs:126: scalar.to_bytes() = canonical integer
+  } else if (status) {
+    fr_t t;
+    if (!big_sub(t, k, Fr::modulus())) atomicOr(status, 1u);
+  }
+  if (plan.naf) {                                  // as msm_naf_records
+    uint32_t kw[10];
+#pragma unroll
+    for (int j = 0; j < 8; j++) kw[j] = k.l[j];
+    kw[8] = 0;
+    kw[9] = 0;
+    const uint32_t w = plan.naf, mask = (1u << w) - 1u, half = 1u << (w - 1);
+    uint32_t pos = 0, carry = 0, slot = 0;
+    while (pos < 256 && slot < plan.W) {
+      const uint32_t flip = carry ? 0xffffffffu : 0u;
+      uint32_t word = pos >> 5, x = ((kw[word] ^ flip) >> (pos & 31));
+      uint32_t p = pos;
+      if (x) {
+        p += __ffs(x) - 1;
+      } else {
+        p = (word + 1) << 5;
+        for (word++; word < 8 && (kw[word] ^ flip) == 0; word++) p += 32;
+        if (word >= 8) {
+          if (!carry) break;
+          p = 256;
+        } else {
+          p += __ffs(kw[word] ^ flip) - 1;
+        }
+      }
+      if (p >= 256) break;
+      const uint32_t wd = p >> 5, sh = p & 31;
+      const uint64_t two = (uint64_t)kw[wd] | ((uint64_t)kw[wd + 1] << 32);
+      const uint32_t e = ((uint32_t)(two >> sh) & mask) + carry;
+      const bool neg = e >= half;
+      const uint32_t mag = neg ? (1u << w) - e : e;
+      carry = neg ? 1u : 0u;
+      emit((mag - 1) >> 1, (i + p * plan.wpoints) | (neg ? 0x80000000u : 0u));
+      slot++;
+      pos = p + w;
+    }
+    return;
+  }
+  uint32_t kp[10];
+  uint64_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    carry += (uint64_t)(j < 8 ? k.l[j] : 0u) + plan.bias[j];
+    kp[j] = (uint32_t)carry;
+    carry >>= 32;
+  }
+  kp[9] = 0;
+  const uint32_t c = plan.c, mask = (1u << c) - 1u, half = 1u << (c - 1);
+  for (uint32_t w = 0; w < plan.W; w++) {
+    const uint32_t o = c * w, word = o >> 5, sh = o & 31;
+    const uint64_t two = (uint64_t)kp[word] | ((uint64_t)kp[word + 1] << 32);
+    const int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (w + 1 < plan.W ? (int32_t)half : 0);
+    if (d != 0) emit(w * plan.wbuckets + digit_bucket(d), (i + w * plan.wpoints) | (d < 0 ? 0x80000000u : 0u));
+  }
+}
+
+// ctl: [0] ticket of finished workgroups, [1 .. 2^pb] partition sizes (zero before the launch).  slice: scalars per workgroup.
+// run_off[0 .. 2^pb] and cursor[0 .. 2^pb) are written by the workgroup that takes the last ticket.
+__global__ void __launch_bounds__(1024) msm_part_count(const fr_t* __restrict__ scalars, int fmt, MsmPlan plan, uint32_t slice, uint32_t pb,
+                                                       uint32_t rbits, uint32_t* __restrict__ ctl, uint32_t* __restrict__ run_off,
+                                                       uint32_t* __restrict__ cursor, uint32_t* __restrict__ status) {
+  __shared__ uint32_t h[PART_MAX], scan16[16], carry_s, last_s;
+  const uint32_t P = 1u << pb;
+  uint32_t* cnt = ctl + 1;
+  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) h[p] = 0;
+  __syncthreads();
+  const uint64_t lo64 = (uint64_t)blockIdx.x * slice;
+  const uint32_t lo = (uint32_t)lo64, hi = lo64 + slice < plan.n ? lo + slice : plan.n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
+    msm_scalar_entries(scalars, i, fmt, plan, status, [&](uint32_t bucket, uint32_t) { atomicAdd(&h[bucket >> rbits], 1u); });
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x)
+    if (h[p]) atomicAdd(&cnt[p], h[p]);
+  // Every wave's additions have been performed (vmcnt = 0) before the workgroup takes its ticket.  The sizes are only ever
+  // touched by device-scope atomics -- here and, below, read by one (an addition of zero) -- so they need no cache maintenance:
+  // a release fence per lane (buffer_wbl2) cost this kernel 270 of its 300 us.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    last_s = atomicAdd(&ctl[0], 1u) == gridDim.x - 1 ? 1u : 0u;
+    carry_s = 0;
+  }
+  __syncthreads();
+  if (!last_s) return;
+  for (uint32_t p0 = 0; p0 < P; p0 += blockDim.x) {
+    const uint32_t p = p0 + threadIdx.x;
+    const uint32_t v = p < P ? atomicAdd(&cnt[p], 0u) : 0u;
+    const uint32_t ex = block_exclusive_scan_1024(v, scan16) + carry_s;
+    if (p < P) {
+      run_off[p] = ex;
+      cursor[p] = ex;
+    }
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry_s = ex + v;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) run_off[P] = carry_s;
+}
+
+extern __shared__ uint32_t msm_part_lds[];        // PACKED: records[cap]; else keys[cap] | vals[cap]   (cap = slice * W)
+template <bool PACKED>
+__global__ void __launch_bounds__(1024) msm_part_scatter(const fr_t* __restrict__ scalars, int fmt, MsmPlan plan, uint32_t slice, uint32_t pb,
+                                                         uint32_t rbits, uint32_t vb, uint32_t cap, uint32_t* __restrict__ cursor,
+                                                         uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+  __shared__ uint32_t h[PART_MAX], lbase[PART_MAX], gbase[PART_MAX], scan16[16], carry_s;
+  uint32_t* st_key = msm_part_lds;
+  uint32_t* st_val = st_key + cap;
+  const uint32_t P = 1u << pb, rmask = (1u << rbits) - 1u;
+  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) h[p] = 0;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const uint64_t lo64 = (uint64_t)blockIdx.x * slice;
+  const uint32_t lo = (uint32_t)lo64, hi = lo64 + slice < plan.n ? lo + slice : plan.n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
+    msm_scalar_entries(scalars, i, fmt, plan, nullptr, [&](uint32_t bucket, uint32_t) { atomicAdd(&h[bucket >> rbits], 1u); });
+  __syncthreads();
+  // this slice's share of every partition: place in the staging area (lbase) and in the partition's final run (gbase)
+  for (uint32_t p0 = 0; p0 < P; p0 += blockDim.x) {
+    const uint32_t p = p0 + threadIdx.x;
+    const uint32_t v = p < P ? h[p] : 0u;
+    const uint32_t ex = block_exclusive_scan_1024(v, scan16) + carry_s;
+    if (p < P) {
+      lbase[p] = ex;
+      gbase[p] = v ? atomicAdd(&cursor[p], v) : 0u;
+      h[p] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry_s = ex + v;
+    __syncthreads();
+  }
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
+    msm_scalar_entries(scalars, i, fmt, plan, nullptr, [&](uint32_t bucket, uint32_t val) {
+      const uint32_t part = bucket >> rbits, pos = lbase[part] + atomicAdd(&h[part], 1u);
+      if (PACKED) {
+        st_key[pos] = ((bucket & rmask) << vb) | ((val >> 31) << (vb - 1)) | (val & 0x7fffffffu);
+      } else {
+        st_key[pos] = bucket;
+        st_val[pos] = val;
+      }
+    });
+  __syncthreads();
+  // partition-major write-out: 16 lanes per partition, four partitions per wave at a time
+  const uint32_t sub = threadIdx.x >> 4, l16 = threadIdx.x & 15, n_sub = blockDim.x >> 4;
+  for (uint32_t p = sub; p < P; p += n_sub) {
+    const uint32_t cnt = h[p], src = lbase[p], dst = gbase[p];
+    for (uint32_t e = l16; e < cnt; e += 16) {
+      keys_out[dst + e] = st_key[src + e];
+      if (!PACKED) vals_out[dst + e] = st_val[src + e];
     }
   }
 }
@@ -863,19 +1064,57 @@ msm_fixup(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __res
   if (sub == 0) store_proj28(&bucket_sum[g], acc);
 }
 
+// The same fix-up, one lane per CHUNK EDGE instead of per bucket, for short buckets (wide windows: 2^19 buckets of ~26 entries
+// under chunks of ~100): there most buckets sit inside one chunk and a lane per bucket leaves three lanes in four idle while
+// their wave issues whole additions (238 us at c = 20, 2^20 points).  Lane t looks at the edge between chunks t - 1 and t
+// (position t * chunk), finds the bucket that holds it by bisection and fixes that bucket up if this edge is the first one
+// strictly inside it -- every straddling bucket has exactly one such edge.
+__global__ void __launch_bounds__(256, 2)
+msm_fixup_edges(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
+                const proj28_slot* __restrict__ partial, uint32_t* __restrict__ long_count, uint32_t* __restrict__ long_list,
+                uint32_t long_cap) {
+  const uint32_t total = plan.total, M = offsets[total];
+  const uint32_t chunk = msm_lane_chunk(plan, M);
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x + 1;
+  const uint64_t p64 = (uint64_t)t * chunk;
+  if (p64 >= M) return;
+  const uint32_t p = (uint32_t)p64;
+  const uint32_t g = bucket_of(offsets, total, p);
+  const uint32_t a = offsets[g], b = offsets[g + 1];
+  if (a == p || a / chunk != t - 1) return;         // the bucket starts at this edge, or an earlier edge already lies inside it
+  const uint32_t t_lo = t - 1, t_hi = (b - 1) / chunk;
+  if (t_hi - t_lo >= FIXUP_LONG) {
+    const uint32_t k = atomicAdd(long_count, 1u);
+    if (k < long_cap) {
+      long_list[k] = g;
+      return;
+    }
+  }
+  g1_proj28 acc = load_proj28(&partial[2 * (size_t)t_lo + partial_slot(a, t_lo, chunk)]);
+  for (uint32_t tt = t_lo + 1; tt <= t_hi; tt++) {
+    g1_proj28 q = load_proj28(&partial[2 * (size_t)tt + partial_slot(a, tt, chunk)]);
+    g1_add28(acc, acc, q);
+  }
+  store_proj28(&bucket_sum[g], acc);
+}
+
 extern __shared__ uint4 msm_lds_tree[];
 __device__ __forceinline__ g1_proj28 block_tree_sum28(g1_proj28 v, uint32_t live);
 
 // Queued (long) buckets.  A bucket of up to FIXUP_LONG_SPLIT_FROM partials is summed by one workgroup; a longer one -- a bucket that
 // holds a large share of a skewed input (scalars 0 / 1: one bucket of n / 2 entries = 16 Ki partials at 2^20) -- by FIXUP_LONG_SLICES
-// workgroups, one slice of its partials each (grid.y), into `scratch`, and msm_fixup_long_merge adds the slice sums.
-// grid (x, FIXUP_LONG_SLICES): workgroup (x, y) takes slice y of the queued buckets x, x + gridDim.x, ...
+// workgroups, one slice of its partials each (grid.y), into `scratch`; the workgroup whose slice is finished last (a ticket per
+// queued bucket, zero before the launch and zero again after it) adds the slice sums.
+// grid (x, FIXUP_LONG_SLICES): workgroup (x, y) takes slice y of the queued buckets x, x + gridDim.x, ...  An empty queue (the
+// normal case: uniformly random scalars on a table) costs one launch of workgroups that read one word and leave.
 constexpr uint32_t FIXUP_LONG_SLICES = 8, FIXUP_LONG_SPLIT_FROM = 2048;
 __global__ void __launch_bounds__(256, 2)
 msm_fixup_long(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
                const proj28_slot* __restrict__ partial, const uint32_t* __restrict__ long_count,
-               const uint32_t* __restrict__ long_list, uint32_t long_cap, proj28_slot* __restrict__ scratch) {
+               const uint32_t* __restrict__ long_list, uint32_t long_cap, proj28_slot* __restrict__ scratch, uint32_t* __restrict__ ticket) {
+  __shared__ uint32_t arrived;
   const uint32_t n_long = *long_count < long_cap ? *long_count : long_cap;
+  if (n_long == 0) return;
   const uint32_t chunk = msm_lane_chunk(plan, offsets[plan.total]);
   for (uint32_t k = blockIdx.x; k < n_long; k += gridDim.x) {
     const uint32_t g = long_list[k];
@@ -891,26 +1130,32 @@ msm_fixup_long(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* 
       g1_add28(acc, acc, q);
     }
     g1_proj28 tot = block_tree_sum28(acc, blockDim.x);
-    if (threadIdx.x == 0) store_proj28(split ? &scratch[(size_t)k * FIXUP_LONG_SLICES + blockIdx.y] : &bucket_sum[g], tot);
+    if (!split) {
+      if (threadIdx.x == 0) store_proj28(&bucket_sum[g], tot);
+      __syncthreads();
+      continue;
+    }
+    // publish this slice's sum, take a ticket; the last of the FIXUP_LONG_SLICES workgroups of bucket k merges.  One lane stores,
+    // releases at agent scope and signals; the merging workgroup acquires before it reads the other slices (MI355X guide, G16)
+    if (threadIdx.x == 0) {
+      store_proj28(&scratch[(size_t)k * FIXUP_LONG_SLICES + blockIdx.y], tot);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t t = atomicAdd(&ticket[k], 1u);
+      if (t == FIXUP_LONG_SLICES - 1) {
+        ticket[k] = 0;                                           // as found, for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      arrived = t;
+    }
     __syncthreads();
-  }
-}
-// one workgroup of FIXUP_LONG_SLICES lanes' worth per split bucket: the slice sums -> the bucket sum
-__global__ void __launch_bounds__(256, 2)
-msm_fixup_long_merge(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
-                     const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_list, uint32_t long_cap,
-                     const proj28_slot* __restrict__ scratch) {
-  const uint32_t n_long = *long_count < long_cap ? *long_count : long_cap;
-  const uint32_t chunk = msm_lane_chunk(plan, offsets[plan.total]);
-  for (uint32_t k = blockIdx.x; k < n_long; k += gridDim.x) {
-    const uint32_t g = long_list[k];
-    const uint32_t a = offsets[g], b = offsets[g + 1];
-    const uint32_t P = (b - 1) / chunk - a / chunk + 1;
-    if (P <= FIXUP_LONG_SPLIT_FROM) continue;                      // uniform
-    g1_proj28 v = g1_identity28();
-    if (threadIdx.x < FIXUP_LONG_SLICES) v = load_proj28(&scratch[(size_t)k * FIXUP_LONG_SLICES + threadIdx.x]);
-    g1_proj28 tot = block_tree_sum28(v, FIXUP_LONG_SLICES);
-    if (threadIdx.x == 0) store_proj28(&bucket_sum[g], tot);
+    if (arrived == FIXUP_LONG_SLICES - 1) {                        // uniform over the workgroup
+      g1_proj28 v = g1_identity28();
+      if (threadIdx.x < FIXUP_LONG_SLICES) v = load_proj28(&scratch[(size_t)k * FIXUP_LONG_SLICES + threadIdx.x]);
+      g1_proj28 sum = block_tree_sum28(v, FIXUP_LONG_SLICES);
+      if (threadIdx.x == 0) store_proj28(&bucket_sum[g], sum);
+    }
     __syncthreads();
   }
 }
@@ -988,86 +1233,97 @@ __global__ void __launch_bounds__(256, 2) msm_window_finish(const proj28_slot* _
 // of only log2(B) additions (the running-sum method needs a chain of ~50 additions/doublings per lane, and at one
 // wave per SIMD that chain, not the work, was the cost).  A node covering 2^k buckets carries (A, T_0 .. T_{k-1});
 // merging the siblings (l, r):   A = A_l + A_r,   T_j = T_j,l + T_j,r  (j < k),   T_k = A_r.
-// msm_planes_block runs the first <= 8 levels per 256-bucket block in LDS, msm_planes_window the rest per window;
-// the c values (A, T_0 .. T_{c-2}) of each window go to the host, whose Horner pass over bit positions replaces
+// Levels with at least a wave round of additions (wide windows only) go through HBM one addition per lane (msm_planes_level);
+// the rest run up to six levels per launch inside workgroups with cooperative additions (msm_planes_step);
+// the c values (A, T_0 .. T_{c-2}) go to the host, whose Horner pass over bit positions replaces
 // the scaling by 2^j (msm.rs:107-115 does the same doublings per window).
-//
-// LDS: two ping-pong arrays of 256 slots (a level never holds more: 2^(8-k) nodes x (k + 1) values <= 256).
-constexpr uint32_t PLANES_BLOCK_LOG = 8;
 
 // cur: 2^levels leaves (one slot each).  Returns the buffer holding the root: A at [0], T_j at [1 + j].
 // planes == false: plain tree sum, only slot [0] of the result is meaningful.
-// COOP_TREE: every addition is shared by a group of COOP lanes (g1_add28_coop: ~1 600 instructions deep instead of ~6 600),
-// for trees with fewer pending additions than lanes / COOP -- the merge steps over a few hundred nodes (msm_planes_window:
-// 512 lanes = 64 groups, 7 levels in ~9 rounds of ~3 us instead of 7 x 12 us).  The wide block stage keeps one addition per
-// lane (cooperative additions there measured 156 us against 131: the wide levels pay twice the work).
-// MODE 0: one addition per lane on every level; 1: cooperative on every level; 2: cooperative on the levels that have at most
-// two rounds of it to do (the narrow upper levels of a block), one addition per lane below.
-template <int MODE>
+// Every addition is shared by a group of COOP lanes (g1_add28_coop: ~1 600 instructions deep instead of ~6 600); the additions of
+// a level come first in the item order, the moves T_k = A_r are done by single lanes afterwards, so a level whose additions fit
+// the workgroup's groups costs exactly one addition.
 __device__ __forceinline__ proj28_slot* planes_tree(proj28_slot* cur, proj28_slot* nxt, uint32_t levels, bool planes) {
+  const uint32_t group = threadIdx.x / COOP, n_groups = blockDim.x / COOP;
+  const bool lead = (threadIdx.x & (COOP - 1)) == 0;
   for (uint32_t k = 0; k < levels; k++) {
     const uint32_t merges = 1u << (levels - k - 1);
-    const uint32_t in_per = planes ? k + 1 : 1, out_per = planes ? k + 2 : 1, items = merges * out_per;
-    const bool coop = MODE == 1 || (MODE == 2 && items * COOP <= 2 * blockDim.x);      // uniform over the workgroup
-    const uint32_t first = coop ? threadIdx.x / COOP : threadIdx.x, step = coop ? blockDim.x / COOP : blockDim.x;
-    const bool writer = !coop || (threadIdx.x & (COOP - 1)) == 0;
-    for (uint32_t item = first; item < items; item += step) {
-      const uint32_t m = item / out_per, v = item - m * out_per;
+    const uint32_t in_per = planes ? k + 1 : 1, out_per = planes ? k + 2 : 1, adds = merges * in_per;
+    for (uint32_t item = group; item < adds; item += n_groups) {               // uniform over a cooperative group
+      const uint32_t m = item / in_per, v = item - m * in_per;
       const proj28_slot* L = cur + (size_t)(2 * m) * in_per;
-      const proj28_slot* R = L + in_per;
-      if (v == k + 1) {
-        if (writer) nxt[(size_t)m * out_per + v] = R[0];       // T_k = A_r
-      } else {
-        g1_proj28 a = load_proj28(&L[v]), b = load_proj28(&R[v]);
-        if (MODE != 0 && coop) a = g1_add28_coop(a, b); else g1_add28(a, a, b);
-        if (writer) store_proj28(&nxt[(size_t)m * out_per + v], a);
-      }
+      g1_proj28 a = load_proj28(&L[v]), b = load_proj28(&L[in_per + v]);
+      a = g1_add28_coop(a, b);
+      if (lead) store_proj28(&nxt[(size_t)m * out_per + v], a);
     }
+    if (planes)
+      for (uint32_t m = threadIdx.x; m < merges; m += blockDim.x) nxt[(size_t)m * out_per + k + 1] = cur[(size_t)(2 * m + 1) * in_per];   // T_k = A_r
     __syncthreads();
     proj28_slot* t = cur; cur = nxt; nxt = t;
   }
   return cur;
 }
 
-// grid (B >> l1, windows), 2^l1 lanes used, LDS = two arrays of 2^l1 slots.  out[(w * gridDim.x + block) * (l1 + 1) + v]
-// Two builds: 256 lanes / 2^8 buckets / one wave per SIMD (c <= 16: few blocks, the dependent chain is what counts), and
-// 128 lanes / 2^7 buckets / two waves per SIMD (wide windows: thousands of blocks, three to four of them share a CU).
-template <int THREADS, int WAVES>
-__global__ void __launch_bounds__(THREADS, WAVES)
-msm_planes_block(const uint32_t* __restrict__ offsets, MsmPlan plan, const proj28_slot* __restrict__ bucket_sum, uint32_t l1,
+// One level of the tree through HBM, one addition per lane ("wide" levels: at least a wave round of additions, where the chip is
+// throughput bound and the cooperative form's doubled work would be the cost).  in: nodes of 2^k buckets, k + 1 values each
+// (LEAF: k = 0, the bucket sums themselves, empty buckets read as the identity); out: n_out nodes of k + 2 values.
+// Lane (node, v), v <= k, adds value v of the node's two children; the lane of v = 0 also moves A_r into the new plane T_k.
+template <bool LEAF>
+__global__ void __launch_bounds__(256, 2)
+msm_planes_level(const uint32_t* __restrict__ offsets, const proj28_slot* __restrict__ in, uint32_t k, uint32_t n_out,
                  proj28_slot* __restrict__ out) {
-  proj28_slot* buf = reinterpret_cast<proj28_slot*>(msm_lds_tree);
-  const uint32_t w = blockIdx.y, nb = 1u << l1;
-  if (threadIdx.x < nb) {
-    const size_t g = (size_t)w * plan.B + ((size_t)blockIdx.x << l1) + threadIdx.x;
-    g1_proj28 s = offsets[g + 1] != offsets[g] ? load_proj28(&bucket_sum[g]) : g1_identity28();   // empty bucket: slot never written
-    store_proj28(&buf[threadIdx.x], s);
+  const uint64_t item = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t per = k + 1, node = (uint32_t)(item / per), v = (uint32_t)(item - (uint64_t)node * per);
+  if (node >= n_out) return;
+  g1_proj28 a, b;
+  if (LEAF) {
+    const size_t g = 2 * (size_t)node;
+    a = offsets[g + 1] != offsets[g] ? load_proj28(&in[g]) : g1_identity28();             // empty bucket: slot never written
+    b = offsets[g + 2] != offsets[g + 1] ? load_proj28(&in[g + 1]) : g1_identity28();
+  } else {
+    const proj28_slot* L = in + (size_t)(2 * (size_t)node) * per;
+    a = load_proj28(&L[v]);
+    b = load_proj28(&L[per + v]);
   }
-  __syncthreads();
-  const proj28_slot* root = planes_tree<THREADS == 256 ? 2 : 0>(buf, buf + nb, l1, true);
-  if (threadIdx.x <= l1) out[((size_t)w * gridDim.x + blockIdx.x) * (l1 + 1) + threadIdx.x] = root[threadIdx.x];
+  proj28_slot* o = out + (size_t)node * (per + 1);
+  if (v == 0) store_proj28(&o[per], b);                                                    // T_k = A_r
+  g1_add28(a, a, b);
+  store_proj28(&o[v], a);
 }
 
-// grid (l1 + 1, nodes out), 512 lanes = 64 cooperative groups (l2 <= 7).  Generic merge step of the tree: 2^l2 input nodes of (l1 + 1) values each (A and
-// l1 planes) become one output node of (l1 + l2 + 1) values; blockIdx.y = output node ("window" w below).  The host applies
-// it repeatedly until one node is left (wide windows: 2^(c-1) buckets need more than the two stages of c <= 16).
-// Workgroup v folds value v of the 2^l2 input nodes of output node w:
-//   v = 0: the block sums A -> window A and the planes l1 .. l1 + l2 - 1 (the block index supplies the high bits);
-//   v > 0: plane v - 1, a plain sum over the blocks.
-// out[w * (l1 + l2 + 1) + {0: A, 1 + j: T_j}]
-__global__ void __launch_bounds__(512, 1)
-msm_planes_window(const proj28_slot* __restrict__ in, uint32_t l1, uint32_t l2, proj28_slot* __restrict__ out,
-                  const uint32_t* __restrict__ status_in, const uint32_t* __restrict__ entries_in, uint32_t* __restrict__ status_out) {
+// m levels of the tree inside one workgroup, every addition shared by a group of COOP lanes ("narrow" levels: fewer pending
+// additions than the chip has lanes, so the length of the dependent chain is the cost: ~1 600 instructions per level instead of
+// ~6 600).  Generic step: 2^m input nodes of k + 1 values each (A and k planes) become one output node of k + m + 1 values.
+// grid (nodes out, k + 1): workgroup (w, v) folds value v of the 2^m input nodes of output node w --
+//   v = 0: the sums A -> the node's A and its planes k .. k + m - 1 (the input node's index supplies those bits);
+//   v > 0: plane v - 1, a plain sum over the input nodes.
+// 256 lanes = 32 cooperative groups: with m <= 6 no level has more than one round of additions (32, 32, 24, 16, 10, 6 for v = 0).
+// LEAF: k = 0, the input nodes are the bucket sums (empty buckets read as the identity).
+// status_out != null on the last step only: the scalar-status word and the entry count ride to the host behind the sums.
+// LDS: two arrays of 2^m slots.   out[w * (k + m + 1) + {0: A, 1 + j: T_j}]
+constexpr uint32_t PLANES_STEP_LOG = 6;
+template <bool LEAF>
+__global__ void __launch_bounds__(256, 2)
+msm_planes_step(const uint32_t* __restrict__ offsets, const proj28_slot* __restrict__ in, uint32_t k, uint32_t m,
+                proj28_slot* __restrict__ out, const uint32_t* __restrict__ status_in, const uint32_t* __restrict__ entries_in,
+                uint32_t* __restrict__ status_out) {
   proj28_slot* buf = reinterpret_cast<proj28_slot*>(msm_lds_tree);
-  const uint32_t v = blockIdx.x, w = blockIdx.y, nblk = 1u << l2, c = l1 + l2 + 1;
-  // status_out != null on the last stage only: the words ride to the host behind the sums
+  const uint32_t w = blockIdx.x, v = blockIdx.y, nin = 1u << m, c = k + m + 1;
   if (status_out && v == 0 && w == 0 && threadIdx.x == 0) { status_out[0] = *status_in; status_out[1] = *entries_in; }
-  if (threadIdx.x < nblk) buf[threadIdx.x] = in[((size_t)w * nblk + threadIdx.x) * (l1 + 1) + v];
+  if (threadIdx.x < nin) {
+    const size_t node = ((size_t)w << m) + threadIdx.x;
+    if (LEAF) {
+      if (offsets[node + 1] != offsets[node]) buf[threadIdx.x] = in[node];
+      else store_proj28(&buf[threadIdx.x], g1_identity28());
+    } else {
+      buf[threadIdx.x] = in[node * (k + 1) + v];
+    }
+  }
   __syncthreads();
-  const proj28_slot* root = planes_tree<1>(buf, buf + 128, l2, v == 0);
+  const proj28_slot* root = planes_tree(buf, buf + nin, m, v == 0);
   if (v == 0) {
     if (threadIdx.x == 0) out[(size_t)w * c] = root[0];
-    else if (threadIdx.x <= l2) out[(size_t)w * c + l1 + threadIdx.x] = root[threadIdx.x];     // T'_{j} -> plane l1 + j
+    else if (threadIdx.x <= m) out[(size_t)w * c + k + threadIdx.x] = root[threadIdx.x];       // T'_j -> plane k + j
   } else if (threadIdx.x == 0) {
     out[(size_t)w * c + v] = root[0];
   }
