@@ -64,6 +64,7 @@ SIGNATURES = {
     "bp_g1_partial_to_bytes96": (_int, [_vp, _vp]),
     "bp_g1_bytes96_to_partial": (_int, [_vp, _vp]),
     "bp_msm_last_stats": (_int, [_vp, _pp(C.c_float), _pp(C.c_float), _pp(_u64), _pp(_u32)]),
+    "bp_msm_last_member_stats": (_int, [_vp, _int, _pp(C.c_float), _pp(C.c_float), _pp(C.c_float), _pp(_u64)]),
     "bp_ntt_fr": (_int, [_vp, _vp, _u32, _int, _int, _sz, _sz]),
     "bp_ntt_fr_device": (_int, [_vp, _vp, _u32, _int, _sz, _sz]),
     "bp_ntt_fr_device_async": (_int, [_vp, _vp, _u32, _int, _sz, _sz]),

@@ -192,6 +192,15 @@ class Context:
         return {"accumulate_ms": a.value, "device_ms": t.value, "mixed_adds": adds.value, "window_bits": c.value,
                 "tables": self._lib.bp_msm_last_used_tables(self._h) == 1}
 
+    def msm_member_stats(self):
+        """per member of a group context: upload (host scalars only), accumulate and whole-pipeline device times of the last MSM"""
+        out = []
+        for r in range(self.n_shards()):
+            u, a, t, adds = C.c_float(), C.c_float(), C.c_float(), C.c_uint64()
+            self.check(self._lib.bp_msm_last_member_stats(self._h, r, C.byref(u), C.byref(a), C.byref(t), C.byref(adds)), "bp_msm_last_member_stats")
+            out.append({"member": r, "upload_ms": u.value, "accumulate_ms": a.value, "device_ms": t.value, "mixed_adds": adds.value})
+        return out
+
     def ntt(self, values, inverse=False, fmt=FR_MONT):
         """one vector; raises like the reference's assert!(is_power_of_two(n)) (utils.rs:65,108)"""
         a = _fr_array(values).copy()

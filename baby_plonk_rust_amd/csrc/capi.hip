@@ -241,9 +241,11 @@ static void over_members(bp_ctx* ctx, size_t R, const std::function<bool(size_t)
   if (R > 0 && use(0)) work(0);
   for (size_t r : sent) lead->workers[r - 1]->wait();
 }
-static bool force_peer_copies() {      // test hook: take the GPU-to-GPU copy branches even when both ends are the same device
-  static const bool on = [] { const char* v = getenv("BP_FORCE_PEER_COPIES"); return v && *v && *v != '0'; }();
-  return on;
+// test hook (BP_FORCE_PEER_COPIES=1): take the GPU-to-GPU copy branch (hipMemcpyPeerAsync behind the leader's event) even when
+// both ends are the same device, so that a one-GPU box executes the lines a multi-GPU node runs
+static bool force_peer_copies() {
+  const char* v = getenv("BP_FORCE_PEER_COPIES");
+  return v && *v && *v != '0';
 }
 
 // contiguous point range [lo, hi) of shard r of R over n points; the first n % R shards get one extra point
@@ -626,8 +628,8 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
     uint32_t lg = 0;
     const uint64_t n = lead->n;
     while ((2ull << lg) <= n) lg++;                       // floor(log2 n)
-    if (lg >= 22) {                   // 13 windows instead of 16: pays once the partitioned sort and the 2^19-bucket tree are
-      c = 20;                         // small against 3 x n additions (measured: -16 % at 2^24, -14 % at 2^23, -7 % at 2^22, 0 at 2^21; profiles/r02_window_width_ab.txt)
+    if (lg >= 21) {                   // 13 windows instead of 16: pays once the sort and the 2^19-bucket tree are small against
+      c = 20;                         // 3 x n additions (round 3: -6 % at 2^21, -12 % at 2^22, a tie at 2^20; profiles/r03_window_width_ab.txt)
     } else if (n >= (1u << 14)) {     // throughput regime: reduction work 2^c stays below the bucket-add work W * n
       c = lg + 2 > 16 ? 16 : lg + 2;
     } else {                          // latency regime (a few thousand points): every kernel is a dependent chain, and the
@@ -674,6 +676,7 @@ static int msm_shard_launch(bp_ctx* m, SrsEntry* e, size_t local_first, const vo
     fr_t* d;
     BP_TRY(ws_get(m, "io.scalars", n * sizeof(fr_t), (void**)&d));
     if (where == 0) {
+      BP_HIP(m, hipEventRecord(m->ev[4], m->stream));            // upload = ev[4] .. ev[0] (msm_launch records ev[0] first thing)
       BP_HIP(m, hipMemcpyAsync(d, scalars, n * sizeof(fr_t), hipMemcpyHostToDevice, m->stream));
     } else {
       BP_HIP(m, hipStreamWaitEvent(m->stream, ready, 0));
@@ -693,6 +696,7 @@ static int msm_shard_launch(bp_ctx* m, SrsEntry* e, size_t local_first, const vo
 struct ShardedPending {
   std::vector<MsmPending> pend;
   std::vector<bool> used;
+  bool host_scalars = false;
 };
 static int msm_all_shards_launch(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
                                  int scalars_on_device, int slot, ShardedPending* sp) {
@@ -708,6 +712,7 @@ static int msm_all_shards_launch(bp_ctx* ctx, uint64_t srs_handle, size_t first,
   }
   sp->pend.assign(sh.size(), MsmPending());
   sp->used.assign(sh.size(), false);
+  sp->host_scalars = !scalars_on_device;
   // every shard's range, then the launches: scalars already in HBM are enqueued by this thread (asynchronous copies and kernels);
   // host scalars go through the members' own threads, so that the uploads -- staged by the issuing thread when the memory is
   // pageable, as a Rust Vec<Scalar> is -- run on all PCIe links at once instead of one after another
@@ -756,6 +761,11 @@ static int msm_all_shards_finish(bp_ctx* ctx, const ShardedPending& sp, int rc, 
   over_members(ctx, sh.size(), [&](size_t r) { return (bool)used[r]; }, [&](size_t r) {
     DeviceGuard guard(sh[r]->device);
     rcs[r] = msm_finish(sh[r], pend[r], &part[r]);
+    sh[r]->msm_upload_ms = 0;
+    if (rcs[r] == BP_OK && sp.host_scalars && !pend[r].empty && hipEventElapsedTime(&sh[r]->msm_upload_ms, sh[r]->ev[4], sh[r]->ev[0]) != hipSuccess) {
+      (void)hipGetLastError();
+      sh[r]->msm_upload_ms = 0;
+    }
   });
   g1_proj acc = g1_identity();
   float acc_ms = 0, dev_ms = 0;
@@ -921,6 +931,17 @@ int bp_g1_bytes96_to_compressed48(const uint8_t in96[96], uint8_t out48[48]) {
   g1_proj p;
   if (!host_decode96(p, in96)) return BP_ERR_BAD_POINT;
   host_compress48(out48, p);
+  return BP_OK;
+}
+int bp_msm_last_member_stats(bp_ctx* ctx, int member, float* upload_ms, float* accumulate_ms, float* total_device_ms, uint64_t* mixed_adds) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  const std::vector<bp_ctx*> sh = shards_of(ctx);
+  if (member < 0 || (size_t)member >= sh.size()) return BP_ERR_INVALID_ARG;
+  const bp_ctx* m = sh[member];
+  if (upload_ms) *upload_ms = m->msm_upload_ms;
+  if (accumulate_ms) *accumulate_ms = m->msm_accumulate_ms;
+  if (total_device_ms) *total_device_ms = m->msm_total_ms;
+  if (mixed_adds) *mixed_adds = m->msm_adds;
   return BP_OK;
 }
 int bp_msm_last_used_tables(bp_ctx* ctx) { return ctx ? (ctx->msm_tables ? 1 : 0) : BP_ERR_INVALID_ARG; }

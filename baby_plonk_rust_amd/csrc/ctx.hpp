@@ -91,6 +91,7 @@ struct bp_ctx {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [0..3] MSM / NTT timing, [4] cross-stream ordering (groups)
   // stats of the last calls
   float msm_accumulate_ms = 0, msm_total_ms = 0;
+  float msm_upload_ms = 0;         // host scalars: the H2D copy in front of the last MSM (ev[4] .. ev[0]); else 0
   uint64_t msm_adds = 0;
   uint32_t msm_c = 0;
   bool msm_tables = false;

@@ -212,6 +212,7 @@ def main():
 
     import baby_plonk_rust_amd as bp
     from baby_plonk_rust_amd import dist as bpd
+    from baby_plonk_rust_amd.synthetic import Q as FR_Q
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -277,11 +278,11 @@ def main():
 
     def timed_ntt(d_vec, log_n, steps, warmup):
         """K transforms of the HBM-resident vector enqueued back to back (bp_ntt_fr_device_async) and one wait: the step is the
-        transform, not a host round trip; the blocking call (one hipStreamSynchronize per transform) is timed beside it"""
-        ms = []
+        transform, not a host round trip; the blocking call (one hipStreamSynchronize per transform) is timed beside it.
+        kernel_ms: HIP events around the passes of one transform of the TIMED region -- after the warm-up has built the pass tables
+        (round 2 read them during the warm-up and reported a kernel time above the step time)."""
         for _ in range(max(warmup, 3)):
             ctx.ntt_device(d_vec.data_ptr(), log_n)
-            ms.append(ctx.ntt_stats()["device_ms"])              # HIP events around the kernels of one transform
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -293,7 +294,43 @@ def main():
             ctx.ntt_device_async(d_vec.data_ptr(), log_n)
         ctx.synchronize()
         barrier()
-        return {"elapsed": time.perf_counter() - t0, "blocking_ms": 1e3 * blocking / steps, "dev_ms": float(np.mean(ms[-3:])), "passes": ctx.ntt_stats()["passes"]}
+        elapsed = time.perf_counter() - t0
+        # events around the passes of the LAST enqueued transform: its first event completes when the transform before it has
+        # drained, so the interval is the transform's own GPU time inside the timed, back-to-back stream (a blocking call's events
+        # also contain the host's launch gaps between the passes)
+        dev_ms = float(ctx.ntt_stats()["device_ms"])
+        # a kernel time cannot exceed the time of the step it is part of (events and wall clock differ by microseconds at most)
+        consistent = dev_ms <= 1.03 * 1e3 * elapsed / steps + 0.003
+        return {"elapsed": elapsed, "blocking_ms": 1e3 * blocking / steps, "dev_ms": dev_ms, "passes": ctx.ntt_stats()["passes"],
+                "kernel_le_step": bool(consistent)}
+
+    def fr_sums(t, count, first):
+        """(sum_i s_i, sum_i (first + i) s_i) over the `count` raw 256-bit words of tensor t (int64 x 4 per element), as Python
+        integers -- exact integer arithmetic on the GPU in 16-bit limbs, no modular reduction, no CPU oracle"""
+        w = t.view(count, 4)
+        idx = torch.arange(first, first + count, dtype=torch.int64, device=t.device)
+        lo, hi = idx & 0xFFF, idx >> 12                                   # i = hi * 4096 + lo, both factors small enough for exact int64 sums
+        s0 = s1 = 0
+        for j in range(4):
+            for part in range(4):
+                limb = (w[:, j] >> (16 * part)) & 0xFFFF
+                shift = 64 * j + 16 * part
+                s0 += int(limb.sum().item()) << shift
+                s1 += (int((limb * lo).sum().item()) + (int((limb * hi).sum().item()) << 12)) << shift
+        return s0, s1
+
+    R_INV = pow(1 << 256, -1, FR_Q)
+
+    def expected_msm(sum_pairs, a0, d0):
+        """96 bytes of (sum_i s_i (a0 + i d0)) G from the ranks' (sum s, sum i s) pairs (s in Montgomery form: one R^-1), through
+        the library itself: a one-point MSM of G by that scalar"""
+        s0 = sum(p[0] for p in sum_pairs)
+        s1 = sum(p[1] for p in sum_pairs)
+        k = (a0 * s0 + d0 * s1) % FR_Q * R_INV % FR_Q
+        g = ctx.srs_generate_progression(1, 1, 0)
+        out = ctx.msm(g, bp.scalars_from_ints([k]))
+        ctx.srs_free(g)
+        return out
 
     def synthetic(count, seed, first=0):
         """`count` scalars of the global stream `seed`, starting at element `first` (8 SplitMix64 words per element)"""
@@ -320,6 +357,11 @@ def main():
     head = timed_msm(srs, scal, n, args.steps, args.warmup)
     assert other["result"] == head["result"], "MSM with and without fixed-base tables disagree"
     assert head["stats"]["tables"] == (not args.no_tables)
+    # the timed result against the closed form: points are (A0 + i D0) G, so the MSM is (sum_i s_i (A0 + i D0)) G -- one dot
+    # product mod q, each rank's share computed where its scalars are (a wrong sum must not print a scaling number)
+    weak_pairs = gather_objects(fr_sums(scal, n, rank * n))
+    weak_ok = expected_msm(weak_pairs, A0, D0) == head["result"]
+    assert weak_ok, "weak-scaling MSM differs from the closed form"
 
     # ---------------------------------------------------------------- seams of the reference (N = 1): host scalars, uncached points
     seams = {}
@@ -334,6 +376,7 @@ def main():
         assert r == head["result"]
         seams["msm_host_scalars"] = {
             "value": n * args.steps / dt, "unit": "scalar-muls/s", "ms_per_step": 1e3 * dt / args.steps, "device_ms": ctx.msm_stats()["device_ms"],
+            "tail_ms": ctx.msm_stats()["device_ms"] - ctx.msm_stats()["accumulate_ms"],
             "seam": "Setup::commit(&Polynomial) (setup.rs:32-37): %d MiB of pageable host scalars cross PCIe per call, SRS and tables resident"
                     % (32 * n >> 20)}
         images = ctx.srs_export_projective144(srs)                         # what Setup.powers_of_x: Vec<G1Projective> holds (g1.rs:442-446)
@@ -359,6 +402,19 @@ def main():
     # ---------------------------------------------------------------- NTT leg (independent columns, no collective)
     nn = 1 << args.ntt_log_n
     vec = synthetic(nn, 0xF40000 + args.ntt_log_n, rank * nn)
+    def ntt_spot_check(v, log_n):
+        """output 0 of a forward transform is the plain sum of the inputs; the inverse brings the vector back"""
+        c = v.clone()
+        ctx.ntt_device(c.data_ptr(), log_n)
+        torch.cuda.synchronize()
+        out0 = sum((int(x) & MASK64) << (64 * j) for j, x in enumerate(c[:4].tolist()))
+        ok = out0 == fr_sums(v, 1 << log_n, 0)[0] % FR_Q
+        ctx.ntt_device(c.data_ptr(), log_n, inverse=True)
+        torch.cuda.synchronize()
+        return bool(ok and torch.equal(c, v))
+
+    ntt_ok = ntt_spot_check(vec, args.ntt_log_n)
+    assert ntt_ok, "NTT spot check failed"
     ntt = timed_ntt(vec, args.ntt_log_n, args.steps, args.warmup)
 
     # ---------------------------------------------------------------- the metric's other sizes, N = 1 (2^16 = configs[1]; 2^24 rides on the strong leg)
@@ -384,13 +440,19 @@ def main():
             vec = synthetic(m, 0xF40000 + lg)
             k = args.steps if lg <= 22 else max(2, min(args.steps, 5))
             r = timed_msm(srs, scal, m, k, args.warmup)
+            size_ok = expected_msm([fr_sums(scal, m, 0)], A0, D0) == r["result"]
+            assert size_ok, "2^%d MSM differs from the closed form" % lg
+            size_ntt_ok = ntt_spot_check(vec, lg)
+            assert size_ntt_ok, "2^%d NTT spot check failed" % lg
             t = timed_ntt(vec, lg, k, args.warmup)
             hbm, issue = msm_roofline(m, r["acc_ms"] * 1e-3, r["stats"]["mixed_adds"], r["stats"]["window_bits"], r["stats"]["tables"])
             sizes["2^%d" % lg] = {"steps": k, "msm": {"value": m * k / r["elapsed"], "unit": "scalar-muls/s", "ms_per_step": 1e3 * r["elapsed"] / k,
-                                                        "device_ms": r["dev_ms"], "window_bits": r["stats"]["window_bits"], "tables": r["stats"]["tables"],
-                                                        "roofline": hbm, "roofline_valu_issue": issue},
+                                                        "device_ms": r["dev_ms"], "accumulate_ms": r["acc_ms"], "tail_ms": r["dev_ms"] - r["acc_ms"],
+                                                        "window_bits": r["stats"]["window_bits"], "tables": r["stats"]["tables"],
+                                                        "equals_closed_form": size_ok, "roofline": hbm, "roofline_valu_issue": issue},
                                   "ntt": {"value": m * k / t["elapsed"], "unit": "elements/s", "ms_per_step": 1e3 * t["elapsed"] / k, "ms_per_blocking_call": t["blocking_ms"],
-                                          "passes": t["passes"], "roofline": ntt_roofline(m, t["dev_ms"] * 1e-3, t["passes"])}}
+                                          "passes": t["passes"], "kernel_le_step": t["kernel_le_step"], "spot_check": size_ntt_ok,
+                                          "roofline": ntt_roofline(m, t["dev_ms"] * 1e-3, t["passes"])}}
 
     # ---------------------------------------------------------------- strong scaling = BASELINE configs[3]: ONE 2^24-point MSM over all ranks
     strong = None
@@ -408,10 +470,58 @@ def main():
         scal = synthetic(m, 0x5EED0000 + args.strong_log_n, lo)
         k = args.strong_steps or max(2, min(args.steps, 10))
         r = timed_msm(srs, scal, m, k, 2)
+        strong_pairs = gather_objects(fr_sums(scal, m, lo))
+        strong_ok = expected_msm(strong_pairs, A0, D0) == r["result"]
+        assert strong_ok, "strong-scaling MSM differs from the closed form"
         strong = {"r": r, "k": k, "m": m, "total": total, "table_info": s_info, "gen_s": t_gen, "table_s": t_tab}
         if world == 1 and args.strong_log_n <= 26:
             vec = synthetic(total, 0xF40000 + args.strong_log_n)
             strong["ntt"] = timed_ntt(vec, args.strong_log_n, k, 2)
+
+    # ---------------------------------------------------------------- the drop-in's multi-GPU seam (N > 1): ONE commit through bp_init_multi
+    # BASELINE configs[3] as the reference's single-threaded caller sees it (setup.rs:32-37, msm.rs:76-81): rank 0's process holds
+    # one context over all N GPUs; one 2^strong_log_n-point MSM from PAGEABLE host scalars per step -- every member's slice crosses
+    # its own PCIe link on its own host thread, every member runs its pipeline, the partial sums are added on the host.  The
+    # other ranks wait on the host (their GPUs are driven by rank 0 here); same points and scalars as the strong leg above.
+    def host_barrier():
+        if use_dist:
+            dist.barrier(group=ctl) if ctl is not None else dist.barrier()
+
+    group_commit = None
+    if world > 1 and strong is not None:
+        torch.cuda.synchronize()
+        host_barrier()
+        if rank == 0:
+            try:
+                total = strong["total"]
+                gctx = bp.Context(list(range(world)) if args.backend == "nccl" else [dev_index] * world)
+                t0 = time.perf_counter()
+                gsrs = gctx.srs_generate_progression(total, A0, D0)
+                ginfo = gctx.srs_precompute(gsrs, bp.SRS_TABLES_OFF if args.no_tables else 0)
+                g_setup = time.perf_counter() - t0
+                hs = synthetic(total, 0x5EED0000 + args.strong_log_n, 0).cpu().numpy().view(np.uint64).reshape(total, 4)    # pageable, as a Vec<Scalar> is
+                for _ in range(2):
+                    gres = gctx.msm(gsrs, hs)
+                k = strong["k"]
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    gres = gctx.msm(gsrs, hs)
+                g_dt = time.perf_counter() - t0
+                members = gctx.msm_member_stats()
+                group_commit = {
+                    "metric": "g1_msm_scalar_muls_per_s", "value": total * k / g_dt, "unit": "scalar-muls/s", "n_gpus": world, "steps": k,
+                    "ms_per_step": 1e3 * g_dt / k, "scalars": "pageable host memory, %d MiB per step, one slice per member over its own PCIe link" % (32 * total >> 20),
+                    "window_bits": ginfo["window_bits"], "table_bytes_all_gpus": ginfo["bytes"], "srs_and_tables_s": g_setup,
+                    "per_member": members, "upload_ms_max": max(m["upload_ms"] for m in members), "device_ms_max": max(m["device_ms"] for m in members),
+                    "same_result": gres == strong["r"]["result"], "result_sha": hashlib.sha256(gres).hexdigest()[:16],
+                    "how": "one bp_init_multi context in rank 0's process (the drop-in for Setup::commit, setup.rs:32-37): SRS sharded by point "
+                           "range, one persistent host thread per member, partial sums added on the host; no collective"}
+                gctx.srs_free(gsrs)
+                gctx.close()
+                del hs
+            except Exception as e:                                # never lose the line over this leg
+                group_commit = {"n_gpus": world, "error": repr(e)[:300]}
+        host_barrier()
 
     # ---------------------------------------------------------------- prover leg (BASELINE configs[4])
     prove = None
@@ -542,12 +652,18 @@ def main():
             "roofline": hbm,
             "roofline_valu_issue": issue,
             "msm_device_ms": head["dev_ms"],
+            "msm_accumulate_ms": head["acc_ms"],
+            "tail_ms": head["dev_ms"] - head["acc_ms"],
+            "tail_note": "device time of one MSM outside msm_accumulate: bucket sort (3 launches), fix-up, bit-plane tree, copies",
+            "equals_closed_form": weak_ok,
             "exchange_ms": head["exchange_ms"],
             ("msm_with_tables" if args.no_tables else "msm_without_tables"): {
                 "value": units / other_elapsed, "unit": "scalar-muls/s", "ms_per_step": 1e3 * other_elapsed / args.steps,
-                "device_ms": other["dev_ms"], "accumulate_ms": other["acc_ms"], "window_bits": other["stats"]["window_bits"]},
+                "device_ms": other["dev_ms"], "accumulate_ms": other["acc_ms"], "tail_ms": other["dev_ms"] - other["acc_ms"],
+                "window_bits": other["stats"]["window_bits"]},
             "ntt": {"metric": "fr_ntt_elements_per_s", "value": world * nn * args.steps / ntt_elapsed, "unit": "elements/s",
                     "ms_per_step": 1e3 * ntt_elapsed / args.steps, "ms_per_blocking_call": ntt["blocking_ms"], "passes": ntt["passes"],
+                    "kernel_le_step": ntt["kernel_le_step"], "spot_check": ntt_ok,
                     "how": "steps enqueued back to back on the context's stream (bp_ntt_fr_device_async), one wait at the end; "
                            "ms_per_blocking_call = the same transform through bp_ntt_fr_device, which waits for the stream every call",
                     "roofline": ntt_roofline(nn, ntt["dev_ms"] * 1e-3, ntt["passes"], "ntt_2p%d" % args.ntt_log_n)},
@@ -571,6 +687,8 @@ def main():
                 "points_per_rank": strong["m"], "window_bits": r["stats"]["window_bits"], "tables": r["stats"]["tables"],
                 "accumulate_ms_per_rank": [p["strong_accumulate_ms"] for p in per_rank],
                 "device_ms_per_rank": [p["strong_device_ms"] for p in per_rank],
+                "tail_ms_per_rank": [p["strong_device_ms"] - p["strong_accumulate_ms"] for p in per_rank],
+                "equals_closed_form": strong_ok,
                 "exchange_ms_per_rank": [p["strong_exchange_ms"] for p in per_rank],
                 "srs_generate_s": strong["gen_s"], "table_build_s": strong["table_s"], "table_bytes_per_gpu": strong["table_info"]["bytes"],
                 "result_sha": hashlib.sha256(r["result"]).hexdigest()[:16],
@@ -578,8 +696,10 @@ def main():
             if "ntt" in strong:
                 t = strong["ntt"]
                 line["strong_scaling"]["ntt"] = {"value": strong["total"] * k / t["elapsed"], "unit": "elements/s", "ms_per_step": 1e3 * t["elapsed"] / k,
-                                                 "ms_per_blocking_call": t["blocking_ms"], "passes": t["passes"],
+                                                 "ms_per_blocking_call": t["blocking_ms"], "passes": t["passes"], "kernel_le_step": t["kernel_le_step"],
                                                  "roofline": ntt_roofline(strong["total"], t["dev_ms"] * 1e-3, t["passes"], "ntt_2p%d" % args.strong_log_n)}
+        if group_commit:
+            line["group_commit"] = group_commit
         if prove:
             line["prove"] = {"metric": "plonk_proofs_per_s", "value": world * prove["streams"] * args.prove_reps / prove_elapsed, "unit": "proofs/s",
                              "gates": 1 << args.prove_log_n, "concurrent_provers_per_gpu": prove["streams"],

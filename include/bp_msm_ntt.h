@@ -155,6 +155,11 @@ int  bp_g1_bytes96_to_compressed48(const uint8_t in96[96], uint8_t out48[48]);
 /* HIP-event duration of the bucket-accumulation kernel of the last MSM on this ctx, and its adds. */
 int  bp_msm_last_stats(bp_ctx* ctx, float* accumulate_ms, float* total_device_ms, uint64_t* mixed_adds,
                        uint32_t* window_bits);
+/* The same per member of a bp_init_multi context (member 0 .. bp_ctx_devices() - 1; a plain context has member 0 only), plus
+ * the time of the member's scalar upload when the last MSM took host scalars (0 otherwise): the split of one
+ * Setup::commit(&Polynomial) (setup.rs:32-37) over the GPUs into PCIe time and compute time.  Any pointer may be null. */
+int  bp_msm_last_member_stats(bp_ctx* ctx, int member, float* upload_ms, float* accumulate_ms, float* total_device_ms,
+                              uint64_t* mixed_adds);
 /* 1 when the last MSM on this ctx went through fixed-base tables, 0 when not, negative on error. */
 int  bp_msm_last_used_tables(bp_ctx* ctx);
 
