@@ -802,10 +802,100 @@ static int msm_all_shards(bp_ctx* ctx, uint64_t srs_handle, size_t first, const 
 
 namespace bp {
 constexpr int MAX_LANES = 3;
+constexpr int MSM_BATCH_MAX = 4;          // = MSM_MAX_BATCH of msm_kernels.hpp (scalar vectors in one pipeline)
+
+// k commitments of HBM-resident coefficient vectors (on the leader) over the members of a group: per batch of up to MSM_BATCH_MAX
+// vectors every member receives its slice of each (peer copies behind the leader's event), runs ONE pipeline over the slices'
+// bucket sets and delivers one partial sum per vector; the host adds the members' partial sums.  BP_ERR_TOO_LARGE before anything
+// was launched = a member's batch does not fit one pipeline.
+static int commit_many_group_batched(bp_ctx* ctx, uint64_t srs_handle, SrsEntry* lead, const fr_t* const* d_coeffs, const size_t* n, int k, g1_proj* out) {
+  const std::vector<bp_ctx*> sh = ctx->members;
+  const std::vector<uint64_t> hs = lead->member_handle;
+  const size_t R = sh.size();
+  std::vector<SrsEntry*> ent(R, nullptr);
+  for (size_t r = 0; r < R; r++) {
+    uint64_t h = hs.empty() ? srs_handle : hs[r];
+    auto it = sh[r]->srs.find(h);
+    if (it == sh[r]->srs.end()) return fail(ctx, BP_ERR_INVALID_ARG, "unknown SRS handle", hipSuccess, __FILE__, __LINE__);
+    ent[r] = &it->second;
+    if (!ent[r]->d_table) return BP_ERR_TOO_LARGE;
+  }
+  for (int base = 0; base < k; base += MSM_BATCH_MAX) {
+    const int cnt = std::min(MSM_BATCH_MAX, k - base);
+    {
+      DeviceGuard guard(ctx->device);
+      BP_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));          // the coefficient vectors were produced on the leader's stream
+    }
+    std::vector<MsmPending> pend(R);
+    std::vector<int> rcs(R, BP_OK);
+    std::vector<bool> used(R, false);
+    int rc = BP_OK;
+    for (size_t r = 0; r < R && rc == BP_OK; r++) {
+      bp_ctx* m = sh[r];
+      SrsEntry* e = ent[r];
+      DeviceGuard guard(m->device);
+      const fr_t* ptrs[MSM_BATCH_MAX];
+      size_t lens[MSM_BATCH_MAX], total = 0;
+      for (int j = 0; j < cnt; j++) {
+        const size_t nj = std::min(n[base + j], lead->n_global);        // zip() truncation, msm.rs:29
+        lens[j] = nj > e->first ? std::min(nj - e->first, e->n) : 0;
+        total += lens[j];
+      }
+      if (total == 0) continue;
+      if (r == 0) {
+        for (int j = 0; j < cnt; j++) ptrs[j] = d_coeffs[base + j] + e->first;
+      } else {
+        fr_t* d;
+        rc = lift(ctx, m, ws_get(m, "io.scalars", total * sizeof(fr_t), (void**)&d));
+        if (rc != BP_OK) break;
+        hipError_t he = hipStreamWaitEvent(m->stream, ctx->ev[4], 0);
+        size_t at = 0;
+        for (int j = 0; j < cnt && he == hipSuccess; j++) {
+          if (lens[j]) {
+            const fr_t* src = d_coeffs[base + j] + e->first;
+            if (ctx->device == m->device && !force_peer_copies()) he = hipMemcpyAsync(d + at, src, lens[j] * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream);
+            else he = hipMemcpyPeerAsync(d + at, m->device, src, ctx->device, lens[j] * sizeof(fr_t), m->stream);
+          }
+          ptrs[j] = d + at;
+          at += lens[j];
+        }
+        if (he != hipSuccess) { rc = fail(ctx, BP_ERR_HIP, "commit batch: scalar slices", he, __FILE__, __LINE__); break; }
+      }
+      // (the tables are used whatever the slice lengths: skipping them for very short slices is a speed heuristic of the single path)
+      rcs[r] = msm_launch_many(m, e->d_table, (uint32_t)cnt, ptrs, lens, BP_FR_MONT, e->table_c, e->n, 0, nullptr, &pend[r]);
+      if (rcs[r] == BP_ERR_TOO_LARGE && r == 0 && base == 0) return BP_ERR_TOO_LARGE;
+      used[r] = rcs[r] == BP_OK;
+      rc = lift(ctx, m, rcs[r]);
+    }
+    std::vector<g1_proj> part(R * MSM_BATCH_MAX);
+    over_members(ctx, R, [&](size_t r) { return (bool)used[r]; }, [&](size_t r) {
+      DeviceGuard guard(sh[r]->device);
+      rcs[r] = msm_finish(sh[r], pend[r], &part[r * MSM_BATCH_MAX]);
+    });
+    for (size_t r = 0; r < R; r++)
+      if (used[r] && rc == BP_OK) rc = lift(ctx, sh[r], rcs[r]);
+    if (rc != BP_OK) return rc;
+    for (int j = 0; j < cnt; j++) {
+      g1_proj acc = g1_identity();
+      for (size_t r = 0; r < R; r++)
+        if (used[r]) g1_add(acc, acc, part[r * MSM_BATCH_MAX + j]);
+      out[base + j] = acc;
+    }
+  }
+  return BP_OK;
+}
+
 int commit_many(bp_ctx* ctx, uint64_t srs_handle, const fr_t* const* d_coeffs, const size_t* n, int k, g1_proj* out) {
   if (k <= 0) return BP_OK;
   SrsEntry* e;
   BP_TRY(srs_find(ctx, srs_handle, &e));
+  if (is_group(ctx) && k > 1 && e->d_table) {   // group: ONE pipeline per member over its slices of up to MSM_BATCH_MAX commitments
+    const char* v = getenv("BP_COMMIT_BATCH");
+    if (!(v && *v == '0')) {
+      int rc = commit_many_group_batched(ctx, srs_handle, e, d_coeffs, n, k, out);
+      if (rc != BP_ERR_TOO_LARGE) return rc;       // too long for one pipeline somewhere: queue the commitments one by one below
+    }
+  }
   if (is_group(ctx) || k == 1) {            // group: every member queues its shards of up to MSM_SLOTS commitments back to back
     for (int base = 0; base < k; base += MSM_SLOTS) {
       const int cnt = std::min((int)MSM_SLOTS, k - base);
@@ -822,6 +912,40 @@ int commit_many(bp_ctx* ctx, uint64_t srs_handle, const fr_t* const* d_coeffs, c
     return BP_OK;
   }
   DeviceGuard guard(ctx->device);
+  // One pipeline over the bucket sets of up to MSM_MAX_BATCH commitments (msm_launch_many): one sort keyed (polynomial, bucket),
+  // one accumulation, one fix-up, one tree over J x 2^(c-1) buckets -- the latency-bound tail is paid once per round instead of
+  // once per commitment.  Needs the SRS's fixed-base tables and a batch short enough for the partition sort.  On ONE device the
+  // concurrent lanes below already hide the tails of two commitments under the accumulation of the third, and the batch's
+  // three-fold sort is exposed: measured 35.6 ms per 2^20-gate proof against 34.4-35.4 with lanes (profiles/r03_commit_batch_ab.txt),
+  // so the batch runs only on request there (BP_COMMIT_BATCH=1).  The members of a group context, whose shards are short and whose
+  // pipelines share one stream each, use it by default (above).
+  {
+    const char* v = getenv("BP_COMMIT_BATCH");
+    size_t n_max = 0;
+    for (int j = 0; j < k; j++) n_max = std::max(n_max, std::min(n[j], e->n));
+    const bool tables = e->d_table && 8 * (uint64_t)n_max >= (1ull << ((e->table_c & MSM_NAF_FLAG) ? (e->table_c & 0xffu) - 2 : e->table_c));
+    if (tables && v && *v == '1') {
+      bool ok = true;
+      for (int base = 0; base < k && ok; base += (int)MSM_BATCH_MAX) {
+        const int cnt = std::min((int)MSM_BATCH_MAX, k - base);
+        const fr_t* ptrs[MSM_BATCH_MAX];
+        size_t lens[MSM_BATCH_MAX];
+        for (int j = 0; j < cnt; j++) {
+          ptrs[j] = d_coeffs[base + j];
+          lens[j] = std::min(n[base + j], e->n);                        // zip() truncation, msm.rs:29
+        }
+        MsmPending pend;
+        int rc = msm_launch_many(ctx, e->d_table, (uint32_t)cnt, ptrs, lens, BP_FR_MONT, e->table_c, e->n, 0, nullptr, &pend);
+        if (rc == BP_ERR_TOO_LARGE && base == 0) {                      // too long for one pipeline: the lanes below
+          ok = false;
+          break;
+        }
+        if (rc != BP_OK) return rc;
+        BP_TRY(msm_finish(ctx, pend, &out[base]));
+      }
+      if (ok) return BP_OK;
+    }
+  }
   while ((int)ctx->lanes.size() < MAX_LANES - 1 && (int)ctx->lanes.size() < k - 1) {
     bp_ctx* lane = nullptr;
     int rc = ctx_create(&lane, ctx->device);

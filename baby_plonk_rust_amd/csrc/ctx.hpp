@@ -149,12 +149,15 @@ struct MsmPending {
   bool empty = true, blob = false;
   uint32_t tables = 0;                  // 0: per-window buckets; 1: fixed-base window tables; 2: every-position tables (odd NAF digits)
   uint32_t c = 0, Wr = 0, n_planes = 0;
+  uint32_t J = 1;                       // scalar vectors in the pipeline (msm_launch_many): msm_finish writes J results
   uint64_t adds = 0;
   const void* h_windows = nullptr;      // pinned: n_planes accumulator slots + the status word
 };
 // d_blob != nullptr: the result stays in HBM as a BP_MSM_BLOB_BYTES record (msm_kernels.hpp) instead of the pinned slot
 int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
                int slot, void* d_blob, MsmPending* out);
+int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, const fr_t* const* d_scalars_each, const size_t* n_each, int fmt,
+                    uint32_t table_c, size_t table_stride, int slot, void* d_blob, MsmPending* out);
 int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out);
 int msm_blobs_sum_device_run(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out);
 int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out);

@@ -28,26 +28,28 @@ static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo = 0, uint32
 // bounded by the 128 KiB LDS histogram of one window (c <= 16); with fixed-base tables wider windows go through the
 // partitioned sort (plan.parts > 1), up to MSM_MAX_TABLE_C.
 // table_c != 0: the SRS carries fixed-base window tables built for that width (row length table_stride)
-static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_stride) {
+static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_stride, uint32_t J = 1) {
   memset(&plan, 0, sizeof plan);
   plan.n = (uint32_t)n;
+  plan.J = J;
+  plan.nj[0] = (uint32_t)n;
   if (table_c & MSM_NAF_FLAG) {         // every-position tables: odd NAF digits of width w, 2^(w-2) buckets, one bucket set
     const uint32_t w = table_c & 0xffu;
     plan.naf = w;
     plan.c = w - 1;
     plan.W = 255 / w + 1;               // digit slots per scalar (most scalars fill 256 / (w + 1) of them)
     plan.B = 1u << (w - 2);
-    plan.total = plan.B;
+    plan.total = J * plan.B;
     plan.wbuckets = 0;
     plan.wpoints = (uint32_t)table_stride;
     plan.parts = plan.B <= (1u << MSM_HIST_LOG) ? 1 : plan.B >> MSM_HIST_LOG;
     // lanes: one wave round (131 072) for the worst case of every slot filled; the kernels cut the sorted list by the actual
     // entry count (a uniform scalar fills 256 / (w + 1) + ~0.45 of its slots: 15.49 / 13.91 / 12.71 at w = 16 / 18 / 20)
-    uint32_t chunk = (uint32_t)(((uint64_t)plan.W * n + 131071) / 131072);
+    uint32_t chunk = (uint32_t)(((uint64_t)plan.W * n * J + 131071) / 131072);
     if (chunk < 4) chunk = 4;
     if (chunk > 1024) chunk = 1024;
     plan.chunk = env_u32("BP_MSM_CHUNK", chunk, 1, 1024);
-    plan.lanes = env_u32("BP_MSM_CHUNK", 0, 1, 1024) ? 0u : (uint32_t)(((uint64_t)plan.W * n + plan.chunk - 1) / plan.chunk);
+    plan.lanes = env_u32("BP_MSM_CHUNK", 0, 1, 1024) ? 0u : (uint32_t)(((uint64_t)plan.W * n * J + plan.chunk - 1) / plan.chunk);
     plan.slices = 1;
     plan.seg = 1;
     return;
@@ -99,11 +101,11 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   plan.c = c;
   plan.W = W;
   plan.B = 1u << (c - 1);
-  plan.total = table_c ? plan.B : W * plan.B;
+  plan.total = table_c ? J * plan.B : W * plan.B;
   plan.wbuckets = table_c ? 0 : plan.B;
   plan.wpoints = table_c ? (uint32_t)table_stride : 0;
   plan.parts = plan.B <= (1u << MSM_HIST_LOG) ? 1 : plan.B >> MSM_HIST_LOG;
-  const uint64_t entries = (uint64_t)W * n;
+  const uint64_t entries = (uint64_t)W * n * J;
   // entries per lane: the kernel runs 2 waves per SIMD = 131072 lanes at a time and every lane does the same work, so the
   // lane count should land just under a whole number of such rounds.  (A power-of-two chunk wasted up to a third of the last
   // round whenever windows * n was not a power of two: 13 or 15 windows.)  Measured with tables (r02_chunk_rounds_ab.txt):
@@ -203,8 +205,21 @@ int msm_init_device(bp_ctx* ctx) {
 // Enqueues the whole pipeline and the device-to-host copy of the window sums on ctx->stream; waits for nothing.
 int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
                int slot, void* d_blob, MsmPending* out) {
+  return msm_launch_many(ctx, d_points28, 1, &d_scalars, &n, fmt, table_c, table_stride, slot, d_blob, out);
+}
+
+// J scalar vectors against the same points in one pipeline (J > 1: fixed-base tables only, results in the pinned slot only);
+// vector j has n_each[j] scalars.  msm_finish then delivers J results.
+int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, const fr_t* const* d_scalars_each, const size_t* n_each, int fmt,
+                    uint32_t table_c, size_t table_stride, int slot, void* d_blob, MsmPending* out) {
   *out = MsmPending();
   out->blob = d_blob != nullptr;
+  if (J < 1 || J > MSM_MAX_BATCH || (J > 1 && (!table_c || d_blob)))
+    return fail(ctx, BP_ERR_INVALID_ARG, "MSM batch", hipSuccess, __FILE__, __LINE__);
+  size_t n = 0;
+  for (uint32_t j = 0; j < J; j++) n = n_each[j] > n ? n_each[j] : n;
+  const fr_t* d_scalars = d_scalars_each[0];
+  out->J = J;
   if (n == 0) {
     if (d_blob) {
       MsmBlobHeader hdr;
@@ -218,11 +233,16 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   if (slot < 0 || slot >= MSM_SLOTS) return fail(ctx, BP_ERR_INVALID_ARG, "MSM result slot", hipSuccess, __FILE__, __LINE__);
   if (n >= (1ull << 31)) return fail(ctx, BP_ERR_TOO_LARGE, "MSM length >= 2^31", hipSuccess, __FILE__, __LINE__);
   MsmPlan plan;
-  make_plan(plan, n, table_c, table_stride);
-  if ((uint64_t)plan.W * n >= (1ull << 32))        // positions in the bucket-sorted list are 32-bit
+  make_plan(plan, n, table_c, table_stride, J);
+  MsmScalars scalars_all;
+  for (uint32_t j = 0; j < MSM_MAX_BATCH; j++) {
+    plan.nj[j] = j < J ? (uint32_t)n_each[j] : 0u;
+    scalars_all.p[j] = j < J ? d_scalars_each[j] : nullptr;
+  }
+  if ((uint64_t)plan.W * n * J >= (1ull << 32))        // positions in the bucket-sorted list are 32-bit
     return fail(ctx, BP_ERR_TOO_LARGE, "MSM length * windows >= 2^32", hipSuccess, __FILE__, __LINE__);
-  const uint32_t W = plan.W, B = plan.B, total = plan.total, Wr = table_c ? 1 : W;   // Wr: windows left after accumulation
-  const uint64_t max_entries = (uint64_t)W * n;
+  const uint32_t W = plan.W, B = plan.B, total = plan.total, Wr = table_c ? J : W;   // Wr: bucket sets left after accumulation
+  const uint64_t max_entries = (uint64_t)W * n * J;
   const uint64_t n_chunks = (max_entries + plan.chunk - 1) / plan.chunk;
   // bucket reduction: running sums per window (msm_reduce), or (tables: one bucket set) the bit-plane tree
   const uint32_t blocks_per_window = table_c ? 0 : ((B + plan.seg - 1) / plan.seg + 255) / 256;
@@ -279,9 +299,12 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   if (pb + MSM_HIST_LOG < kb) pb = kb - MSM_HIST_LOG;                   // a final run's buckets must fit one LDS histogram
   if (pb > kb) pb = kb;
   if (pb > 16) pb = 16;
+  if (pb > PART_MAX_BITS && (max_entries >> PART_MAX_BITS) <= 32768) pb = PART_MAX_BITS;     // final runs of up to 32 Ki entries are fine for one workgroup
+  if (pb + MSM_HIST_LOG < kb) pb = kb - MSM_HIST_LOG;
   const uint32_t sort_env = env_u32("BP_MSM_SORT", 2, 0, 2);
-  const bool hist_ok = plan.parts == 1 && !plan.naf;
-  const int sort_mode = (sort_env == 0 && hist_ok) ? 0 : ((sort_env == 1 || pb > PART_MAX_BITS) ? 1 : 2);
+  const bool hist_ok = plan.parts == 1 && !plan.naf && J == 1;
+  const int sort_mode = (sort_env == 0 && hist_ok) ? 0 : (((sort_env == 1 && J == 1) || pb > PART_MAX_BITS) ? 1 : 2);
+  if (sort_mode != 2 && J > 1) return fail(ctx, BP_ERR_TOO_LARGE, "MSM batch too long for the partition sort", hipSuccess, __FILE__, __LINE__);
   const uint32_t rbits = kb - pb, n_final = 1u << pb;
   const size_t rhist = ((size_t)1 << rbits) * 4;
   uint32_t* rlong_n = ctl + 2;
@@ -294,10 +317,10 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
     const uint32_t rec_bytes = packed ? 4 : 8;
     // scalars per workgroup: the staging area (slice * W records) within 64 KiB, and >= 512 workgroups where n allows
     uint32_t slice = 64;
-    while (slice < 1024 && (uint64_t)2 * slice * W * rec_bytes <= 65536 && (uint64_t)slice * 512 < n) slice <<= 1;
+    while (slice < 1024 && (uint64_t)2 * slice * W * rec_bytes <= 65536 && (uint64_t)slice * 512 < (uint64_t)n * J) slice <<= 1;
     slice = env_u32("BP_MSM_PART_SLICE", slice, 64, 4096);
     if (slice < 64 || slice > 4096 || (uint64_t)slice * W * rec_bytes > 98304) slice = 64;
-    const uint32_t cap = slice * W, n_slices = (uint32_t)((n + slice - 1) / slice);
+    const uint32_t cap = slice * W, n_slices = (uint32_t)(((uint64_t)n * J + slice - 1) / slice);
     const unsigned threads = slice >= 1024 ? 1024u : (slice <= 256 ? 256u : slice);
     uint32_t *recs = nullptr, *rvals = nullptr, *roff, *cur, *rlong_list;
     BP_TRY(ws_get(ctx, "msm.rkeys0", max_entries * 4, (void**)&recs));
@@ -305,9 +328,9 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
     BP_TRY(ws_get(ctx, "msm.run_off", ((size_t)3 * n_final + 16) * 4, (void**)&roff));
     BP_TRY(ws_get(ctx, "msm.run_cur", (size_t)n_final * 4, (void**)&cur));
     BP_TRY(ws_get(ctx, "msm.run_long", ((size_t)n_final + 2) * 4, (void**)&rlong_list));
-    hipLaunchKernelGGL(msm_part_count, dim3(n_slices), dim3(threads), 0, st, d_scalars, fmt, plan, slice, pb, rbits, ctl + 4, roff, cur, long_count + 1);
+    hipLaunchKernelGGL(msm_part_count, dim3(n_slices), dim3(threads), 0, st, scalars_all, fmt, plan, slice, pb, rbits, ctl + 4, roff, cur, long_count + 1);
     if (packed) {
-      hipLaunchKernelGGL(msm_part_scatter<true>, dim3(n_slices), dim3(threads), (size_t)cap * 4, st, d_scalars, fmt, plan, slice, pb, rbits, vb, cap, cur,
+      hipLaunchKernelGGL(msm_part_scatter<true>, dim3(n_slices), dim3(threads), (size_t)cap * 4, st, scalars_all, fmt, plan, slice, pb, rbits, vb, cap, cur,
                          recs, rvals);
       const RunRecords<true> rr{recs, nullptr, (1u << rbits) - 1u, vb};
       hipLaunchKernelGGL(msm_radix_final<true>, dim3(n_final < 4096 ? n_final : 4096), dim3(1024), rhist, st, rr, roff, n_final, rbits, total, offsets,
@@ -320,7 +343,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
         hipLaunchKernelGGL(msm_radix_long_scatter<true>, lgrid, dim3(1024), rhist, st, rr, roff, rbits, rlong_n, rlong_list, cursors, sorted);
       }
     } else {
-      hipLaunchKernelGGL(msm_part_scatter<false>, dim3(n_slices), dim3(threads), (size_t)cap * 8, st, d_scalars, fmt, plan, slice, pb, rbits, vb, cap, cur,
+      hipLaunchKernelGGL(msm_part_scatter<false>, dim3(n_slices), dim3(threads), (size_t)cap * 8, st, scalars_all, fmt, plan, slice, pb, rbits, vb, cap, cur,
                          recs, rvals);
       const RunRecords<false> rr{recs, rvals, (1u << rbits) - 1u, 0u};
       hipLaunchKernelGGL(msm_radix_final<false>, dim3(n_final < 4096 ? n_final : 4096), dim3(1024), rhist, st, rr, roff, n_final, rbits, total, offsets,
@@ -427,8 +450,8 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
     // A node of 2^k buckets carries k + 1 values; the two ping-pong buffers hold at most B values (level 1).
     const uint32_t levels = plan.c - 1;               // >= 1 (make_plan keeps c >= 2)
     const uint64_t wide_min = env_u32("BP_MSM_PLANES_WIDE_MIN", 40000, 256, 1u << 30);
-    uint32_t k = 0, nodes = B, n_wide = 0;
-    while (n_wide < levels && (uint64_t)(B >> (n_wide + 1)) * (n_wide + 1) >= wide_min) n_wide++;
+    uint32_t k = 0, nodes = total, n_wide = 0;            // total = J B leaves: a forest of J trees (J > 1: the vectors of a batch)
+    while (n_wide < levels && (uint64_t)(total >> (n_wide + 1)) * (n_wide + 1) >= wide_min) n_wide++;
     proj28_slot* tmp[2] = {nullptr, nullptr};
     {
       size_t need[2] = {0, 0};
@@ -437,7 +460,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
         const uint32_t m = kk < n_wide ? 1 : (levels - kk < PLANES_STEP_LOG ? levels - kk : PLANES_STEP_LOG);
         kk += m;
         if (kk < levels) {
-          const size_t slots = (size_t)(B >> kk) * (kk + 1);
+          const size_t slots = (size_t)(total >> kk) * (kk + 1);
           if (slots > need[flip]) need[flip] = slots;
         }
         flip ^= 1;
@@ -484,7 +507,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
     memset(&hdr, 0, sizeof hdr);
     hdr.magic = MSM_BLOB_MAGIC;
     hdr.c = plan.c;
-    hdr.Wr = Wr;
+    hdr.Wr = table_c ? 1 : Wr;
     hdr.n_planes = n_planes;
     hdr.tables = plan.naf ? 2u : (table_c != 0 ? 1u : 0u);
     hipLaunchKernelGGL(msm_write_blob, dim3(1), dim3(256), 0, st, window_sum, hdr, (uint8_t*)d_blob);
@@ -496,7 +519,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
   out->empty = false;
   out->tables = plan.naf ? 2u : (table_c != 0 ? 1u : 0u);
   out->c = plan.c;
-  out->Wr = Wr;
+  out->Wr = table_c ? 1 : Wr;
   out->n_planes = n_planes;
   out->adds = max_entries;      // upper bound (blob mode keeps it); msm_finish replaces it by the exact count of non-zero digits
   out->h_windows = h_windows;
@@ -507,7 +530,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
 // Montgomery limbs, then Horner (msm.rs:107-115).  The timing stats describe the last launched MSM of this ctx.
 int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out) {
   if (pend.empty) {
-    if (host_out) *host_out = g1_identity();
+    for (uint32_t j = 0; host_out && j < pend.J; j++) host_out[j] = g1_identity();
     ctx->msm_accumulate_ms = ctx->msm_total_ms = 0;
     ctx->msm_adds = 0;
     if (pend.blob) BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -530,8 +553,12 @@ int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out) {
   ctx->msm_adds = tail[1];             // entries of the bucket-sorted list = non-zero digits = bucket additions performed
   std::vector<g1_proj> windows(n_planes);
   for (uint32_t w = 0; w < n_planes; w++) windows[w] = slot_to_proj(&h_windows[w]);
-  if (pend.tables) host_plane_horner(*host_out, windows.data(), pend.Wr, pend.c, pend.tables == 2);
-  else host_horner(*host_out, windows.data(), pend.Wr, pend.c);
+  if (pend.tables) {
+    for (uint32_t j = 0; j < pend.J; j++)              // a batch: c values per vector, one Horner pass each
+      host_plane_horner(host_out[j], windows.data() + (size_t)j * pend.c, pend.Wr, pend.c, pend.tables == 2);
+  } else {
+    host_horner(*host_out, windows.data(), pend.Wr, pend.c);
+  }
   return BP_OK;
 }
 

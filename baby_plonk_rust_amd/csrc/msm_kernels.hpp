@@ -66,7 +66,15 @@ struct MsmPlan {
   // positions -- 256 / (naf + 1) bucket additions per scalar on average instead of 256 / c, with only 2^(naf-2) buckets
   // (bucket (|d| - 1) / 2).  Then c = naf - 1 (so that B = 2^(c-1) as everywhere), W = digit slots per scalar.
   uint32_t naf;        // 0, or the NAF width
+  // Several scalar vectors against ONE table set in one pipeline (the commitments of a prover round, prover.rs:249-251,
+  // 483-485, 640-641): vector j owns the buckets [j B, (j + 1) B), so the sort, the accumulation, the fix-up and the tree run
+  // once over J bucket sets and deliver J results.  n is then the longest vector; scalar (j, i) is element j * n + i of the
+  // pipeline's index space, elements with i >= nj[j] do not exist.  Partition sort only (msm_part_*); J = 1 everywhere else.
+  uint32_t J;          // 1 .. MSM_MAX_BATCH
+  uint32_t nj[4];      // length of vector j
 };
+constexpr uint32_t MSM_MAX_BATCH = 4;
+struct MsmScalars { const fr_t* p[MSM_MAX_BATCH]; };
 
 // ---------------------------------------------------------------- 1. digits
 // fmt 0: 32-byte little-endian canonical (Scalar::to_bytes), 1: Montgomery limbs (Scalar::to_array)
@@ -590,9 +598,8 @@ constexpr uint32_t PART_MAX_BITS = 11, PART_MAX = 1u << PART_MAX_BITS;
 // every (bucket id, entry | sign << 31) of scalar i, in window (or NAF slot) order.  status != null: canonical-bytes inputs are
 // range-checked (Scalar::from_bytes rejects values >= q, scalar.rs:264-288)
 template <class F>
-__device__ __forceinline__ void msm_scalar_entries(const fr_t* __restrict__ scalars, uint32_t i, int fmt, const MsmPlan& plan,
+__device__ __forceinline__ void msm_scalar_entries(fr_t k, uint32_t i, uint32_t bucket_base, int fmt, const MsmPlan& plan,
                                                    uint32_t* __restrict__ status, F&& emit) {
-  fr_t k = scalars[i];
   if (fmt == 1) {
     Fr::from_mont(k, k);                           // msm.rs:126: scalar.to_bytes() = canonical integer
   } else if (status) {
@@ -630,7 +637,7 @@ __device__ __forceinline__ void msm_scalar_entries(const fr_t* __restrict__ scal
       const bool neg = e >= half;
       const uint32_t mag = neg ? (1u << w) - e : e;
       carry = neg ? 1u : 0u;
-      emit((mag - 1) >> 1, (i + p * plan.wpoints) | (neg ? 0x80000000u : 0u));
+      emit(bucket_base + ((mag - 1) >> 1), (i + p * plan.wpoints) | (neg ? 0x80000000u : 0u));
       slot++;
       pos = p + w;
     }
@@ -650,13 +657,32 @@ __device__ __forceinline__ void msm_scalar_entries(const fr_t* __restrict__ scal
     const uint32_t o = c * w, word = o >> 5, sh = o & 31;
     const uint64_t two = (uint64_t)kp[word] | ((uint64_t)kp[word + 1] << 32);
     const int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (w + 1 < plan.W ? (int32_t)half : 0);
-    if (d != 0) emit(w * plan.wbuckets + digit_bucket(d), (i + w * plan.wpoints) | (d < 0 ? 0x80000000u : 0u));
+    if (d != 0) emit(bucket_base + w * plan.wbuckets + digit_bucket(d), (i + w * plan.wpoints) | (d < 0 ? 0x80000000u : 0u));
+  }
+}
+
+// the entries of the scalars [lo, hi) of the pipeline's index space (element x = vector x / n, position x % n)
+template <class F>
+__device__ __forceinline__ void msm_slice_entries(const MsmScalars& sc, uint64_t lo, uint64_t hi, int fmt, const MsmPlan& plan,
+                                                  uint32_t* __restrict__ status, F&& emit) {
+  for (uint64_t x = lo + threadIdx.x; x < hi; x += blockDim.x) {
+    uint32_t j = 0, i = (uint32_t)x;
+    if (plan.J > 1) {
+      j = (uint32_t)(x / plan.n);
+      i = (uint32_t)(x - (uint64_t)j * plan.n);
+    }
+    if (i >= plan.nj[j]) continue;
+    const fr_t* __restrict__ src = sc.p[0];
+    if (j == 1) src = sc.p[1];
+    if (j == 2) src = sc.p[2];
+    if (j == 3) src = sc.p[3];
+    msm_scalar_entries(src[i], i, j * plan.B, fmt, plan, status, emit);
   }
 }
 
 // ctl: [0] ticket of finished workgroups, [1 .. 2^pb] partition sizes (zero before the launch).  slice: scalars per workgroup.
 // run_off[0 .. 2^pb] and cursor[0 .. 2^pb) are written by the workgroup that takes the last ticket.
-__global__ void __launch_bounds__(1024) msm_part_count(const fr_t* __restrict__ scalars, int fmt, MsmPlan plan, uint32_t slice, uint32_t pb,
+__global__ void __launch_bounds__(1024) msm_part_count(MsmScalars scalars, int fmt, MsmPlan plan, uint32_t slice, uint32_t pb,
                                                        uint32_t rbits, uint32_t* __restrict__ ctl, uint32_t* __restrict__ run_off,
                                                        uint32_t* __restrict__ cursor, uint32_t* __restrict__ status) {
   __shared__ uint32_t h[PART_MAX], scan16[16], carry_s, last_s;
@@ -664,10 +690,8 @@ __global__ void __launch_bounds__(1024) msm_part_count(const fr_t* __restrict__ 
   uint32_t* cnt = ctl + 1;
   for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) h[p] = 0;
   __syncthreads();
-  const uint64_t lo64 = (uint64_t)blockIdx.x * slice;
-  const uint32_t lo = (uint32_t)lo64, hi = lo64 + slice < plan.n ? lo + slice : plan.n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
-    msm_scalar_entries(scalars, i, fmt, plan, status, [&](uint32_t bucket, uint32_t) { atomicAdd(&h[bucket >> rbits], 1u); });
+  const uint64_t all = (uint64_t)plan.J * plan.n, lo = (uint64_t)blockIdx.x * slice, hi = lo + slice < all ? lo + slice : all;
+  msm_slice_entries(scalars, lo, hi, fmt, plan, status, [&](uint32_t bucket, uint32_t) { atomicAdd(&h[bucket >> rbits], 1u); });
   __syncthreads();
   for (uint32_t p = threadIdx.x; p < P; p += blockDim.x)
     if (h[p]) atomicAdd(&cnt[p], h[p]);
@@ -699,7 +723,7 @@ __global__ void __launch_bounds__(1024) msm_part_count(const fr_t* __restrict__ 
 
 extern __shared__ uint32_t msm_part_lds[];        // PACKED: records[cap]; else keys[cap] | vals[cap]   (cap = slice * W)
 template <bool PACKED>
-__global__ void __launch_bounds__(1024) msm_part_scatter(const fr_t* __restrict__ scalars, int fmt, MsmPlan plan, uint32_t slice, uint32_t pb,
+__global__ void __launch_bounds__(1024) msm_part_scatter(MsmScalars scalars, int fmt, MsmPlan plan, uint32_t slice, uint32_t pb,
                                                          uint32_t rbits, uint32_t vb, uint32_t cap, uint32_t* __restrict__ cursor,
                                                          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
   __shared__ uint32_t h[PART_MAX], lbase[PART_MAX], gbase[PART_MAX], scan16[16], carry_s;
@@ -709,10 +733,8 @@ __global__ void __launch_bounds__(1024) msm_part_scatter(const fr_t* __restrict_
   for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) h[p] = 0;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  const uint64_t lo64 = (uint64_t)blockIdx.x * slice;
-  const uint32_t lo = (uint32_t)lo64, hi = lo64 + slice < plan.n ? lo + slice : plan.n;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
-    msm_scalar_entries(scalars, i, fmt, plan, nullptr, [&](uint32_t bucket, uint32_t) { atomicAdd(&h[bucket >> rbits], 1u); });
+  const uint64_t all = (uint64_t)plan.J * plan.n, lo = (uint64_t)blockIdx.x * slice, hi = lo + slice < all ? lo + slice : all;
+  msm_slice_entries(scalars, lo, hi, fmt, plan, nullptr, [&](uint32_t bucket, uint32_t) { atomicAdd(&h[bucket >> rbits], 1u); });
   __syncthreads();
   // this slice's share of every partition: place in the staging area (lbase) and in the partition's final run (gbase)
   for (uint32_t p0 = 0; p0 < P; p0 += blockDim.x) {
@@ -728,16 +750,15 @@ __global__ void __launch_bounds__(1024) msm_part_scatter(const fr_t* __restrict_
     if (threadIdx.x == blockDim.x - 1) carry_s = ex + v;
     __syncthreads();
   }
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
-    msm_scalar_entries(scalars, i, fmt, plan, nullptr, [&](uint32_t bucket, uint32_t val) {
-      const uint32_t part = bucket >> rbits, pos = lbase[part] + atomicAdd(&h[part], 1u);
-      if (PACKED) {
-        st_key[pos] = ((bucket & rmask) << vb) | ((val >> 31) << (vb - 1)) | (val & 0x7fffffffu);
-      } else {
-        st_key[pos] = bucket;
-        st_val[pos] = val;
-      }
-    });
+  msm_slice_entries(scalars, lo, hi, fmt, plan, nullptr, [&](uint32_t bucket, uint32_t val) {
+    const uint32_t part = bucket >> rbits, pos = lbase[part] + atomicAdd(&h[part], 1u);
+    if (PACKED) {
+      st_key[pos] = ((bucket & rmask) << vb) | ((val >> 31) << (vb - 1)) | (val & 0x7fffffffu);
+    } else {
+      st_key[pos] = bucket;
+      st_val[pos] = val;
+    }
+  });
   __syncthreads();
   // partition-major write-out: 16 lanes per partition, four partitions per wave at a time
   const uint32_t sub = threadIdx.x >> 4, l16 = threadIdx.x & 15, n_sub = blockDim.x >> 4;
