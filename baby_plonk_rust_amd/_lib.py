@@ -58,6 +58,8 @@ SIGNATURES = {
     "bp_msm_g1": (_int, [_vp, _u64, _vp, _sz, _int, _vp]),
     "bp_msm_g1_partial": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),
     "bp_msm_g1_blob_device": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),
+    "bp_msm_g1_blob_device_async": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),
+    "bp_msm_blobs_sum_device_async": (_int, [_vp, _vp, _sz, _vp]),
     "bp_msm_blobs_sum_device": (_int, [_vp, _vp, _sz, _vp]),
     "bp_msm_blobs_combine": (_int, [_vp, _sz, _vp]),
     "bp_g1_sum_partials": (_int, [_vp, _sz, _vp]),

@@ -173,18 +173,21 @@ class Context:
         self.check(rc, "bp_msm_g1_partial")
         return bytes(out)
 
-    def msm_blob_device(self, handle, d_blob_ptr, scalars=None, first=0, fmt=FR_MONT, device_ptr=None, n=None):
-        """one process per GPU: this rank's partial sums stay in HBM at d_blob_ptr (MSM_BLOB_BYTES), ready for the all-gather"""
+    def msm_blob_device(self, handle, d_blob_ptr, scalars=None, first=0, fmt=FR_MONT, device_ptr=None, n=None, wait=True):
+        """one process per GPU: this rank's partial sums stay in HBM at d_blob_ptr (MSM_BLOB_BYTES), ready for the all-gather.
+        wait=False: stream-ordered (bp_msm_g1_blob_device_async): enqueued on the context's stream (set_stream), not waited for"""
+        fn = self._lib.bp_msm_g1_blob_device if wait else self._lib.bp_msm_g1_blob_device_async
         if device_ptr is not None:
-            rc = self._lib.bp_msm_g1_blob_device(self._h, handle, first, device_ptr, n, fmt, 1, d_blob_ptr)
+            rc = fn(self._h, handle, first, device_ptr, n, fmt, 1, d_blob_ptr)
         else:
             s = _fr_array(scalars) if fmt == FR_MONT else np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
-            rc = self._lib.bp_msm_g1_blob_device(self._h, handle, first, s.ctypes.data, len(s), fmt, 0, d_blob_ptr)
-        self.check(rc, "bp_msm_g1_blob_device")
+            rc = fn(self._h, handle, first, s.ctypes.data, len(s), fmt, 0, d_blob_ptr)
+        self.check(rc, "bp_msm_g1_blob_device" if wait else "bp_msm_g1_blob_device_async")
 
-    def msm_blobs_sum_device(self, d_blobs_ptr, n_blobs, d_out_ptr):
+    def msm_blobs_sum_device(self, d_blobs_ptr, n_blobs, d_out_ptr, wait=True):
         """gathered records of equal layout -> one record, added slot by slot on the GPU (see bp_msm_blobs_sum_device)"""
-        self.check(self._lib.bp_msm_blobs_sum_device(self._h, d_blobs_ptr, n_blobs, d_out_ptr), "bp_msm_blobs_sum_device")
+        fn = self._lib.bp_msm_blobs_sum_device if wait else self._lib.bp_msm_blobs_sum_device_async
+        self.check(fn(self._h, d_blobs_ptr, n_blobs, d_out_ptr), "bp_msm_blobs_sum_device")
 
     def msm_stats(self):
         a, t, adds, c = C.c_float(), C.c_float(), C.c_uint64(), C.c_uint32()

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -27,12 +28,26 @@ int fail(bp_ctx* ctx, int code, const char* what, hipError_t e, const char* file
   return code;
 }
 
+hipError_t stream_wait(hipStream_t st) {
+  static const bool block = [] { const char* v = getenv("BP_WAIT_BLOCK"); return v && *v == '1'; }();
+  if (!block) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+      const hipError_t e = hipStreamQuery(st);
+      if (e != hipErrorNotReady) return e;
+      __builtin_ia32_pause();
+      if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(6)) break;
+    }
+  }
+  return hipStreamSynchronize(st);
+}
+
 int ws_get(bp_ctx* ctx, const char* name, size_t bytes, void** out) {
   DevBuf& b = ctx->ws[name];
   if (bytes == 0) bytes = 16;
   if (b.cap < bytes) {
     if (b.p) {
-      BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      BP_HIP(ctx, stream_wait(ctx->stream));
       BP_HIP(ctx, hipFree(b.p));
       b.p = nullptr;
       b.cap = 0;
@@ -169,7 +184,7 @@ static int download_fr(bp_ctx* ctx, fr_t* d, void* host, size_t n, int fmt) {
   if (n == 0) return BP_OK;
   if (fmt == BP_FR_BYTES_LE) BP_TRY(fr_convert_run(ctx, d, n, 1));
   BP_HIP(ctx, hipMemcpyAsync(host, d, n * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   return BP_OK;
 }
 
@@ -290,7 +305,7 @@ static int ctx_create(bp_ctx** out, int device_id) {
     bp_destroy(ctx);
     return rc;
   }
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+  if (stream_wait(ctx->stream) != hipSuccess) {
     bp_destroy(ctx);
     return BP_ERR_HIP;
   }
@@ -360,7 +375,7 @@ void bp_destroy(bp_ctx* ctx) {
   for (bp_ctx* lane : ctx->lanes) bp_destroy(lane);
   ctx->lanes.clear();
   DeviceGuard guard(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream) (void)stream_wait(ctx->stream);
   for (auto& kv : ctx->ws)
     if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->srs) {
@@ -392,7 +407,7 @@ const char* bp_last_error(bp_ctx* ctx) { return ctx ? ctx->last_error.c_str() : 
 int bp_set_stream(bp_ctx* ctx, void* hip_stream) {
   if (!ctx) return BP_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   if (hip_stream == nullptr) {
     if (!ctx->own_stream) {
       BP_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -410,7 +425,7 @@ int bp_synchronize(bp_ctx* ctx) {
   if (!ctx) return BP_ERR_INVALID_ARG;
   for (bp_ctx* m : shards_of(ctx)) {
     DeviceGuard guard(m->device);
-    BP_HIP(ctx, hipStreamSynchronize(m->stream));
+    BP_HIP(ctx, stream_wait(m->stream));
   }
   return BP_OK;
 }
@@ -424,7 +439,7 @@ static int srs_register(bp_ctx* ctx, g1_affine* d, size_t n, size_t first, size_
   e.first = first;
   e.n_global = n_global;
   int rc = srs_to28_run(ctx, d, n, &e.d_points28);
-  if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "srs_to28", hipGetLastError(), __FILE__, __LINE__);
+  if (rc == BP_OK && stream_wait(ctx->stream) != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "srs_to28", hipGetLastError(), __FILE__, __LINE__);
   if (rc != BP_OK) {
     (void)hipFree(d);
     if (e.d_points28) (void)hipFree(e.d_points28);
@@ -447,7 +462,7 @@ static int srs_free_one(bp_ctx* ctx, uint64_t handle) {
   SrsEntry* e;
   BP_TRY(srs_find(ctx, handle, &e));
   DeviceGuard guard(ctx->device);
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   BP_HIP(ctx, hipFree(e->d_points));
   BP_HIP(ctx, hipFree(e->d_points28));
   if (e->d_table) BP_HIP(ctx, hipFree(e->d_table));
@@ -476,7 +491,7 @@ static int srs_make_one(bp_ctx* ctx, int kind, const uint8_t* src, const fr_t& a
     rc = srs_generate_run(ctx, a, d, kind == 2 ? 0 : 1, first, n, d_pts);
   }
   if (rc == BP_OK) {
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = stream_wait(ctx->stream);
     if (e != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "SRS build", e, __FILE__, __LINE__);
   }
   if (rc != BP_OK) {
@@ -555,7 +570,7 @@ int bp_srs_export(bp_ctx* ctx, uint64_t srs_handle, size_t first, size_t n, uint
     BP_TRY(lift(ctx, m, ws_get(m, "io.bytes", (hi - lo) * 96, (void**)&d_bytes)));
     BP_TRY(lift(ctx, m, srs_encode_run(m, e->d_points + (lo - e->first), hi - lo, d_bytes)));
     BP_HIP(ctx, hipMemcpyAsync(points96 + (lo - first) * 96, d_bytes, (hi - lo) * 96, hipMemcpyDeviceToHost, m->stream));
-    BP_HIP(ctx, hipStreamSynchronize(m->stream));
+    BP_HIP(ctx, stream_wait(m->stream));
   }
   return BP_OK;
 }
@@ -576,7 +591,7 @@ int bp_srs_export_projective144(bp_ctx* ctx, uint64_t srs_handle, size_t first, 
     DeviceGuard guard(m->device);
     std::vector<g1_affine> aff(hi - lo);
     BP_HIP(ctx, hipMemcpyAsync(aff.data(), e->d_points + (lo - e->first), (hi - lo) * sizeof(g1_affine), hipMemcpyDeviceToHost, m->stream));
-    BP_HIP(ctx, hipStreamSynchronize(m->stream));
+    BP_HIP(ctx, stream_wait(m->stream));
     for (size_t i = 0; i < hi - lo; i++) {                   // G1Projective::from(&G1Affine) (g1.rs:176-190): z = 1, or 0 for the identity
       g1_proj p;
       p.x = aff[i].x;
@@ -607,7 +622,7 @@ static int srs_precompute_one(bp_ctx* ctx, uint64_t handle, uint32_t c) {
   SrsEntry* e;
   BP_TRY(srs_find(ctx, handle, &e));
   DeviceGuard guard(ctx->device);
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   if (e->d_table) {
     BP_HIP(ctx, hipFree(e->d_table));
     e->d_table = nullptr;
@@ -1016,10 +1031,35 @@ int bp_msm_g1_blob_device(bp_ctx* ctx, uint64_t srs_handle, size_t first, const 
   return msm_finish(ctx, pend, nullptr);
 }
 
+int bp_msm_g1_blob_device_async(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
+                                int scalars_on_device, void* d_blob) {
+  if (!ctx || !d_blob || !fmt_ok(scalar_fmt) || (n_scalars && !scalars)) return BP_ERR_INVALID_ARG;
+  if (is_group(ctx)) return fail(ctx, BP_ERR_INVALID_ARG, "blob records are the one-process-per-GPU exchange; a bp_init_multi context combines its shards itself", hipSuccess, __FILE__, __LINE__);
+  SrsEntry* e;
+  BP_TRY(srs_find(ctx, srs_handle, &e));
+  if (first > e->n) return fail(ctx, BP_ERR_INVALID_ARG, "SRS offset out of bounds", hipSuccess, __FILE__, __LINE__);
+  const size_t n = std::min(n_scalars, e->n - first);
+  DeviceGuard guard(ctx->device);
+  MsmPending pend;
+  BP_TRY(msm_shard_launch(ctx, e, first, scalars, n, scalar_fmt, scalars_on_device ? 1 : 0, ctx->device, nullptr, 0, d_blob, &pend));
+  // nothing is waited for: the stats of this MSM are read from its events by bp_msm_last_stats once the stream has passed them
+  ctx->msm_async_pending = !pend.empty;
+  ctx->msm_c = pend.tables == 2 ? (MSM_NAF_FLAG | (pend.c + 1)) : pend.c;
+  ctx->msm_tables = pend.tables != 0;
+  ctx->msm_adds = pend.adds;
+  if (pend.empty) ctx->msm_accumulate_ms = ctx->msm_total_ms = 0;
+  return BP_OK;
+}
+
 int bp_msm_blobs_sum_device(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out_blob) {
   if (!ctx || !d_blobs || !d_out_blob || n_blobs == 0 || n_blobs > 4096) return BP_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
   return msm_blobs_sum_device_run(ctx, d_blobs, n_blobs, d_out_blob);
+}
+int bp_msm_blobs_sum_device_async(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out_blob) {
+  if (!ctx || !d_blobs || !d_out_blob || n_blobs == 0 || n_blobs > 4096) return BP_ERR_INVALID_ARG;
+  DeviceGuard guard(ctx->device);
+  return msm_blobs_sum_device_run(ctx, d_blobs, n_blobs, d_out_blob, false);
 }
 
 int bp_msm_blobs_combine(const void* blobs, size_t n_blobs, uint8_t out96[96]) {
@@ -1071,6 +1111,18 @@ int bp_msm_last_member_stats(bp_ctx* ctx, int member, float* upload_ms, float* a
 int bp_msm_last_used_tables(bp_ctx* ctx) { return ctx ? (ctx->msm_tables ? 1 : 0) : BP_ERR_INVALID_ARG; }
 int bp_msm_last_stats(bp_ctx* ctx, float* accumulate_ms, float* total_device_ms, uint64_t* mixed_adds, uint32_t* window_bits) {
   if (!ctx) return BP_ERR_INVALID_ARG;
+  if (ctx->msm_async_pending) {        // the last MSM was only enqueued: its events are read now (0 while it is still running)
+    DeviceGuard guard(ctx->device);
+    float a = 0, t = 0;
+    if (hipEventElapsedTime(&a, ctx->ev[1], ctx->ev[2]) == hipSuccess && hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[3]) == hipSuccess) {
+      ctx->msm_accumulate_ms = a;
+      ctx->msm_total_ms = t;
+      ctx->msm_async_pending = false;
+    } else {
+      (void)hipGetLastError();
+      ctx->msm_accumulate_ms = ctx->msm_total_ms = 0;
+    }
+  }
   if (accumulate_ms) *accumulate_ms = ctx->msm_accumulate_ms;
   if (total_device_ms) *total_device_ms = ctx->msm_total_ms;
   if (mixed_adds) *mixed_adds = ctx->msm_adds;
@@ -1087,7 +1139,7 @@ int bp_ntt_fr_device(bp_ctx* ctx, void* d_data, uint32_t log_n, int inverse, siz
   }
   DeviceGuard guard(ctx->device);
   BP_TRY(ntt_run(ctx, (fr_t*)d_data, log_n, inverse, batch, stride));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   BP_HIP(ctx, hipEventElapsedTime(&ctx->ntt_ms, ctx->ev[0], ctx->ev[1]));
   ctx->ntt_async_pending = false;
   return BP_OK;
@@ -1140,7 +1192,7 @@ static int ntt_columns_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, 
   for (size_t r = 0; r < R; r++) {                       // wait for every member, also after a failure elsewhere
     if (cnt[r] == 0) continue;
     DeviceGuard guard(sh[r]->device);
-    hipError_t e = hipStreamSynchronize(sh[r]->stream);
+    hipError_t e = stream_wait(sh[r]->stream);
     if (e != hipSuccess && rc == BP_OK) rc = fail(ctx, BP_ERR_HIP, "NTT columns", e, __FILE__, __LINE__);
     float t = 0;
     if (rc == BP_OK && hipEventElapsedTime(&t, sh[r]->ev[0], sh[r]->ev[1]) == hipSuccess) ms = std::max(ms, t);
@@ -1193,7 +1245,7 @@ static int ntt_one_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, int 
     if (scalar_fmt == BP_FR_BYTES_LE) BP_TRY(fr_convert_run(m, dbuf[g], N, 0));      // other columns: unused memory, converted and ignored
     BP_TRY(ntt_run_part(m, dbuf[g], log_n, inverse, 1, N, 0, g, R));
     BP_HIP(m, hipEventRecord(m->ev[4], m->stream));               // pass 1 of this member is behind this event: the exchange waits for it
-    BP_HIP(m, hipStreamSynchronize(m->stream));
+    BP_HIP(m, stream_wait(m->stream));
     return BP_OK;
   });
   if (rc != BP_OK) return rc;
@@ -1213,7 +1265,7 @@ static int ntt_one_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, int 
   }
   for (uint32_t g = 0; g < R; g++) {                           // every member, also after a failure elsewhere
     DeviceGuard guard(sh[g]->device);
-    hipError_t e = hipStreamSynchronize(sh[g]->stream);
+    hipError_t e = stream_wait(sh[g]->stream);
     if (e != hipSuccess && rc == BP_OK) rc = fail(ctx, BP_ERR_HIP, "NTT over the members", e, __FILE__, __LINE__);
   }
   if (rc != BP_OK) return rc;
@@ -1222,7 +1274,7 @@ static int ntt_one_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, int 
     DeviceGuard guard(m->device);
     hipError_t e = hipMemcpy2DAsync(data + g * rows * esz, L1 * esz, dbuf[g] + g * rows, L1 * esz, rows * esz, S, hipMemcpyDeviceToHost, m->stream);
     if (e != hipSuccess) return fail(m, BP_ERR_HIP, "NTT output download", e, __FILE__, __LINE__);
-    BP_HIP(m, hipStreamSynchronize(m->stream));
+    BP_HIP(m, stream_wait(m->stream));
     return BP_OK;
   });
   if (rc != BP_OK) return rc;
@@ -1322,7 +1374,7 @@ int bp_fr_synthetic_device(bp_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
   if (!ctx || (n && !d_out)) return BP_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
   BP_TRY(fr_synthetic_run(ctx, (fr_t*)d_out, n, seed));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   return BP_OK;
 }
 
@@ -1458,7 +1510,7 @@ static int poly_addsub_device(bp_ctx* ctx, const void* a, size_t na, const void*
   if (!out) return BP_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
   BP_TRY(fr_binary_run(ctx, (const fr_t*)a, na, (const fr_t*)b, nb, (fr_t*)out, n, op));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   return BP_OK;
 }
 int bp_poly_add_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b, size_t nb, int basis, void* d_out, size_t* n_out) {
@@ -1483,7 +1535,7 @@ int bp_poly_scalar_op_device(bp_ctx* ctx, const void* d_a, size_t n, int basis, 
   } else {
     BP_TRY(fr_scalar_run(ctx, a, s, out, n, 0));
   }
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   return BP_OK;
 }
 int bp_poly_mul_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b, size_t nb, int basis, void* d_out, size_t* n_out) {
@@ -1505,7 +1557,7 @@ int bp_poly_mul_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b,
   BP_TRY(fr_binary_run(ctx, d, N, d + N, N, d, N, 2));
   BP_TRY(ntt_run(ctx, d, k, 1, 1, N));
   BP_HIP(ctx, hipMemcpyAsync(d_out, d, target * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   *n_out = target;
   return BP_OK;
 }
@@ -1525,7 +1577,7 @@ int bp_poly_div_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b,
   fr_t ends[2];
   BP_HIP(ctx, hipMemcpyAsync(&ends[0], d_b, sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
   BP_HIP(ctx, hipMemcpyAsync(&ends[1], (const fr_t*)d_b + (nb_eff - 1), sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   const size_t nq = na_eff - nb_eff + 1;
   fr_t *work, *q;
   BP_TRY(ws_get(ctx, "io.poly_div_work", na_eff * sizeof(fr_t), (void**)&work));       // the general path clobbers its dividend
@@ -1537,14 +1589,14 @@ int bp_poly_div_device(bp_ctx* ctx, const void* d_a, size_t na, const void* d_b,
   BP_TRY(fr_nonzero_stats_run(ctx, q, nq, 0, nq, &q_eff, &q_nonzero));
   if (q_nonzero == nq) {
     BP_HIP(ctx, hipMemcpyAsync(d_out, q, nq * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
-    BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    BP_HIP(ctx, stream_wait(ctx->stream));
     *n_out = nq;
     return BP_OK;
   }
   size_t m = nq;
   BP_TRY(fr_compact_nonzero_run(ctx, q, &m));
   if (m) BP_HIP(ctx, hipMemcpyAsync(d_out, q, m * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   *n_out = m;
   return BP_OK;
 }
@@ -1564,7 +1616,7 @@ int bp_poly_scale_powers_device(bp_ctx* ctx, const void* d_a, size_t n, const vo
   memcpy(&w, w32_mont, 32);
   DeviceGuard guard(ctx->device);
   BP_TRY(fr_scale_powers_run(ctx, (const fr_t*)d_a, n, w, (fr_t*)d_out));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   return BP_OK;
 }
 int bp_roots_of_unity_device(bp_ctx* ctx, uint64_t group_order, void* d_out) {
@@ -1574,7 +1626,7 @@ int bp_roots_of_unity_device(bp_ctx* ctx, uint64_t group_order, void* d_out) {
   if (group_order > ((uint64_t)1 << 28)) return fail(ctx, BP_ERR_TOO_LARGE, "group_order > 2^28", hipSuccess, __FILE__, __LINE__);
   DeviceGuard guard(ctx->device);
   BP_TRY(roots_run(ctx, w, group_order, (fr_t*)d_out));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   return BP_OK;
 }
 int bp_grand_product_device(bp_ctx* ctx, const void* a, const void* b, const void* c, const void* s1, const void* s2, const void* s3, size_t n,
@@ -1588,7 +1640,7 @@ int bp_grand_product_device(bp_ctx* ctx, const void* a, const void* b, const voi
   DeviceGuard guard(ctx->device);
   BP_TRY(grand_product_run(ctx, (const fr_t*)a, (const fr_t*)b, (const fr_t*)c, (const fr_t*)s1, (const fr_t*)s2, (const fr_t*)s3, n, beta, gamma,
                            k1, k2, root, (fr_t*)d_z));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   return BP_OK;
 }
 int bp_commit_device(bp_ctx* ctx, uint64_t srs_handle, const void* d_coeffs, size_t n, int basis, uint8_t out96[96]) {
@@ -1681,7 +1733,7 @@ int bp_circuit_free(bp_ctx* ctx, uint64_t handle) {
   auto it = ctx->circuits.find(handle);
   if (it == ctx->circuits.end()) return fail(ctx, BP_ERR_INVALID_ARG, "unknown circuit handle", hipSuccess, __FILE__, __LINE__);
   DeviceGuard guard(ctx->device);
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   circuit_release(it->second);
   ctx->circuits.erase(it);
   return BP_OK;

@@ -96,6 +96,7 @@ struct bp_ctx {
   uint32_t msm_c = 0;
   bool msm_tables = false;
   float prove_ms[6] = {0, 0, 0, 0, 0, 0};            // host wall clock of rounds 1..5 and of the whole bp_prove
+  bool msm_async_pending = false;  // bp_msm_g1_blob_device_async enqueued an MSM whose events have not been read yet
   float ntt_ms = 0;
   bool ntt_async_pending = false;  // bp_ntt_fr_device_async enqueued a transform whose events have not been read yet
   uint32_t ntt_passes = 0;
@@ -136,6 +137,11 @@ inline bool is_group(const bp_ctx* ctx) { return ctx->members.size() > 1; }
     if (rc__ != BP_OK) return rc__; \
   } while (0)
 
+// Wait for a stream.  A thread blocked in hipStreamSynchronize wakes up tens of microseconds after the GPU has finished; the
+// calls of this library are a few milliseconds long and wait several times each (nine commitments and ~30 small results per
+// proof), so the wait polls hipStreamQuery for the first few milliseconds and only then blocks.  BP_WAIT_BLOCK=1: always block.
+hipError_t stream_wait(hipStream_t st);
+
 // device workspace `name` of at least `bytes` (contents undefined after growth)
 int ws_get(bp_ctx* ctx, const char* name, size_t bytes, void** out);
 int pinned_get(bp_ctx* ctx, size_t bytes, void** out);
@@ -159,7 +165,7 @@ int msm_launch(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t*
 int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, const fr_t* const* d_scalars_each, const size_t* n_each, int fmt,
                     uint32_t table_c, size_t table_stride, int slot, void* d_blob, MsmPending* out);
 int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out);
-int msm_blobs_sum_device_run(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out);
+int msm_blobs_sum_device_run(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out, bool wait = true);
 int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out);
 int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
             g1_proj* host_out);

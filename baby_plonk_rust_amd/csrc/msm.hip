@@ -165,7 +165,7 @@ int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_
     hipLaunchKernelGGL(srs_window_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_points, n, (c & MSM_NAF_FLAG) ? 1u : c, W, t);
   }
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = stream_wait(ctx->stream);
   if (e != hipSuccess) {
     (void)hipFree(t);
     return fail(ctx, BP_ERR_HIP, "srs_window_tables", e, __FILE__, __LINE__);
@@ -529,14 +529,15 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
 // waits for the stream, checks the scalar status and runs the host epilogue: window sums / planes back to the reference's
 // Montgomery limbs, then Horner (msm.rs:107-115).  The timing stats describe the last launched MSM of this ctx.
 int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out) {
+  ctx->msm_async_pending = false;
   if (pend.empty) {
     for (uint32_t j = 0; host_out && j < pend.J; j++) host_out[j] = g1_identity();
     ctx->msm_accumulate_ms = ctx->msm_total_ms = 0;
     ctx->msm_adds = 0;
-    if (pend.blob) BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (pend.blob) BP_HIP(ctx, stream_wait(ctx->stream));
     return BP_OK;
   }
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   BP_HIP(ctx, hipEventElapsedTime(&ctx->msm_accumulate_ms, ctx->ev[1], ctx->ev[2]));
   BP_HIP(ctx, hipEventElapsedTime(&ctx->msm_total_ms, ctx->ev[0], ctx->ev[3]));
   ctx->msm_c = pend.tables == 2 ? (MSM_NAF_FLAG | (pend.c + 1)) : pend.c;       // as given to bp_srs_precompute
@@ -606,11 +607,11 @@ int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out) {
   return BP_OK;
 }
 
-int msm_blobs_sum_device_run(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out) {
+int msm_blobs_sum_device_run(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out, bool wait) {
   hipLaunchKernelGGL(msm_blob_sum, dim3((MSM_MAX_WINDOWS + 7) / 8), dim3(64), 0, ctx->stream, (const uint8_t*)d_blobs, (uint32_t)n_blobs,
                      (uint32_t)BP_MSM_BLOB_BYTES, (uint8_t*)d_out);
   BP_HIP(ctx, hipGetLastError());
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (wait) BP_HIP(ctx, stream_wait(ctx->stream));
   return BP_OK;
 }
 

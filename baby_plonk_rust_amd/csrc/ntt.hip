@@ -104,7 +104,7 @@ static int get_tables(bp_ctx* ctx, uint32_t k, int inverse, NttTables** out) {
     fr_invert(n_inv, n_m);
     BP_HIP(ctx, hipMalloc((void**)&t.n_inv, sizeof(fr_t)));
     BP_HIP(ctx, hipMemcpyAsync(t.n_inv, &n_inv, sizeof(fr_t), hipMemcpyHostToDevice, ctx->stream));
-    BP_HIP(ctx, hipStreamSynchronize(ctx->stream));    // n_inv lives on this stack frame
+    BP_HIP(ctx, stream_wait(ctx->stream));    // n_inv lives on this stack frame
     BP_HIP(ctx, hipMalloc((void**)&t.hi_scaled, (size_t)nhi * sizeof(tw29_t)));
     BP_TRY(make_table(ctx, w, nhi, t.h, t.n_inv, nullptr, t.hi_scaled));
     BP_HIP(ctx, hipMalloc((void**)&t.n_inv_tw, sizeof(tw29_t)));
@@ -182,7 +182,7 @@ int ntt_run_part(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batc
       const size_t lds = tile_lds(l, cl);
       const tw29_t* hi = (inverse && i == 0) ? tab->hi_scaled : tab->hi;   // N^-1 rides on the first twiddle
       if (tab->full[i] && tab->full_ls[i] != ((l << 8) | s)) {
-        BP_HIP(ctx, hipStreamSynchronize(st));
+        BP_HIP(ctx, stream_wait(st));
         BP_HIP(ctx, hipFree(tab->full[i]));
         tab->full[i] = nullptr;
       }

@@ -26,7 +26,7 @@ int poly_eval_run(bp_ctx* ctx, const fr_t* d_coeffs, size_t n, const fr_t& x, fr
   hipLaunchKernelGGL(fr_sum_small, dim3(1), dim3(256), 256 * sizeof(fr_t), ctx->stream, partial, blocks, result);
   BP_HIP(ctx, hipGetLastError());
   BP_HIP(ctx, hipMemcpyAsync(host_out, result, sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   return BP_OK;
 }
 
@@ -75,7 +75,7 @@ int fr_nonzero_stats_run(bp_ctx* ctx, const fr_t* d_a, size_t n, size_t lo, size
   if (n) hipLaunchKernelGGL(fr_nonzero_stats, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, ctx->stream, d_a, n, lo, hi, d_out);
   unsigned long long h[2];
   BP_HIP(ctx, hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, ctx->stream));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   *eff_len = (size_t)h[0];
   if (nonzero_in_range) *nonzero_in_range = (size_t)h[1];
   return BP_OK;
@@ -97,7 +97,7 @@ int fr_compact_nonzero_run(bp_ctx* ctx, fr_t* d_q, size_t* n) {
   BP_HIP(ctx, hipGetLastError());
   unsigned long long m = 0;
   BP_HIP(ctx, hipMemcpyAsync(&m, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   if (m) BP_HIP(ctx, hipMemcpyAsync(d_q, tmp, (size_t)m * sizeof(fr_t), hipMemcpyDeviceToDevice, ctx->stream));
   *n = (size_t)m;
   return BP_OK;
@@ -142,7 +142,7 @@ int grand_product_run(bp_ctx* ctx, const fr_t* a, const fr_t* b, const fr_t* c, 
   BP_TRY(fr_scan_mul_run(ctx, den, n, 1, 1, sd, totals + 1));                  // inclusive suffix products of the denominators
   fr_t h_tot[2];
   BP_HIP(ctx, hipMemcpyAsync(h_tot, totals, 2 * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   if (big_is_zero(h_tot[1])) return fail(ctx, BP_ERR_DIV_ZERO, "round 2: a permutation denominator is zero (invert().unwrap())", hipSuccess, __FILE__, __LINE__);
   if (!big_eq(h_tot[0], h_tot[1])) return fail(ctx, BP_ERR_ASSERT, "round 2: z_n != 1 (prover.rs:319)", hipSuccess, __FILE__, __LINE__);
   fr_t td_inv;

@@ -163,7 +163,7 @@ int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out) {
   CircuitEntry e;
   e.log_n = log_n;
   int rc = circuit_fill(ctx, d_lag, e);
-  if (rc == BP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "circuit_build", hipGetLastError(), __FILE__, __LINE__);
+  if (rc == BP_OK && stream_wait(ctx->stream) != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "circuit_build", hipGetLastError(), __FILE__, __LINE__);
   if (rc != BP_OK) {
     circuit_release(e);               // e.lag is still null: the caller keeps d_lag
     return rc;

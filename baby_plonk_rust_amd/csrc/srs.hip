@@ -13,7 +13,7 @@ int srs_decode_run(bp_ctx* ctx, const uint8_t* d_bytes, size_t n, g1_affine* d_o
   BP_HIP(ctx, hipGetLastError());
   uint32_t h = 0;
   BP_HIP(ctx, hipMemcpyAsync(&h, status, 4, hipMemcpyDeviceToHost, ctx->stream));
-  BP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
   if (h) return fail(ctx, BP_ERR_BAD_POINT, h & 1 ? "non-canonical point encoding" : "point not on the curve", hipSuccess, __FILE__, __LINE__);
   return BP_OK;
 }

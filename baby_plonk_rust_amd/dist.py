@@ -54,46 +54,73 @@ def combine_partials(partial144, device=None, group=None):
 
 
 class ShardedMsm:
-    """The MSM path of one rank: the rank's partial sums stay in HBM (bp_msm_g1_blob_device), ONE all-gather
-    of the records over RCCL/xGMI, ONE device-to-host copy of the gathered buffer, host combine (bp_msm_blobs_combine).
-    Buffers are allocated once; `exchange_s` is the wall time of the last collective + copy + combine."""
+    """The MSM path of one rank: the rank's partial sums stay in HBM (bp_msm_g1_blob_device_async), ONE all-gather
+    of the records over RCCL/xGMI, the device-side pre-sum, ONE device-to-host copy, host combine (bp_msm_blobs_combine).
+    Stream-ordered end to end: the library context is put on a torch stream owned by this object (bp_set_stream) and the record,
+    the collective, the pre-sum and the copy are enqueued on it in that order -- the copy's is the only host wait of a call.
+    Buffers are allocated once.  `exchange_s`: GPU time from "record complete" to "gathered, summed and copied" (two events on
+    the stream).  close() (or garbage collection) gives the context its own stream back."""
 
     def __init__(self, ctx, group=None):
         self.ctx, self.group = ctx, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.gpu = torch.device("cuda", ctx.device)
-        self.mine = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu)
+        self.stream = torch.cuda.Stream(self.gpu)
+        ctx.set_stream(self.stream.cuda_stream)          # every later call on ctx is ordered on this stream
         self.collective = dist.is_initialized()          # under a launcher even a single rank goes through the collective
         self.on_gpu = self.collective and dist.get_backend(group) == "nccl"
-        self.gathered = torch.empty(self.world * _lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu if self.on_gpu else "cpu")
-        self.summed = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu)
+        with torch.cuda.stream(self.stream):
+            self.mine = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu)
+            self.gathered = torch.empty(self.world * _lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu if self.on_gpu else "cpu")
+            self.summed = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu)
+        self.record_done = torch.cuda.Event(enable_timing=True)
+        self.all_done = torch.cuda.Event(enable_timing=True)
         self.exchange_s = 0.0
-        torch.cuda.synchronize(self.gpu)
+        # (no synchronize: the fills above and the first record are on the same stream)
 
     def __call__(self, srs_handle_local, scalars_local=None, device_ptr=None, n=None, first=0):
-        import time
-        self.ctx.msm_blob_device(srs_handle_local, self.mine.data_ptr(), scalars_local, first=first, device_ptr=device_ptr, n=n)
-        t0 = time.perf_counter()
-        if not self.collective:
-            host = self.mine.cpu()
-        elif self.on_gpu:
-            dist.all_gather_into_tensor(self.gathered, self.mine, group=self.group)       # the path's single collective
-            torch.cuda.current_stream(self.gpu).synchronize()                             # the library adds on its own stream
-            self.ctx.msm_blobs_sum_device(self.gathered.data_ptr(), self.world, self.summed.data_ptr())     # equal layouts: one record
-            host = self.summed.cpu()                                                      # the path's single D2H (22 KB)
-            if int.from_bytes(host[:4].numpy().tobytes(), "little") == 0:                # layouts differ: all records to the host
-                host = self.gathered.cpu()
-        else:
-            dist.all_gather_into_tensor(self.gathered, self.mine.cpu(), group=self.group)
-            host = self.gathered
+        self.stream.wait_stream(torch.cuda.current_stream(self.gpu))        # behind whatever produced the scalars; enqueue only
+        self.ctx.msm_blob_device(srs_handle_local, self.mine.data_ptr(), scalars_local, first=first, device_ptr=device_ptr, n=n, wait=False)
+        with torch.cuda.stream(self.stream):
+            self.record_done.record()
+            if not self.collective:
+                host = self.mine.cpu()
+            elif self.on_gpu:
+                dist.all_gather_into_tensor(self.gathered, self.mine, group=self.group)       # the path's single collective
+                self.ctx.msm_blobs_sum_device(self.gathered.data_ptr(), self.world, self.summed.data_ptr(), wait=False)     # equal layouts: one record
+                host = self.summed.cpu()                                                      # the path's single D2H (22 KB) and only host wait
+                if int.from_bytes(host[:4].numpy().tobytes(), "little") == 0:                # layouts differ: all records to the host
+                    host = self.gathered.cpu()
+            else:
+                mine = self.mine.cpu()
+                dist.all_gather_into_tensor(self.gathered, mine, group=self.group)
+                host = self.gathered
+            self.all_done.record()
         out = api.combine_blobs(host.numpy().tobytes())
-        self.exchange_s = time.perf_counter() - t0
+        self.all_done.synchronize()
+        self.exchange_s = 1e-3 * self.record_done.elapsed_time(self.all_done)      # GPU-side: record complete -> gathered, summed and copied
         return out
+
+
+    def close(self):
+        if getattr(self, "ctx", None) is not None and getattr(self.ctx, "_h", None):
+            self.ctx.set_stream(None)                    # waits for the stream, then back to the context's own
+        self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def msm_sharded(ctx, srs_handle_local, scalars_local, device_ptr=None, n=None, group=None):
     """sum over ALL ranks' (point, scalar) pairs; `srs_handle_local` is this rank's point-range shard"""
-    return ShardedMsm(ctx, group)(srs_handle_local, scalars_local, device_ptr=device_ptr, n=n)
+    ex = ShardedMsm(ctx, group)
+    try:
+        return ex(srs_handle_local, scalars_local, device_ptr=device_ptr, n=n)
+    finally:
+        ex.close()
 
 
 def all_gather_columns(local_columns, n_columns, group=None, device=None):

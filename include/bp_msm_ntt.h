@@ -71,7 +71,11 @@ int  bp_ctx_devices(bp_ctx* ctx, int* device_ids, int cap);
 void bp_destroy(bp_ctx* ctx);
 const char* bp_last_error(bp_ctx* ctx);            /* text of the last error on this ctx ("" if none) */
 const char* bp_version(void);
-/* Run all subsequent work of this ctx on an existing hipStream_t (e.g. torch's current stream). NULL = own stream. */
+/* Run all subsequent work of this ctx on an existing hipStream_t (e.g. torch's current stream). NULL = own stream.
+ * Every entry point that reads or writes CALLER device memory (the *_device family) is ordered on that stream: work the caller
+ * enqueued on the same stream before the call is seen, work enqueued after sees the call's results -- the blocking forms
+ * additionally wait for the stream, the *_async forms do not.  On the context's own stream (the default) the caller must
+ * have finished its pending work on those buffers before the call. */
 int  bp_set_stream(bp_ctx* ctx, void* hip_stream);
 int  bp_synchronize(bp_ctx* ctx);
 
@@ -136,11 +140,20 @@ int  bp_msm_g1_partial(bp_ctx* ctx, uint64_t srs_handle, size_t first, const voi
 #define BP_MSM_BLOB_BYTES 22592u      /* 64-byte header + 128 accumulator slots of 176 bytes */
 int  bp_msm_g1_blob_device(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
                            int scalars_on_device, void* d_blob);
+/* The same, STREAM-ORDERED: enqueued on the context's stream and not waited for.  With bp_set_stream(the caller's stream) the
+ * record is written in that stream's order: behind whatever the caller enqueued on d_blob or the scalars before (a zero fill,
+ * a producer kernel), in front of whatever it enqueues next (the RCCL all-gather of dist.ShardedMsm) -- no host wait, and
+ * ordering is a property of the call, not of prose.  Errors that need the result (a canonical-bytes scalar >= q) travel in
+ * the record's header and surface in bp_msm_blobs_combine.  bp_msm_last_stats reads the timing once the stream has passed it. */
+int  bp_msm_g1_blob_device_async(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
+                                 int scalars_on_device, void* d_blob);
 /* Optional device-side pre-sum of the gathered records (n_blobs of them in HBM, BP_MSM_BLOB_BYTES apart): records of equal
  * window layout -- the normal case -- are added slot by slot on the GPU into ONE record at d_out_blob, so only 22 KB cross to
  * the host and the host does one Horner pass.  If the layouts differ the output record is marked invalid (bp_msm_blobs_combine
  * rejects it with BP_ERR_INVALID_ARG) and the caller combines the gathered records on the host instead. */
 int  bp_msm_blobs_sum_device(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out_blob);
+/* The same, stream-ordered (enqueued on the context's stream, not waited for). */
+int  bp_msm_blobs_sum_device_async(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out_blob);
 /* Host-side: combine n_blobs records (host memory, BP_MSM_BLOB_BYTES apart) into the affine result.  Records with the
  * same window layout are added slot by slot before the one Horner pass (msm.rs:107-115). */
 int  bp_msm_blobs_combine(const void* blobs, size_t n_blobs, uint8_t out96[96]);

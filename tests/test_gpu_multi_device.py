@@ -214,6 +214,40 @@ def test_blob_records_one_gather_one_copy():
     assert e.value.code == -4
 
 
+def test_blob_record_is_stream_ordered():
+    """ordering against the caller's work is a property of the entry point, not of prose.  With the context on
+    the caller's stream (bp_set_stream) the record lands BEHIND a fill the caller enqueued on the destination just before -- no
+    synchronize anywhere -- for the enqueue-only form and for the blocking form, for an empty shard (one tiny kernel: round 2 lost
+    this race 19 times in 25 on the context's own stream) and for a real one."""
+    ctx = bp.Context(0)
+    n, a, d = 3000, 97531, 86420
+    h = ctx.srs_generate_progression(n, a, d)
+    sc = O.splitmix_scalars(n, 0x0DD)
+    want = M.enc96(M.ec_mul(G.oracle_dot(sc, a, d)))
+    dsc = torch.from_numpy(sc.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    ctx.set_stream(st.cuda_stream)
+    with torch.cuda.stream(st):
+        for trial in range(12):
+            for wait in (False, True):
+                big = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+                big.fill_(0xEE)                                     # ~50 us of fill on the caller's stream, in flight when the call comes
+                rec = big[-_lib.MSM_BLOB_BYTES:]
+                ctx.msm_blob_device(h, rec.data_ptr(), None, device_ptr=dsc.data_ptr(), n=0, wait=wait)         # empty shard
+                assert bp.combine_blobs(rec.cpu().numpy().tobytes()) == M.enc96(None), (trial, wait)
+                big.fill_(0x77)
+                ctx.msm_blob_device(h, rec.data_ptr(), None, device_ptr=dsc.data_ptr(), n=n, wait=wait)
+                out = torch.empty_like(rec)
+                out.copy_(rec)                                      # the caller's next operation on the same stream sees the record
+                assert bp.combine_blobs(out.cpu().numpy().tobytes()) == want, (trial, wait)
+                del big
+    st.synchronize()
+    ctx.set_stream(None)
+    assert ctx.msm(h, sc) == want
+    ctx.close()
+
+
 def test_projective_image_seam():
     """bucket_msm(points: &[G1Projective], ..) (msm.rs:76-81): the points as the reference holds them in memory, z != 1"""
     ctx = bp.Context(0)
