@@ -196,8 +196,10 @@ int msm_init_device(bp_ctx* ctx) {
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_long_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_long_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_long_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_part_scatter<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_part_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_part_scatter<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_part_scatter<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_part_scatter<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+  BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_part_scatter<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
   return BP_OK;
 }
 
@@ -301,6 +303,14 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   if (pb > 16) pb = 16;
   if (pb > PART_MAX_BITS && (max_entries >> PART_MAX_BITS) <= 32768) pb = PART_MAX_BITS;     // final runs of up to 32 Ki entries are fine for one workgroup
   if (pb + MSM_HIST_LOG < kb) pb = kb - MSM_HIST_LOG;
+  // record form of the partition sort: the packed word holds the bucket's low kb - pb bits, the sign and the entry (point or
+  // table index, vb - 1 bits).  Where a few more partitions make the record fit one word (c = 20 at 2^20: 2^12 instead of 2^10)
+  // they are taken: half the bytes through the scatter and the final sort (BP_MSM_PACKED=2 keeps the run length instead).
+  const uint64_t idx_max = (uint64_t)(n - 1) + (uint64_t)(plan.naf ? 255u : W - 1) * plan.wpoints;
+  uint32_t vb = 1;
+  while ((idx_max >> (vb - 1)) != 0) vb++;                              // vb - 1 = bits of the largest entry, + 1 for the sign
+  const uint32_t packed_env = env_u32("BP_MSM_PACKED", 1, 0, 2);
+  if (packed_env == 1 && kb + vb > 32 + pb && kb + vb - 32 <= PART_MAX_BITS && env_u32("BP_MSM_RADIX_BITS", 99, 0, 16) == 99) pb = kb + vb - 32;
   const uint32_t sort_env = env_u32("BP_MSM_SORT", 2, 0, 2);
   const bool hist_ok = plan.parts == 1 && !plan.naf && J == 1;
   const int sort_mode = (sort_env == 0 && hist_ok) ? 0 : (((sort_env == 1 && J == 1) || pb > PART_MAX_BITS) ? 1 : 2);
@@ -309,17 +319,13 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   const size_t rhist = ((size_t)1 << rbits) * 4;
   uint32_t* rlong_n = ctl + 2;
   if (sort_mode == 2) {
-    // record form: the packed word holds the bucket's low rbits bits, the sign and the entry (point or table index)
-    const uint64_t idx_max = (uint64_t)(n - 1) + (uint64_t)(plan.naf ? 255u : W - 1) * plan.wpoints;
-    uint32_t vb = 1;
-    while ((idx_max >> (vb - 1)) != 0) vb++;                            // vb - 1 = bits of the largest entry, + 1 for the sign
-    const bool packed = rbits + vb <= 32 && env_u32("BP_MSM_PACKED", 1, 0, 1) != 0;
+    const bool packed = rbits + vb <= 32 && packed_env != 0;
     const uint32_t rec_bytes = packed ? 4 : 8;
     // scalars per workgroup: the staging area (slice * W records) within 64 KiB, and >= 512 workgroups where n allows
     uint32_t slice = 64;
     while (slice < 1024 && (uint64_t)2 * slice * W * rec_bytes <= 65536 && (uint64_t)slice * 512 < (uint64_t)n * J) slice <<= 1;
     slice = env_u32("BP_MSM_PART_SLICE", slice, 64, 4096);
-    if (slice < 64 || slice > 4096 || (uint64_t)slice * W * rec_bytes > 98304) slice = 64;
+    if (slice < 64 || slice > 4096 || (uint64_t)slice * W * rec_bytes > 65536) slice = 64;
     const uint32_t cap = slice * W, n_slices = (uint32_t)(((uint64_t)n * J + slice - 1) / slice);
     const unsigned threads = slice >= 1024 ? 1024u : (slice <= 256 ? 256u : slice);
     uint32_t *recs = nullptr, *rvals = nullptr, *roff, *cur, *rlong_list;
@@ -329,27 +335,30 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     BP_TRY(ws_get(ctx, "msm.run_cur", (size_t)n_final * 4, (void**)&cur));
     BP_TRY(ws_get(ctx, "msm.run_long", ((size_t)n_final + 2) * 4, (void**)&rlong_list));
     hipLaunchKernelGGL(msm_part_count, dim3(n_slices), dim3(threads), 0, st, scalars_all, fmt, plan, slice, pb, rbits, ctl + 4, roff, cur, long_count + 1);
+    // a slice's share of a partition: long -> partition-major write-out, short -> one lane per record (BP_MSM_PART_FLAT = 0 / 1 forces)
+    const uint32_t flat_env = env_u32("BP_MSM_PART_FLAT", 2, 0, 2);
+    const bool flat = flat_env == 2 ? (cap >> pb) < 8 : flat_env == 1;
+    const size_t part_lds = (size_t)3 * n_final * 4 + (size_t)cap * rec_bytes + (flat ? (size_t)cap * 2 : 0);
+    const dim3 lgrid(64, n_final < 4 ? n_final : 4);
     if (packed) {
-      hipLaunchKernelGGL(msm_part_scatter<true>, dim3(n_slices), dim3(threads), (size_t)cap * 4, st, scalars_all, fmt, plan, slice, pb, rbits, vb, cap, cur,
-                         recs, rvals);
+      if (flat) hipLaunchKernelGGL((msm_part_scatter<true, true>), dim3(n_slices), dim3(threads), part_lds, st, scalars_all, fmt, plan, slice, pb, rbits, vb, cap, cur, recs, rvals);
+      else hipLaunchKernelGGL((msm_part_scatter<true, false>), dim3(n_slices), dim3(threads), part_lds, st, scalars_all, fmt, plan, slice, pb, rbits, vb, cap, cur, recs, rvals);
       const RunRecords<true> rr{recs, nullptr, (1u << rbits) - 1u, vb};
       hipLaunchKernelGGL(msm_radix_final<true>, dim3(n_final < 4096 ? n_final : 4096), dim3(1024), rhist, st, rr, roff, n_final, rbits, total, offsets,
                          sorted, rlong_n, rlong_list, counts);
       if (n_final > 1) {
-        const dim3 lgrid(64, n_final < 4 ? n_final : 4);
         hipLaunchKernelGGL(msm_radix_long_count<true>, lgrid, dim3(1024), rhist, st, rr, roff, rbits, rlong_n, rlong_list, counts);
         hipLaunchKernelGGL(msm_radix_long_prefix, dim3(n_final < 16 ? n_final : 16), dim3(1024), 0, st, roff, n_final, rbits, total, rlong_n, rlong_list,
                            counts, offsets, cursors);
         hipLaunchKernelGGL(msm_radix_long_scatter<true>, lgrid, dim3(1024), rhist, st, rr, roff, rbits, rlong_n, rlong_list, cursors, sorted);
       }
     } else {
-      hipLaunchKernelGGL(msm_part_scatter<false>, dim3(n_slices), dim3(threads), (size_t)cap * 8, st, scalars_all, fmt, plan, slice, pb, rbits, vb, cap, cur,
-                         recs, rvals);
+      if (flat) hipLaunchKernelGGL((msm_part_scatter<false, true>), dim3(n_slices), dim3(threads), part_lds, st, scalars_all, fmt, plan, slice, pb, rbits, vb, cap, cur, recs, rvals);
+      else hipLaunchKernelGGL((msm_part_scatter<false, false>), dim3(n_slices), dim3(threads), part_lds, st, scalars_all, fmt, plan, slice, pb, rbits, vb, cap, cur, recs, rvals);
       const RunRecords<false> rr{recs, rvals, (1u << rbits) - 1u, 0u};
       hipLaunchKernelGGL(msm_radix_final<false>, dim3(n_final < 4096 ? n_final : 4096), dim3(1024), rhist, st, rr, roff, n_final, rbits, total, offsets,
                          sorted, rlong_n, rlong_list, counts);
       if (n_final > 1) {
-        const dim3 lgrid(64, n_final < 4 ? n_final : 4);
         hipLaunchKernelGGL(msm_radix_long_count<false>, lgrid, dim3(1024), rhist, st, rr, roff, rbits, rlong_n, rlong_list, counts);
         hipLaunchKernelGGL(msm_radix_long_prefix, dim3(n_final < 16 ? n_final : 16), dim3(1024), 0, st, roff, n_final, rbits, total, rlong_n, rlong_list,
                            counts, offsets, cursors);
@@ -470,9 +479,16 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     }
     const proj28_slot* in = bucket_sum;
     int flip = 0;
+    const bool fuse01 = n_wide >= 2 && env_u32("BP_MSM_PLANES_FUSE01", 1, 0, 1) != 0;
     while (k < levels) {
       const bool leaf = k == 0;
-      if (k < n_wide) {
+      if (leaf && fuse01) {                 // levels 0 and 1 in one launch, four buckets per lane
+        nodes >>= 2;
+        flip ^= 1;                          // the output takes the buffer level 1 would have taken
+        hipLaunchKernelGGL(msm_planes_level01, dim3((nodes + 255) / 256), dim3(256), 0, st, offsets, in, nodes, tmp[flip]);
+        in = tmp[flip];
+        k = 2;
+      } else if (k < n_wide) {
         nodes >>= 1;
         const uint64_t items = (uint64_t)nodes * (k + 1);
         const dim3 grid((unsigned)((items + 255) / 256));

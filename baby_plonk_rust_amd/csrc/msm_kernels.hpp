@@ -586,14 +586,14 @@ __global__ void __launch_bounds__(1024) msm_radix_long_scatter(RunRecords<PACKED
 // The default bucket sort.  The histogram sort of section 4 pays one global atomic per (workgroup, bucket) it touches -- ~10^7 of
 // them at 2^20 points, twice -- and isolated 4-byte stores; the two-level sort of 4c moves 8-byte records three times.  Here:
 //   msm_part_count     a workgroup per slice of scalars: Montgomery -> canonical -> digits in registers, LDS histogram of the
-//                      entries' PARTITIONS (the high pb bits of the bucket id, <= 2^11), one global atomic per (workgroup,
+//                      entries' PARTITIONS (the high pb bits of the bucket id, <= 2^12), one global atomic per (workgroup,
 //                      partition); the workgroup that finishes last (a ticket) scans the 2^pb sizes = the final runs' offsets
 //   msm_part_scatter   the same slices, digits recomputed (32 B of scalar re-read instead of 128 B of records written and read):
 //                      rank in LDS, reserve the slice's range in every partition, stage sorted by partition, write each
 //                      partition's share lane-adjacent
 //   msm_radix_final    one workgroup per final run, as in 4c (packed records where they fit: RunRecords)
 // No digit array, no record arrays before the final runs, no scan launches.
-constexpr uint32_t PART_MAX_BITS = 11, PART_MAX = 1u << PART_MAX_BITS;
+constexpr uint32_t PART_MAX_BITS = 12, PART_MAX = 1u << PART_MAX_BITS;
 
 // every (bucket id, entry | sign << 31) of scalar i, in window (or NAF slot) order.  status != null: canonical-bytes inputs are
 // range-checked (Scalar::from_bytes rejects values >= q, scalar.rs:264-288)
@@ -721,15 +721,24 @@ __global__ void __launch_bounds__(1024) msm_part_count(MsmScalars scalars, int f
   if (threadIdx.x == 0) run_off[P] = carry_s;
 }
 
-extern __shared__ uint32_t msm_part_lds[];        // PACKED: records[cap]; else keys[cap] | vals[cap]   (cap = slice * W)
-template <bool PACKED>
+// LDS (dynamic): h[P] | lbase[P] | gbase[P] | records[cap] (PACKED) or keys[cap] | vals[cap] | FLAT: partition of every staged
+// record, u16[cap]   (cap = slice * W, P = 2^pb)
+// FLAT picks the write-out.  false: partition-major, 16 lanes per partition -- for shares of >= 8 records per partition (c <= 16:
+// 2^10 partitions).  true: one lane per staged record, consecutive lanes = consecutive records of a partition -- for short
+// shares (c = 20 at 2^20: 2^12 partitions, ~3 records per slice each), where the partition-major loop leaves 13 lanes in 16 idle.
+extern __shared__ uint32_t msm_part_lds[];
+template <bool PACKED, bool FLAT>
 __global__ void __launch_bounds__(1024) msm_part_scatter(MsmScalars scalars, int fmt, MsmPlan plan, uint32_t slice, uint32_t pb,
                                                          uint32_t rbits, uint32_t vb, uint32_t cap, uint32_t* __restrict__ cursor,
                                                          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-  __shared__ uint32_t h[PART_MAX], lbase[PART_MAX], gbase[PART_MAX], scan16[16], carry_s;
-  uint32_t* st_key = msm_part_lds;
-  uint32_t* st_val = st_key + cap;
+  __shared__ uint32_t scan16[16], carry_s;
   const uint32_t P = 1u << pb, rmask = (1u << rbits) - 1u;
+  uint32_t* h = msm_part_lds;
+  uint32_t* lbase = h + P;
+  uint32_t* gbase = lbase + P;
+  uint32_t* st_key = gbase + P;
+  uint32_t* st_val = st_key + cap;
+  uint16_t* st_part = reinterpret_cast<uint16_t*>(PACKED ? st_val : st_val + cap);
   for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) h[p] = 0;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
@@ -758,15 +767,24 @@ __global__ void __launch_bounds__(1024) msm_part_scatter(MsmScalars scalars, int
       st_key[pos] = bucket;
       st_val[pos] = val;
     }
+    if (FLAT) st_part[pos] = (uint16_t)part;
   });
   __syncthreads();
-  // partition-major write-out: 16 lanes per partition, four partitions per wave at a time
-  const uint32_t sub = threadIdx.x >> 4, l16 = threadIdx.x & 15, n_sub = blockDim.x >> 4;
-  for (uint32_t p = sub; p < P; p += n_sub) {
-    const uint32_t cnt = h[p], src = lbase[p], dst = gbase[p];
-    for (uint32_t e = l16; e < cnt; e += 16) {
-      keys_out[dst + e] = st_key[src + e];
-      if (!PACKED) vals_out[dst + e] = st_val[src + e];
+  if (FLAT) {
+    const uint32_t live = carry_s;
+    for (uint32_t j = threadIdx.x; j < live; j += blockDim.x) {
+      const uint32_t p = st_part[j], g = gbase[p] + (j - lbase[p]);
+      keys_out[g] = st_key[j];
+      if (!PACKED) vals_out[g] = st_val[j];
+    }
+  } else {      // 16 lanes per partition, four partitions per wave at a time
+    const uint32_t sub = threadIdx.x >> 4, l16 = threadIdx.x & 15, n_sub = blockDim.x >> 4;
+    for (uint32_t p = sub; p < P; p += n_sub) {
+      const uint32_t cnt = h[p], src = lbase[p], dst = gbase[p];
+      for (uint32_t e = l16; e < cnt; e += 16) {
+        keys_out[dst + e] = st_key[src + e];
+        if (!PACKED) vals_out[dst + e] = st_val[src + e];
+      }
     }
   }
 }
@@ -1310,6 +1328,29 @@ msm_planes_level(const uint32_t* __restrict__ offsets, const proj28_slot* __rest
   if (v == 0) store_proj28(&o[per], b);                                                    // T_k = A_r
   g1_add28(a, a, b);
   store_proj28(&o[v], a);
+}
+
+// Levels 0 and 1 in one launch: a lane takes four consecutive buckets S0..S3 and writes the node (A, T0, T1) = (S0+S1+S2+S3,
+// S1+S3, S2+S3) -- the same four additions as two msm_planes_level launches, without the round trip of the level-1 nodes
+// through HBM and with one launch less (2^19 buckets: 83 + 75 us -> see profiles/r03_window_width_ab.txt).  n_out = buckets / 4.
+__global__ void __launch_bounds__(256, 2)       // (five points live: 177 registers spill at two waves per SIMD -- 138 us; one wave per SIMD without spills measured 151)
+msm_planes_level01(const uint32_t* __restrict__ offsets, const proj28_slot* __restrict__ in, uint32_t n_out, proj28_slot* __restrict__ out) {
+  const uint32_t node = blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= n_out) return;
+  const size_t g = 4 * (size_t)node;
+  const uint32_t o0 = offsets[g], o1 = offsets[g + 1], o2 = offsets[g + 2], o3 = offsets[g + 3], o4 = offsets[g + 4];
+  proj28_slot* o = out + (size_t)node * 3;
+  g1_proj28 s1 = o2 != o1 ? load_proj28(&in[g + 1]) : g1_identity28();
+  g1_proj28 a01 = o1 != o0 ? load_proj28(&in[g]) : g1_identity28();
+  g1_add28(a01, a01, s1);                                   // S0 + S1
+  g1_proj28 s3 = o4 != o3 ? load_proj28(&in[g + 3]) : g1_identity28();
+  g1_add28(s1, s1, s3);                                     // T0 = S1 + S3
+  store_proj28(&o[1], s1);
+  g1_proj28 a23 = o3 != o2 ? load_proj28(&in[g + 2]) : g1_identity28();
+  g1_add28(a23, a23, s3);                                   // T1 = S2 + S3
+  store_proj28(&o[2], a23);
+  g1_add28(a01, a01, a23);                                  // A
+  store_proj28(&o[0], a01);
 }
 
 // m levels of the tree inside one workgroup, every addition shared by a group of COOP lanes ("narrow" levels: fewer pending

@@ -145,10 +145,13 @@ def test_full_size_2p20_with_tables(ctx):
     h = ctx.srs_generate_progression(n, a, d)
     sc = O.splitmix_scalars(n, 0x5EED0014)
     plain = ctx.msm(h, sc)
-    info = ctx.srs_precompute(h)
-    assert info == {"window_bits": 16, "windows": 16, "bytes": 16 * n * 112}
     want = M.enc96(M.ec_mul(oracle_dot(sc, a, d)))
-    assert ctx.msm(h, sc) == want == plain and ctx.msm_stats()["tables"]
+    info = ctx.srs_precompute(h, 16)                                 # the widest window whose buckets fit one LDS histogram (round 2's choice here)
+    assert info == {"window_bits": 16, "windows": 16, "bytes": 16 * n * 112}
+    assert ctx.msm(h, sc) == want == plain and ctx.msm_stats()["tables"] and ctx.msm_stats()["window_bits"] == 16
+    info = ctx.srs_precompute(h)                                     # auto: 13 windows of 20 bits from 2^20 points (profiles/r03_window_width_ab.txt)
+    assert info == {"window_bits": 20, "windows": 13, "bytes": 13 * n * 112}
+    assert ctx.msm(h, sc) == want == plain and ctx.msm_stats()["tables"] and ctx.msm_stats()["window_bits"] == 20
     t = torch.from_numpy(sc.view(np.int64)).cuda()
     torch.cuda.synchronize()
     assert bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n)) == want
