@@ -450,7 +450,7 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   else
     hipLaunchKernelGGL(msm_fixup<1>, dim3((total + 255) / 256), dim3(256), 0, st, offsets, plan, bucket_sum, partial, long_count, long_list,
                        long_cap);
-  hipLaunchKernelGGL(msm_fixup_long, dim3(64, FIXUP_LONG_SLICES), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
+  hipLaunchKernelGGL(msm_fixup_long, dim3(512), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
                      long_count, long_list, long_cap, long_scratch, long_ticket);
   if (table_c) {
     // The tree over the B = 2^(c-1) buckets, level by level.  A level with at least PLANES_WIDE_MIN additions is throughput

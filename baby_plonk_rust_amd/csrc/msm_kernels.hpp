@@ -837,6 +837,17 @@ __device__ __forceinline__ g1_proj28 load_proj28(const proj28_slot* __restrict__
   for (int j = 0; j < N28; j++) { p.x.l[j] = w[j]; p.y.l[j] = w[N28 + j]; p.z.l[j] = w[2 * N28 + j]; }
   return p;
 }
+// z limbs all zero: the identity exactly as g1_identity28() writes it (an empty bucket, or a sum of such).  A tree over mostly
+// empty buckets (8-bit or sparse scalars on 2^19 buckets) skips the additions of its empty regions on this test: waves whose
+// lanes all see two such operands do not execute the addition at all.  (A sum that happens to be the identity with non-zero lazy
+// limbs is simply added like any other point.)
+__device__ __forceinline__ bool is_blank28(const g1_proj28& p) {
+  uint32_t z = 0;
+#pragma unroll
+  for (int j = 0; j < N28; j++) z |= p.z.l[j];
+  return z == 0;
+}
+
 // Cooperative complete addition (g1_28.hpp): the COOP consecutive lanes of a group pass the same two points; the six
 // products and the three output coordinates travel between the lanes by shuffles; every lane returns the full sum.
 // ~1 600 instructions deep instead of ~6 600, at twice the work -- it pays only where fewer additions than lanes / 8 are
@@ -1142,10 +1153,9 @@ __device__ __forceinline__ g1_proj28 block_tree_sum28(g1_proj28 v, uint32_t live
 
 // Queued (long) buckets.  A bucket of up to FIXUP_LONG_SPLIT_FROM partials is summed by one workgroup; a longer one -- a bucket that
 // holds a large share of a skewed input (scalars 0 / 1: one bucket of n / 2 entries = 16 Ki partials at 2^20) -- by FIXUP_LONG_SLICES
-// workgroups, one slice of its partials each (grid.y), into `scratch`; the workgroup whose slice is finished last (a ticket per
+// workgroups, one slice of its partials each, into `scratch`; the workgroup whose slice is finished last (a ticket per
 // queued bucket, zero before the launch and zero again after it) adds the slice sums.
-// grid (x, FIXUP_LONG_SLICES): workgroup (x, y) takes slice y of the queued buckets x, x + gridDim.x, ...  An empty queue (the
-// normal case: uniformly random scalars on a table) costs one launch of workgroups that read one word and leave.
+// An empty queue (the normal case: uniformly random scalars on a table) costs one launch of workgroups that read one word and leave.
 constexpr uint32_t FIXUP_LONG_SLICES = 8, FIXUP_LONG_SPLIT_FROM = 2048;
 __global__ void __launch_bounds__(256, 2)
 msm_fixup_long(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* __restrict__ bucket_sum,
@@ -1155,20 +1165,25 @@ msm_fixup_long(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* 
   const uint32_t n_long = *long_count < long_cap ? *long_count : long_cap;
   if (n_long == 0) return;
   const uint32_t chunk = msm_lane_chunk(plan, offsets[plan.total]);
-  for (uint32_t k = blockIdx.x; k < n_long; k += gridDim.x) {
+  // work items dealt round-robin over a one-dimensional grid: 255 long buckets (8-bit scalars) keep 255 workgroups busy, one
+  // bucket of 16 Ki partials (scalars 0 / 1) keeps eight
+  // first the buckets one workgroup sums alone (item = bucket), then the slices of the split ones (item = bucket, slice)
+  for (uint32_t item = blockIdx.x; item < n_long * (1 + FIXUP_LONG_SLICES); item += gridDim.x) {
+    const bool whole = item < n_long;
+    const uint32_t k = whole ? item : (item - n_long) / FIXUP_LONG_SLICES, y = whole ? 0u : (item - n_long) % FIXUP_LONG_SLICES;
     const uint32_t g = long_list[k];
     const uint32_t a = offsets[g], b = offsets[g + 1];
     const uint32_t t_lo = a / chunk, t_hi = (b - 1) / chunk, P = t_hi - t_lo + 1;
     const bool split = P > FIXUP_LONG_SPLIT_FROM;                  // uniform over the workgroup (and over the bucket's workgroups)
-    if (!split && blockIdx.y != 0) continue;
+    if (split == whole) continue;
     const uint32_t per = split ? (P + FIXUP_LONG_SLICES - 1) / FIXUP_LONG_SLICES : P;
-    const uint32_t s_lo = t_lo + blockIdx.y * per, s_hi = s_lo + per - 1 < t_hi ? s_lo + per - 1 : t_hi;      // inclusive; empty when s_lo > t_hi
+    const uint32_t s_lo = t_lo + y * per, s_hi = s_lo + per - 1 < t_hi ? s_lo + per - 1 : t_hi;      // inclusive; empty when s_lo > t_hi
     g1_proj28 acc = g1_identity28();
     for (uint64_t t = (uint64_t)s_lo + threadIdx.x; t <= s_hi; t += blockDim.x) {
       g1_proj28 q = load_proj28(&partial[2 * (size_t)t + partial_slot(a, (uint32_t)t, chunk)]);
       g1_add28(acc, acc, q);
     }
-    g1_proj28 tot = block_tree_sum28(acc, blockDim.x);
+    g1_proj28 tot = block_tree_sum28(acc, per < blockDim.x ? per : blockDim.x);          // lanes beyond the slice hold the identity
     if (!split) {
       if (threadIdx.x == 0) store_proj28(&bucket_sum[g], tot);
       __syncthreads();
@@ -1177,7 +1192,7 @@ msm_fixup_long(const uint32_t* __restrict__ offsets, MsmPlan plan, proj28_slot* 
     // publish this slice's sum, take a ticket; the last of the FIXUP_LONG_SLICES workgroups of bucket k merges.  One lane stores,
     // releases at agent scope and signals; the merging workgroup acquires before it reads the other slices (MI355X guide, G16)
     if (threadIdx.x == 0) {
-      store_proj28(&scratch[(size_t)k * FIXUP_LONG_SLICES + blockIdx.y], tot);
+      store_proj28(&scratch[(size_t)k * FIXUP_LONG_SLICES + y], tot);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const uint32_t t = atomicAdd(&ticket[k], 1u);
@@ -1292,7 +1307,7 @@ __device__ __forceinline__ proj28_slot* planes_tree(proj28_slot* cur, proj28_slo
       const uint32_t m = item / in_per, v = item - m * in_per;
       const proj28_slot* L = cur + (size_t)(2 * m) * in_per;
       g1_proj28 a = load_proj28(&L[v]), b = load_proj28(&L[in_per + v]);
-      a = g1_add28_coop(a, b);
+      if (!(is_blank28(a) && is_blank28(b))) a = g1_add28_coop(a, b);            // uniform over the group (all its lanes hold the same points)
       if (lead) store_proj28(&nxt[(size_t)m * out_per + v], a);
     }
     if (planes)
@@ -1326,7 +1341,7 @@ msm_planes_level(const uint32_t* __restrict__ offsets, const proj28_slot* __rest
   }
   proj28_slot* o = out + (size_t)node * (per + 1);
   if (v == 0) store_proj28(&o[per], b);                                                    // T_k = A_r
-  g1_add28(a, a, b);
+  if (!(is_blank28(a) && is_blank28(b))) g1_add28(a, a, b);                                // empty regions: whole waves skip
   store_proj28(&o[v], a);
 }
 
@@ -1340,16 +1355,35 @@ msm_planes_level01(const uint32_t* __restrict__ offsets, const proj28_slot* __re
   const size_t g = 4 * (size_t)node;
   const uint32_t o0 = offsets[g], o1 = offsets[g + 1], o2 = offsets[g + 2], o3 = offsets[g + 3], o4 = offsets[g + 4];
   proj28_slot* o = out + (size_t)node * 3;
-  g1_proj28 s1 = o2 != o1 ? load_proj28(&in[g + 1]) : g1_identity28();
-  g1_proj28 a01 = o1 != o0 ? load_proj28(&in[g]) : g1_identity28();
-  g1_add28(a01, a01, s1);                                   // S0 + S1
-  g1_proj28 s3 = o4 != o3 ? load_proj28(&in[g + 3]) : g1_identity28();
-  g1_add28(s1, s1, s3);                                     // T0 = S1 + S3
-  store_proj28(&o[1], s1);
+  if (o4 == o0) {                                           // four empty buckets (8-bit or sparse scalars leave most of 2^19 empty): no additions
+    const g1_proj28 blank = g1_identity28();
+    store_proj28(&o[0], blank);
+    store_proj28(&o[1], blank);
+    store_proj28(&o[2], blank);
+    return;
+  }
+  // at most three points live at a time (five would spill ~180 registers at two waves per SIMD): S3 is read twice and S0 + S1
+  // makes a round trip through its output slot instead
+  {
+    g1_proj28 s1 = o2 != o1 ? load_proj28(&in[g + 1]) : g1_identity28();
+    {
+      g1_proj28 a01 = o1 != o0 ? load_proj28(&in[g]) : g1_identity28();
+      g1_add28(a01, a01, s1);                                 // S0 + S1
+      store_proj28(&o[0], a01);
+    }
+    const g1_proj28 s3 = o4 != o3 ? load_proj28(&in[g + 3]) : g1_identity28();
+    g1_add28(s1, s1, s3);                                     // T0 = S1 + S3
+    store_proj28(&o[1], s1);
+  }
   g1_proj28 a23 = o3 != o2 ? load_proj28(&in[g + 2]) : g1_identity28();
-  g1_add28(a23, a23, s3);                                   // T1 = S2 + S3
+  {
+    const g1_proj28 s3 = o4 != o3 ? load_proj28(&in[g + 3]) : g1_identity28();
+    g1_add28(a23, a23, s3);                                   // T1 = S2 + S3
+  }
   store_proj28(&o[2], a23);
-  g1_add28(a01, a01, a23);                                  // A
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this lane's own store of S0 + S1 has landed before it is read back
+  g1_proj28 a01 = load_proj28(&o[0]);
+  g1_add28(a01, a01, a23);                                    // A
   store_proj28(&o[0], a01);
 }
 

@@ -11,6 +11,7 @@ from oracle import oracle as O
 ap = argparse.ArgumentParser()
 ap.add_argument("--log-n", type=int, default=20)
 ap.add_argument("--window-bits", type=int, default=0, help="table width (0 = auto)")
+ap.add_argument("--only", default="", help="one distribution only, with tables only (a target for rocprofv3)")
 args = ap.parse_args()
 n = 1 << args.log_n
 Q = O.Q
@@ -36,7 +37,9 @@ two = np.zeros(n, dtype=np.uint64); two[::2] = 1
 kinds["zeros_and_ones"] = to_mont(two)
 sparse = np.zeros((n, 4), dtype=np.uint64); idx = np.random.default_rng(3).integers(0, n, n // 100); sparse[idx] = base[idx]
 kinds["sparse_1pct"] = sparse
-for tables in (False, True):
+if args.only:
+    kinds = {args.only: kinds[args.only]}
+for tables in ((True,) if args.only else (False, True)):
     if tables:
         print(ctx.srs_precompute(h, args.window_bits))
     for name, sc in kinds.items():
