@@ -776,6 +776,9 @@ static int msm_all_shards_finish(bp_ctx* ctx, const ShardedPending& sp, int rc, 
   over_members(ctx, sh.size(), [&](size_t r) { return (bool)used[r]; }, [&](size_t r) {
     DeviceGuard guard(sh[r]->device);
     rcs[r] = msm_finish(sh[r], pend[r], &part[r]);
+    sh[r]->shard_accumulate_ms = sh[r]->msm_accumulate_ms;
+    sh[r]->shard_total_ms = sh[r]->msm_total_ms;
+    sh[r]->shard_adds = sh[r]->msm_adds;
     sh[r]->msm_upload_ms = 0;
     if (rcs[r] == BP_OK && sp.host_scalars && !pend[r].empty && hipEventElapsedTime(&sh[r]->msm_upload_ms, sh[r]->ev[4], sh[r]->ev[0]) != hipSuccess) {
       (void)hipGetLastError();
@@ -1103,9 +1106,10 @@ int bp_msm_last_member_stats(bp_ctx* ctx, int member, float* upload_ms, float* a
   if (member < 0 || (size_t)member >= sh.size()) return BP_ERR_INVALID_ARG;
   const bp_ctx* m = sh[member];
   if (upload_ms) *upload_ms = m->msm_upload_ms;
-  if (accumulate_ms) *accumulate_ms = m->msm_accumulate_ms;
-  if (total_device_ms) *total_device_ms = m->msm_total_ms;
-  if (mixed_adds) *mixed_adds = m->msm_adds;
+  const bool group = sh.size() > 1;
+  if (accumulate_ms) *accumulate_ms = group ? m->shard_accumulate_ms : m->msm_accumulate_ms;
+  if (total_device_ms) *total_device_ms = group ? m->shard_total_ms : m->msm_total_ms;
+  if (mixed_adds) *mixed_adds = group ? m->shard_adds : m->msm_adds;
   return BP_OK;
 }
 int bp_msm_last_used_tables(bp_ctx* ctx) { return ctx ? (ctx->msm_tables ? 1 : 0) : BP_ERR_INVALID_ARG; }

@@ -92,6 +92,8 @@ struct bp_ctx {
   // stats of the last calls
   float msm_accumulate_ms = 0, msm_total_ms = 0;
   float msm_upload_ms = 0;         // host scalars: the H2D copy in front of the last MSM (ev[4] .. ev[0]); else 0
+  float shard_accumulate_ms = 0, shard_total_ms = 0;    // this member's own share of the last MSM (the fields above hold the group's
+  uint64_t shard_adds = 0;                               // figures on the leader: slowest shard, all additions)
   uint64_t msm_adds = 0;
   uint32_t msm_c = 0;
   bool msm_tables = false;
