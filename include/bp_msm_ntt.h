@@ -18,7 +18,10 @@
  *                        sharded by contiguous point range over the GPUs; bp_msm_g1 / bp_commit / bp_prove split the scalars
  *                        the same way, run the shards concurrently and add the partial sums -- the single-threaded Rust caller
  *                        of Setup::commit (src/setup.rs:32-37) uses all GPUs without knowing about them.  Batched host NTTs
- *                        (bp_ntt_fr with batch > 1) spread their independent columns over the GPUs.
+ *                        (bp_ntt_fr with batch > 1) spread their independent columns over the GPUs.  Every GPU beyond the
+ *                        first is driven by a persistent host thread of the library (uploads, waits, epilogues in parallel).
+ *                        STATUS: the GPU-to-GPU copy branches have run on one card only (tests force them with
+ *                        BP_FORCE_PEER_COPIES=1 over device lists {0,0} / {0,0,0}); no run on distinct GPUs is recorded yet.
  *       one process per GPU (torch.distributed / MPI launchers): every rank owns a point range in a plain bp_init context,
  *                        leaves its partial sums in HBM (bp_msm_g1_blob_device), the caller all-gathers those buffers
  *                        over RCCL/xGMI and every rank combines them (bp_msm_blobs_combine): one collective, one D2H.
