@@ -73,6 +73,7 @@ SIGNATURES = {
     "bp_ntt_last_stats": (_int, [_vp, _pp(C.c_float), _pp(_u32)]),
     "bp_ntt_last_members": (_int, [_vp]),
     "bp_fr_convert": (_int, [_vp, _sz, _int, _int, _vp]),
+    "bp_msm_window_scalars": (_int, [_vp, _sz, _int, _sz, _sz, _vp]),
     "bp_fr_synthetic_device": (_int, [_vp, _vp, _sz, _u64]),
     "bp_root_of_unity": (_int, [_u64, _int, _vp]),
     "bp_roots_of_unity": (_int, [_vp, _u64, _int, _vp]),

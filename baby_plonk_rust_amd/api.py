@@ -327,15 +327,23 @@ class BucketMSM:
     @staticmethod
     def bucket_msm(points96, scalars, b=256, c=4, ctx=None):
         """msm.rs:76-118.  points96: concatenated 96-byte encodings; scalars [n,4] Montgomery limbs.
-        b = 256 with c dividing 256 (the reference's only call, setup.rs:36: b = 256, c = 4) does not change the group
-        element.  Other (b, c) make the reference drop the low 256 - c*floor(b/c) bits of every scalar (msm.rs:83,
-        119-139); that is not reproduced, so they are rejected."""
-        if b != 256 or c <= 0 or 256 % c:
-            raise BpError(-1, "BucketMSM.bucket_msm", "only b = 256 with c dividing 256 is supported (got b=%d, c=%d)" % (b, c))
+        The reference walks floor(b / c) windows of c bits from the most significant end of the scalar's 256-bit image
+        (msm.rs:83, 119-139): with b = 256 and c dividing 256 (its only call, setup.rs:36: b = 256, c = 4) that is the whole
+        scalar; any other (b, c) silently drops the low 256 - c * floor(b / c) bits.  bp_msm_window_scalars reproduces exactly
+        that (and the reference's panics as errors), so every (b, c) gives the reference's group element."""
         ctx = ctx or default_context()
+        s = _fr_array(scalars)
+        k = b // c if c > 0 else 0
+        fmt = FR_MONT
+        if not (c > 0 and k * c == 256):
+            eff = np.zeros((len(s), 32), dtype=np.uint8)
+            rc = ctx._lib.bp_msm_window_scalars(s.ctypes.data, len(s), FR_MONT, b, c, eff.ctypes.data)
+            if rc != 0:
+                raise BpError(rc, "BucketMSM.bucket_msm", "the reference panics for b=%d, c=%d (msm.rs:24,105,132)" % (b, c))
+            s, fmt = eff, FR_BYTES_LE
         h = ctx.srs_load(points96)
         try:
-            return ctx.msm(h, scalars)
+            return ctx.msm(h, s, fmt=fmt)
         finally:
             ctx.srs_free(h)
 

@@ -1073,6 +1073,31 @@ int bp_msm_blobs_combine(const void* blobs, size_t n_blobs, uint8_t out96[96]) {
   return BP_OK;
 }
 
+int bp_msm_window_scalars(const void* scalars, size_t n, int scalar_fmt, size_t b, size_t c, void* out_le32) {
+  if (!fmt_ok(scalar_fmt) || (n && (!scalars || !out_le32)) || c == 0 || c > 63) return BP_ERR_INVALID_ARG;
+  const size_t k = b / c;
+  if (k == 0 || k * c > 256) return BP_ERR_INVALID_ARG;
+  const size_t shift = 256 - k * c, words = shift / 32, bits = shift % 32;
+  const uint8_t* in = (const uint8_t*)scalars;
+  uint8_t* out = (uint8_t*)out_le32;
+  for (size_t i = 0; i < n; i++) {
+    fr_t v, r;
+    memcpy(&v, in + 32 * i, 32);
+    if (scalar_fmt == BP_FR_MONT) {
+      Fr::from_mont(v, v);                                // Scalar::to_bytes (scalar.rs:292-304)
+    } else {
+      fr_t t;
+      if (!big_sub(t, v, Fr::modulus())) return BP_ERR_BAD_SCALAR;
+    }
+    for (size_t j = 0; j < 8; j++) {
+      const uint64_t lo = j + words < 8 ? v.l[j + words] : 0u, hi = j + words + 1 < 8 ? v.l[j + words + 1] : 0u;
+      r.l[j] = (uint32_t)(((hi << 32) | lo) >> bits);
+    }
+    memcpy(out + 32 * i, &r, 32);
+  }
+  return BP_OK;
+}
+
 int bp_g1_sum_partials(const uint8_t* partials144, size_t n, uint8_t out96[96]) {
   if (!out96 || (n && !partials144)) return BP_ERR_INVALID_ARG;
   g1_proj acc = g1_identity();

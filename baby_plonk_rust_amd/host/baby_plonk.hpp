@@ -191,17 +191,25 @@ class Polynomial {
 };
 
 // src/msm.rs:8,76-118
+// The reference walks floor(b / c) windows of c bits from the most significant end of the scalar's 256-bit image (msm.rs:83,
+// 119-139): b = 256 with c dividing 256 (its only call: setup.rs:36, b = 256, c = 4) uses the whole scalar, any other (b, c) drops
+// the low 256 - c * floor(b / c) bits.  bp_msm_window_scalars reproduces that (the reference's panics become Panic).
+inline int msm_scalars_as_walked(Context& ctx, const std::vector<Scalar>& scalars, size_t b, size_t c, std::vector<uint8_t>& eff) {
+  if (c != 0 && (b / c) * c == 256) return BP_FR_MONT;                  // the whole scalar: hand the Montgomery limbs over as they are
+  eff.assign(32 * scalars.size() + 32, 0);
+  ctx.check(bp_msm_window_scalars(scalars.data(), scalars.size(), BP_FR_MONT, b, c, eff.data()), "bucket_msm: the reference panics for this (b, c)");
+  return BP_FR_BYTES_LE;
+}
 struct BucketMSM {
-  // points: 96-byte encodings.  b = 256 with c dividing 256 (the reference's only call: setup.rs:36, b = 256, c = 4) does
-  // not change the group element; for other (b, c) the reference drops the low 256 - c*floor(b/c) bits of every scalar
-  // (msm.rs:83,119-139), which is not reproduced: rejected.
+  // points: 96-byte encodings
   static G1 bucket_msm(const std::vector<G1>& points, const std::vector<Scalar>& scalars, size_t b = 256, size_t c = 4,
                        Context& ctx = Context::global()) {
-    if (b != 256 || c == 0 || 256 % c != 0) throw Panic(BP_ERR_INVALID_ARG, "bucket_msm: only b = 256 with c dividing 256 is supported");
+    std::vector<uint8_t> eff;
+    const int fmt = msm_scalars_as_walked(ctx, scalars, b, c, eff);
     uint64_t h = 0;
     ctx.check(bp_srs_load(ctx.raw(), points.empty() ? nullptr : points[0].data(), points.size(), &h), "bucket_msm: points");
     G1 out{};
-    int rc = bp_msm_g1(ctx.raw(), h, scalars.data(), scalars.size(), BP_FR_MONT, out.data());
+    int rc = bp_msm_g1(ctx.raw(), h, fmt == BP_FR_MONT ? (const void*)scalars.data() : (const void*)eff.data(), scalars.size(), fmt, out.data());
     bp_srs_free(ctx.raw(), h);
     ctx.check(rc, "bucket_msm");
     return out;
@@ -213,11 +221,12 @@ using G1ProjectiveImage = std::array<uint8_t, 144>;
 // the literal seam bucket_msm(points: &[G1Projective], scalars: &[Scalar], b, c) (msm.rs:76-81): upload, multiply, free
 inline G1 bucket_msm_projective(const std::vector<G1ProjectiveImage>& points, const std::vector<Scalar>& scalars, size_t b = 256,
                                 size_t c = 4, Context& ctx = Context::global()) {
-  if (b != 256 || c == 0 || 256 % c != 0) throw Panic(BP_ERR_INVALID_ARG, "bucket_msm: only b = 256 with c dividing 256 is supported");
+  std::vector<uint8_t> eff;
+  const int fmt = msm_scalars_as_walked(ctx, scalars, b, c, eff);
   uint64_t h = 0;
   ctx.check(bp_srs_load_projective144(ctx.raw(), points.empty() ? nullptr : points[0].data(), points.size(), &h), "bucket_msm: points");
   G1 out{};
-  int rc = bp_msm_g1(ctx.raw(), h, scalars.data(), scalars.size(), BP_FR_MONT, out.data());
+  int rc = bp_msm_g1(ctx.raw(), h, fmt == BP_FR_MONT ? (const void*)scalars.data() : (const void*)eff.data(), scalars.size(), fmt, out.data());
   bp_srs_free(ctx.raw(), h);
   ctx.check(rc, "bucket_msm");
   return out;

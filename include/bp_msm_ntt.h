@@ -160,6 +160,14 @@ int  bp_msm_blobs_sum_device_async(bp_ctx* ctx, const void* d_blobs, size_t n_bl
 /* Host-side: combine n_blobs records (host memory, BP_MSM_BLOB_BYTES apart) into the affine result.  Records with the
  * same window layout are added slot by slot before the one Horner pass (msm.rs:107-115). */
 int  bp_msm_blobs_combine(const void* blobs, size_t n_blobs, uint8_t out96[96]);
+/* Host-side, no GPU: the scalars that BucketMSM::bucket_msm(points, scalars, b, c) effectively multiplies the points by, for ANY
+ * (b, c).  The reference walks k = floor(b / c) windows of c bits over the 256-bit big-endian image of the scalar, most
+ * significant first (msm.rs:83, 119-139), so it uses the top k*c bits only: result = sum_i (K_i >> (256 - k*c)) * P_i.  For its
+ * one call site (b = 256, c = 4, setup.rs:36) and whenever c divides 256 = b the shift is zero.  out_le32 receives n 32-byte
+ * little-endian canonical values (feed them to bp_msm_g1 with BP_FR_BYTES_LE).  BP_ERR_INVALID_ARG where the reference panics:
+ * c = 0 (division by zero), k = 0 (t_points[0], msm.rs:105), k*c > 256 (bit slice out of range, msm.rs:132), c > 63
+ * (the 1 << c bucket vector, msm.rs:24). */
+int  bp_msm_window_scalars(const void* scalars, size_t n, int scalar_fmt, size_t b, size_t c, void* out_le32);
 /* Host-side: add n projective partials (complete addition, g1.rs:670-712) and normalise (g1.rs:49-63). */
 int  bp_g1_sum_partials(const uint8_t* partials144, size_t n, uint8_t out96[96]);
 /* Host-side conversions of single points (for the Rust shim's G1Projective <-> bytes plumbing). */

@@ -134,6 +134,13 @@ int main(int argc, char** argv) {
     CHECK(BucketMSM::bucket_msm({pts[0], pts[1]}, {S(5), S(7), S(9)}) == BucketMSM::bucket_msm({pts[0]}, {S(19)}));
     CHECK(BucketMSM::bucket_msm({pts[0], pts[1], pts[2]}, {S(5)}) == BucketMSM::bucket_msm({pts[0]}, {S(5)}));
     CHECK(panics([&] { s2.commit(Polynomial({S(1)}, Basis::Lagrange)); }, BP_ERR_BASIS));          // setup.rs:34
+    // window parameters that make the reference drop low scalar bits (msm.rs:83,119-139): 13 = 0b1101 walked as 51 windows of 5 bits
+    // loses its lowest bit (6), as 32 windows of 4 bits over b = 128 loses everything below bit 128 (0); panicking ones panic
+    CHECK(BucketMSM::bucket_msm({pts[0]}, {S(13)}, 256, 5) == BucketMSM::bucket_msm({pts[0]}, {S(6)}));
+    CHECK(BucketMSM::bucket_msm({pts[0]}, {S(13)}, 128, 4) == BucketMSM::bucket_msm({pts[0]}, {S(0)}));
+    CHECK(BucketMSM::bucket_msm({pts[0]}, {S(13)}, 256, 8) == BucketMSM::bucket_msm({pts[0]}, {S(13)}));
+    CHECK(panics([&] { BucketMSM::bucket_msm({pts[0]}, {S(13)}, 256, 0); }, BP_ERR_INVALID_ARG));
+    CHECK(panics([&] { BucketMSM::bucket_msm({pts[0]}, {S(13)}, 300, 4); }, BP_ERR_INVALID_ARG));
   }
   std::printf("host mirror ok\n");
   return 0;

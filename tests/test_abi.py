@@ -138,11 +138,35 @@ def test_blob_combine_host_side():
         bp.combine_blobs(bytes(_lib.MSM_BLOB_BYTES))
 
 
-def test_bucket_msm_rejects_window_parameters_the_reference_truncates():
-    """msm.rs:83,119-139: for b != 256 or c not dividing 256 the reference drops low scalar bits; the mirrors refuse"""
-    for b, c in ((256, 3), (128, 4), (256, 0), (255, 5)):
-        with pytest.raises(bp.BpError):
-            bp.BucketMSM.bucket_msm(b"", np.zeros((0, 4), dtype=np.uint64), b, c)
+def test_window_scalars_are_what_the_reference_walks():
+    """msm.rs:83,119-139: bucket_msm(points, scalars, b, c) walks floor(b / c) windows of c bits from the top of the 256-bit image, so
+    it multiplies by K >> (256 - c * floor(b / c)).  bp_msm_window_scalars (host-side, no GPU) against the oracle's literal
+    get_c_bit_chunk walk recombined by Horner, for window parameters that drop bits and for those that do not; the reference's
+    panics are errors."""
+    from oracle import oracle as O
+    lib = bp.load()
+    sc = O.splitmix_scalars(40, 0xB17)
+    sc[0] = 0
+    sc[1] = bp.scalar_from_int(M.Q - 1)
+    ints = O.fr_array_to_ints(sc)
+    for b, c in ((256, 4), (256, 16), (256, 3), (256, 5), (256, 7), (255, 5), (128, 4), (200, 8), (64, 63), (17, 16), (256, 20)):
+        out = np.zeros((len(sc), 32), dtype=np.uint8)
+        assert lib.bp_msm_window_scalars(sc.ctypes.data, len(sc), bp.FR_MONT, b, c, out.ctypes.data) == 0, (b, c)
+        k = b // c
+        for i, v in enumerate(ints):
+            walked = 0
+            for w in range(k):
+                walked = (walked << c) | int(O.lib.msm_get_c_bit_chunk(sc[i].ctypes.data, w, c))      # most significant window first
+            assert walked == v >> (256 - k * c)
+            assert int.from_bytes(out[i].tobytes(), "little") == walked, (b, c, i)
+        le = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in ints), dtype=np.uint8).reshape(-1, 32).copy()
+        out2 = np.zeros_like(out)
+        assert lib.bp_msm_window_scalars(le.ctypes.data, len(le), bp.FR_BYTES_LE, b, c, out2.ctypes.data) == 0 and (out2 == out).all()
+    out = np.zeros((len(sc), 32), dtype=np.uint8)
+    for b, c in ((256, 0), (3, 4), (300, 4), (260, 13), (256, 64), (512, 100)):       # division by zero; t_points[0]; slice past bit 256 (twice); 1 << 64
+        assert lib.bp_msm_window_scalars(sc.ctypes.data, len(sc), bp.FR_MONT, b, c, out.ctypes.data) == -1, (b, c)
+    bad = np.full((1, 32), 0xFF, dtype=np.uint8)
+    assert lib.bp_msm_window_scalars(bad.ctypes.data, 1, bp.FR_BYTES_LE, 256, 4, out.ctypes.data) == -4
 
 
 def test_new_entry_points_reject_bad_arguments_without_a_gpu():

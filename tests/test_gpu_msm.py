@@ -217,3 +217,19 @@ def test_odd_sizes_vs_oracle(ctx, n):
         aff = O.points_progression(n, a, d)
         assert got == O.g1_bytes96(O.bucket_msm(O.affine_to_proj(aff), sc, threads=NTHREADS))
     ctx.srs_free(h)
+
+
+@pytest.mark.parametrize("b,c", [(256, 4), (256, 8), (256, 3), (256, 5), (255, 5), (128, 4), (200, 8), (17, 16)])
+def test_bucket_msm_any_window_parameters_vs_oracle(ctx, b, c):
+    """BucketMSM::bucket_msm(points, scalars, b, c) for window parameters other than the reference's one call site (256, 4): the
+    reference then drops the low 256 - c * floor(b / c) bits of every scalar (msm.rs:83, 119-139).  The mirror reproduces the
+    oracle's literal restatement byte for byte (VERDICT r02 missing #6); parameters that make the reference panic raise."""
+    n = 300
+    aff = O.points_progression(n, 0xABCDEF, 0x13579)
+    sc = O.splitmix_scalars(n, 0xB0C0 + b + c)
+    sc[3] = bp.scalar_from_int(Q - 1)
+    want = O.g1_bytes96(O.bucket_msm(O.affine_to_proj(aff), sc, b, c, threads=NTHREADS))
+    assert bp.BucketMSM.bucket_msm(bytes(O.points_to_bytes96(aff)), sc, b, c, ctx) == want
+    for bad_b, bad_c in ((256, 0), (3, 4), (300, 4), (256, 64)):
+        with pytest.raises(bp.BpError):
+            bp.BucketMSM.bucket_msm(bytes(O.points_to_bytes96(aff)), sc, bad_b, bad_c, ctx)
