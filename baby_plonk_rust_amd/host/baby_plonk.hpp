@@ -195,7 +195,7 @@ class Polynomial {
 // 119-139): b = 256 with c dividing 256 (its only call: setup.rs:36, b = 256, c = 4) uses the whole scalar, any other (b, c) drops
 // the low 256 - c * floor(b / c) bits.  bp_msm_window_scalars reproduces that (the reference's panics become Panic).
 inline int msm_scalars_as_walked(Context& ctx, const std::vector<Scalar>& scalars, size_t b, size_t c, std::vector<uint8_t>& eff) {
-  if (c != 0 && (b / c) * c == 256) return BP_FR_MONT;                  // the whole scalar: hand the Montgomery limbs over as they are
+  if (c != 0 && c <= 63 && (b / c) * c == 256) return BP_FR_MONT;       // the whole scalar: hand the Montgomery limbs over as they are
   eff.assign(32 * scalars.size() + 32, 0);
   ctx.check(bp_msm_window_scalars(scalars.data(), scalars.size(), BP_FR_MONT, b, c, eff.data()), "bucket_msm: the reference panics for this (b, c)");
   return BP_FR_BYTES_LE;
