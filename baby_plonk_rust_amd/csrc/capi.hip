@@ -313,6 +313,22 @@ static int ctx_create(bp_ctx** out, int device_id) {
   return BP_OK;
 }
 
+namespace bp {
+int side_ctx_get(bp_ctx* ctx, bp_ctx** out) {
+  if (!ctx->side) {
+    bp_ctx* sd = nullptr;
+    int rc = ctx_create(&sd, ctx->device);
+    if (rc != BP_OK) return fail(ctx, rc, "side context", hipSuccess, __FILE__, __LINE__);
+    ctx->side = sd;
+    DeviceGuard guard(ctx->device);
+    for (auto& e : ctx->side_ev)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(ctx, BP_ERR_HIP, "side events", hipGetLastError(), __FILE__, __LINE__);
+  }
+  *out = ctx->side;
+  return BP_OK;
+}
+}  // namespace bp
+
 extern "C" {
 
 const char* bp_version(void) { return "bp_msm_ntt 0.2 (gfx950)"; }
@@ -374,6 +390,16 @@ void bp_destroy(bp_ctx* ctx) {
   ctx->members.clear();
   for (bp_ctx* lane : ctx->lanes) bp_destroy(lane);
   ctx->lanes.clear();
+  if (ctx->side) {
+    bp_destroy(ctx->side);
+    ctx->side = nullptr;
+  }
+  for (auto& e : ctx->side_ev)
+    if (e) {
+      DeviceGuard guard(ctx->device);
+      (void)hipEventDestroy(e);
+      e = nullptr;
+    }
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)stream_wait(ctx->stream);
   for (auto& kv : ctx->ws)

@@ -79,6 +79,11 @@ struct bp_ctx {
   // one caller -- the three of prover rounds 1 and 3, the two of round 5, the verifier's eight -- run on them concurrently,
   // so one MSM's latency-bound tail (bucket tree, fix-up, scans) overlaps another's bulk kernel.
   std::vector<bp_ctx*> lanes;
+  // One more single-device context on this device for prover work that does not wait for a Fiat-Shamir challenge (the coset
+  // evaluations of a, b, c and PI, prover.rs:386-450, are known after round 1): enqueued beside rounds 1-2, it fills the GPU time
+  // the commitments' latency-bound tails and the host's transcript steps leave idle.  side_ev: [0] inputs ready, [1] side work done.
+  bp_ctx* side = nullptr;
+  hipEvent_t side_ev[2] = {nullptr, nullptr};
   hipStream_t stream = nullptr;
   bool own_stream = true;
   std::string last_error;
@@ -189,6 +194,7 @@ int fr_convert_run(bp_ctx* ctx, fr_t* d, size_t n, int dir);
 int fr_binary_run(bp_ctx* ctx, const fr_t* a, size_t na, const fr_t* b, size_t nb, fr_t* out, size_t n, int op);
 int fr_scalar_run(bp_ctx* ctx, const fr_t* a, const fr_t& s, fr_t* out, size_t n, int op);
 int poly_eval_run(bp_ctx* ctx, const fr_t* d_coeffs, size_t n, const fr_t& x, fr_t* host_out);
+int poly_eval_many_run(bp_ctx* ctx, int k, const fr_t* const* d_coeffs, const size_t* n, const fr_t* x, fr_t* host_out);
 int poly_div_run(bp_ctx* ctx, fr_t* d_a, size_t na, const fr_t* d_b, size_t nb, const fr_t& b0, const fr_t& b_lead, bool binomial,
                  fr_t* d_q, size_t nq);
 int fr_nonzero_stats_run(bp_ctx* ctx, const fr_t* d_a, size_t n, size_t lo, size_t hi, size_t* eff_len, size_t* nonzero_in_range);
@@ -205,6 +211,7 @@ int srs_encode_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, uint8_t* d_byte
 int srs_from_projective_run(bp_ctx* ctx, const g1_proj* d_in, size_t n, g1_affine* d_out);
 int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t first, size_t n, g1_affine* d_out);
 
+int side_ctx_get(bp_ctx* ctx, bp_ctx** out);       // creates ctx->side and its events on first use (capi.hip)
 int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out);
 void circuit_release(CircuitEntry& e);
 int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_wit, const fr_t blind[11], uint8_t proof[624]);

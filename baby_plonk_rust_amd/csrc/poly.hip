@@ -21,11 +21,44 @@ int poly_eval_run(bp_ctx* ctx, const fr_t* d_coeffs, size_t n, const fr_t& x, fr
   const unsigned blocks = (unsigned)((lanes + 255) / 256);
   fr_t *partial, *result;
   BP_TRY(ws_get(ctx, "poly.partial", (size_t)blocks * sizeof(fr_t), (void**)&partial));
-  BP_TRY(ws_get(ctx, "poly.result", sizeof(fr_t), (void**)&result));
+  BP_TRY(ws_get(ctx, "poly.result", 16 * sizeof(fr_t), (void**)&result));
   hipLaunchKernelGGL(poly_eval_partial, dim3(blocks), dim3(256), 256 * sizeof(fr_t), ctx->stream, d_coeffs, n, x, K, partial);
   hipLaunchKernelGGL(fr_sum_small, dim3(1), dim3(256), 256 * sizeof(fr_t), ctx->stream, partial, blocks, result);
   BP_HIP(ctx, hipGetLastError());
   BP_HIP(ctx, hipMemcpyAsync(host_out, result, sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
+  BP_HIP(ctx, stream_wait(ctx->stream));
+  return BP_OK;
+}
+
+// k evaluations enqueued together, one copy of the k results, one wait (the six of prover round 4, prover.rs:502-541: six
+// sequential calls were six stream waits of ~55 us each)
+int poly_eval_many_run(bp_ctx* ctx, int k, const fr_t* const* d_coeffs, const size_t* n, const fr_t* x, fr_t* host_out) {
+  if (k <= 0) return BP_OK;
+  if (k > 8) return fail(ctx, BP_ERR_INVALID_ARG, "poly_eval_many: more than 8 evaluations", hipSuccess, __FILE__, __LINE__);
+  PolyEvalMany a;
+  memset(&a, 0, sizeof a);
+  size_t total = 0;
+  unsigned max_blocks = 1;
+  for (int j = 0; j < k; j++) {
+    uint32_t K = 16;
+    while ((n[j] + K - 1) / K > 256 * 1024 && K < (1u << 20)) K <<= 1;
+    const size_t lanes = (n[j] + K - 1) / K;
+    a.c[j] = d_coeffs[j];
+    a.n[j] = n[j];
+    a.x[j] = x[j];
+    a.K[j] = K;
+    a.blocks[j] = (uint32_t)((lanes + 255) / 256);       // 0 for an empty polynomial: its sum over no partials is zero
+    a.off[j] = (uint32_t)total;
+    total += a.blocks[j];
+    max_blocks = std::max(max_blocks, (unsigned)a.blocks[j]);
+  }
+  fr_t *partial, *result;
+  BP_TRY(ws_get(ctx, "poly.partial", (total ? total : 1) * sizeof(fr_t), (void**)&partial));
+  BP_TRY(ws_get(ctx, "poly.result", 16 * sizeof(fr_t), (void**)&result));
+  hipLaunchKernelGGL(poly_eval_partial_many, dim3(max_blocks, (unsigned)k), dim3(256), 256 * sizeof(fr_t), ctx->stream, a, partial);
+  hipLaunchKernelGGL(fr_sum_small_many, dim3((unsigned)k), dim3(256), 256 * sizeof(fr_t), ctx->stream, a, partial, result);
+  BP_HIP(ctx, hipGetLastError());
+  BP_HIP(ctx, hipMemcpyAsync(host_out, result, (size_t)k * sizeof(fr_t), hipMemcpyDeviceToHost, ctx->stream));
   BP_HIP(ctx, stream_wait(ctx->stream));
   return BP_OK;
 }

@@ -51,6 +51,48 @@ __global__ void __launch_bounds__(256) poly_eval_partial(const fr_t* __restrict_
   fr_t s = block_sum_fr(acc);
   if (threadIdx.x == 0) store_fr(&partial[blockIdx.x], s);
 }
+// the same for up to 8 polynomials in ONE launch (blockIdx.y = polynomial): each alone is half a wave round of lanes and therefore
+// latency bound (43 us: 16 Horner steps + x^(16 t) per lane); together they fill the chip
+struct PolyEvalMany {
+  const fr_t* c[8];
+  size_t n[8];
+  fr_t x[8];
+  uint32_t K[8];
+  uint32_t off[8];        // first partial slot of polynomial j
+  uint32_t blocks[8];
+};
+__global__ void __launch_bounds__(256) poly_eval_partial_many(PolyEvalMany a, fr_t* __restrict__ partial) {
+  const uint32_t j = blockIdx.y;
+  if (blockIdx.x >= a.blocks[j]) return;
+  const fr_t* __restrict__ c = a.c[j];
+  const size_t n = a.n[j];
+  const uint32_t K = a.K[j];
+  const fr_t x = a.x[j];
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lo = t * K, hi = lo + K < n ? lo + K : n;
+  fr_t acc = Fr::zero();
+  if (lo < n) {
+    for (size_t i = hi; i-- > lo;) {
+      Fr::mul(acc, acc, x);
+      fr_t ci = load_fr(&c[i]);
+      Fr::add(acc, acc, ci);
+    }
+    fr_t xp = fr_pow_u64(x, lo);
+    Fr::mul(acc, acc, xp);
+  }
+  fr_t s = block_sum_fr(acc);
+  if (threadIdx.x == 0) store_fr(&partial[a.off[j] + blockIdx.x], s);
+}
+__global__ void __launch_bounds__(256) fr_sum_small_many(PolyEvalMany a, const fr_t* __restrict__ partial, fr_t* __restrict__ out) {
+  const uint32_t j = blockIdx.x;
+  fr_t acc = Fr::zero();
+  for (uint32_t i = threadIdx.x; i < a.blocks[j]; i += blockDim.x) {
+    fr_t v = load_fr(&partial[a.off[j] + i]);
+    Fr::add(acc, acc, v);
+  }
+  fr_t s = block_sum_fr(acc);
+  if (threadIdx.x == 0) store_fr(&out[j], s);
+}
 __global__ void __launch_bounds__(256) fr_sum_small(const fr_t* __restrict__ in, uint32_t n, fr_t* __restrict__ out) {
   fr_t acc = Fr::zero();
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {

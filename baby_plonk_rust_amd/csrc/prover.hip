@@ -226,6 +226,7 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   const size_t n = (size_t)1 << k, N = 4 * n;
   const fr_t omega = root_of_unity(n), k1 = from_u64(2), k2 = from_u64(3), one = Fr::one();      // prover.rs:99-100
   hipStream_t st = ctx->stream;
+  if (ctx->side) BP_HIP(ctx, stream_wait(ctx->side->stream));     // side work of a proof that was abandoned half way must not outlive its buffers
   const double t_start = now_ms();
   PlonkTranscript tr;
   g1_proj cm[9];
@@ -243,10 +244,39 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
     hipLaunchKernelGGL(fr_blind, dim3(blocks_n), dim3(256), 0, st, coefs + (size_t)j * n, n, blind[2 * j + 1], blind[2 * j], Fr::zero(), 2u,
                        poly_abc[j]);
   BP_HIP(ctx, hipGetLastError());
+  // Round 3's evaluations of a, b, c and PI on the quotient coset (prover.rs:386-450) depend on no challenge: they are enqueued on the
+  // side context's stream once round 1's commitments are in (beside them they only took the GPU from three concurrent pipelines:
+  // +2.6 ms on round 1 for -1.9 on round 3) and run beside round 2 -- one commitment, whose sort and tree leave most of the chip idle,
+  // and the host's transcript steps.  Round 3 waits for the second event and transforms z alone.  BP_PROVE_SIDE=0: all five in round 3.
+  fr_t* ev;
+  BP_TRY(ws_get(ctx, "prove.coset_wit", 5 * N * sizeof(fr_t), (void**)&ev));         // a | b | c | z | PI evaluations
+  const unsigned blocks_N = (unsigned)((N + 255) / 256);
+  bool side_on = true;
+  {
+    const char* v = getenv("BP_PROVE_SIDE");
+    if (v && *v == '0') side_on = false;
+  }
   {                                       // three independent commitments in flight together (commit_many)
     const fr_t* polys[3] = {poly_abc[0], poly_abc[1], poly_abc[2]};
     const size_t lens[3] = {n + 2, n + 2, n + 2};
     BP_TRY(commit_many(ctx, srs, polys, lens, 3, &cm[0]));
+  }
+  bp_ctx* side = nullptr;
+  if (side_on) {
+    BP_TRY(side_ctx_get(ctx, &side));
+    BP_HIP(ctx, hipEventRecord(ctx->side_ev[0], st));
+    hipStream_t ss = side->stream;
+    BP_HIP(ctx, hipStreamWaitEvent(ss, ctx->side_ev[0], 0));
+    for (int j = 0; j < 3; j++) hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, ss, poly_abc[j], n + 2, cir.g_pow, ev + (size_t)j * N, N);
+    hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, ss, coefs + 3 * n, n, cir.g_pow, ev + 4 * N, N);
+    BP_HIP(ctx, hipGetLastError());
+    int rc = ntt_run(side, ev, k + 2, 0, 3, N);
+    if (rc == BP_OK) rc = ntt_run(side, ev + 4 * N, k + 2, 0, 1, N);
+    if (rc != BP_OK) {
+      ctx->last_error = side->last_error;
+      return rc;
+    }
+    BP_HIP(ctx, hipEventRecord(ctx->side_ev[1], ss));
   }
   tr.point("a_1", cm[0]); tr.point("b_1", cm[1]); tr.point("c_1", cm[2]);
   const fr_t beta = tr.challenge("beta"), gamma = tr.challenge("gamma");
@@ -265,15 +295,20 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   const double t_r2 = now_ms();
 
   // ---- round 3 (prover.rs:370-500): quotient on the coset g <w_4n>
-  fr_t *ev, *t;
-  BP_TRY(ws_get(ctx, "prove.coset_wit", 5 * N * sizeof(fr_t), (void**)&ev));         // a | b | c | z | PI evaluations
+  fr_t* t;
   BP_TRY(ws_get(ctx, "prove.t", (N + 16) * sizeof(fr_t), (void**)&t));
-  const unsigned blocks_N = (unsigned)((N + 255) / 256);
-  for (int j = 0; j < 3; j++) hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, poly_abc[j], n + 2, cir.g_pow, ev + (size_t)j * N, N);
-  hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, z_coeff, n + 3, cir.g_pow, ev + 3 * N, N);
-  hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, coefs + 3 * n, n, cir.g_pow, ev + 4 * N, N);
-  BP_HIP(ctx, hipGetLastError());
-  BP_TRY(ntt_run(ctx, ev, k + 2, 0, 5, N));
+  if (side_on) {
+    hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, z_coeff, n + 3, cir.g_pow, ev + 3 * N, N);
+    BP_HIP(ctx, hipGetLastError());
+    BP_TRY(ntt_run(ctx, ev + 3 * N, k + 2, 0, 1, N));
+    BP_HIP(ctx, hipStreamWaitEvent(st, ctx->side_ev[1], 0));                         // a, b, c, PI: transformed beside rounds 1-2
+  } else {
+    for (int j = 0; j < 3; j++) hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, poly_abc[j], n + 2, cir.g_pow, ev + (size_t)j * N, N);
+    hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, z_coeff, n + 3, cir.g_pow, ev + 3 * N, N);
+    hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, coefs + 3 * n, n, cir.g_pow, ev + 4 * N, N);
+    BP_HIP(ctx, hipGetLastError());
+    BP_TRY(ntt_run(ctx, ev, k + 2, 0, 5, N));
+  }
   QuotientArgs qa;
   qa.alpha = alpha; qa.alpha2 = fmul(alpha, alpha); qa.beta = beta; qa.gamma = gamma;
   qa.beta_k1 = fmul(beta, k1); qa.beta_k2 = fmul(beta, k2); qa.one = one;
@@ -315,19 +350,21 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   // ---- round 4 (prover.rs:502-541): evaluations at zeta (z at zeta w)
   const fr_t *s1c = cir.coef + 5 * n, *s2c = cir.coef + 6 * n, *s3c = cir.coef + 7 * n;
   fr_t a_bar, b_bar, c_bar, s1_bar, s2_bar, zw_bar, pi_zeta;
-  BP_TRY(poly_eval_run(ctx, poly_abc[0], n + 2, zeta, &a_bar));
-  BP_TRY(poly_eval_run(ctx, poly_abc[1], n + 2, zeta, &b_bar));
-  BP_TRY(poly_eval_run(ctx, poly_abc[2], n + 2, zeta, &c_bar));
-  BP_TRY(poly_eval_run(ctx, s1c, n, zeta, &s1_bar));
-  BP_TRY(poly_eval_run(ctx, s2c, n, zeta, &s2_bar));
-  BP_TRY(poly_eval_run(ctx, z_coeff, n + 3, fmul(zeta, omega), &zw_bar));           // z_omega(zeta) = z(zeta w), :661-674
+  {                                        // the six evaluations (and PI(zeta), which round 5 wants) in one enqueue and one wait
+    const fr_t* polys[7] = {poly_abc[0], poly_abc[1], poly_abc[2], s1c, s2c, z_coeff, coefs + 3 * n};
+    const size_t lens[7] = {n + 2, n + 2, n + 2, n, n, n + 3, n};
+    const fr_t zw = fmul(zeta, omega);                                               // z_omega(zeta) = z(zeta w), :661-674
+    const fr_t at[7] = {zeta, zeta, zeta, zeta, zeta, zw, zeta};
+    fr_t vals[7];
+    BP_TRY(poly_eval_many_run(ctx, 7, polys, lens, at, vals));
+    a_bar = vals[0]; b_bar = vals[1]; c_bar = vals[2]; s1_bar = vals[3]; s2_bar = vals[4]; zw_bar = vals[5]; pi_zeta = vals[6];
+  }
   tr.scalar("a_eval", a_bar); tr.scalar("b_eval", b_bar); tr.scalar("c_eval", c_bar);
   tr.scalar("s1_eval", s1_bar); tr.scalar("s2_eval", s2_bar); tr.scalar("z_shifted_eval", zw_bar);
   const fr_t nu = tr.challenge("nu");
   const double t_r4 = now_ms();
 
   // ---- round 5 (prover.rs:543-647): linearisation r and the two opening quotients
-  BP_TRY(poly_eval_run(ctx, coefs + 3 * n, n, zeta, &pi_zeta));
   const fr_t zeta_n = fpow(zeta, n), zh_zeta = fsub(zeta_n, one);
   // L1(zeta) = (1/n) sum_i zeta^i  (l1_coeff.coeffs_evaluate, :590)
   const fr_t l1_zeta = big_eq(zeta, one) ? one : fmul(zh_zeta, finv(fmul(from_u64(n), fsub(zeta, one))));
