@@ -1266,9 +1266,12 @@ static int ntt_columns_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, 
 // Returns 1 (not an error code of the ABI) when the shape does not split; only then does the caller run the transform on the
 // leader.  Any other failure is returned as it is: the download phase writes `data` from every member at once, so after a
 // failed copy the buffer may be part input, part output, and must not be transformed again.
-static uint32_t env_u32(const char* name, uint32_t dflt) {
+static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {        // out-of-range or malformed: the default
   const char* v = getenv(name);
-  return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+  if (!v || !*v) return dflt;
+  char* end = nullptr;
+  const unsigned long x = strtoul(v, &end, 10);
+  return (end == v || *end || x < lo || x > hi) ? dflt : (uint32_t)x;
 }
 static int ntt_one_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, int inverse, int scalar_fmt) {
   const std::vector<bp_ctx*> sh = shards_of(ctx);
@@ -1354,7 +1357,7 @@ int bp_ntt_fr(bp_ctx* ctx, void* data, uint32_t log_n, int inverse, int scalar_f
   if (batch > 1 && stride < N) return fail(ctx, BP_ERR_INVALID_ARG, "NTT stride < N", hipSuccess, __FILE__, __LINE__);
   if (batch > 65535) return fail(ctx, BP_ERR_TOO_LARGE, "NTT batch > 65535", hipSuccess, __FILE__, __LINE__);
   if (is_group(ctx) && batch > 1) return ntt_columns_over_members(ctx, (uint8_t*)data, log_n, inverse, scalar_fmt, batch, stride);
-  if (is_group(ctx) && log_n >= env_u32("BP_NTT_GROUP_SPLIT_FROM", 22)) {     // one large transform: every member's PCIe link and a share of the work
+  if (is_group(ctx) && log_n >= env_u32("BP_NTT_GROUP_SPLIT_FROM", 22, 11, 29)) {     // one large transform: every member's PCIe link and a share of the work
     const int rc = ntt_one_over_members(ctx, (uint8_t*)data, log_n, inverse, scalar_fmt);
     if (rc != 1) return rc;                 // done, or a real failure (reported, never papered over: host data may be partly written);
   }                                         // 1 = the shape does not split over this many members: on the leader
