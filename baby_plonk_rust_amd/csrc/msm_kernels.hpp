@@ -960,8 +960,12 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
   const uint32_t p0 = (uint32_t)p0_64;
   const uint32_t p1 = (uint64_t)p0 + chunk < M ? p0 + chunk : M;
 
+  // bucket g = [g_start, g_end); g_end2 = the end of bucket g + 1, fetched one boundary ahead: leaving a bucket then costs no
+  // dependent load (the wave used to stall on offsets[g + 1] at every boundary -- four per lane at c = 20, where some lane of a
+  // wave leaves a bucket in most iterations -- and to re-read offsets[g] for the "whole bucket" test)
   uint32_t g = bucket_of(offsets, total, p0);
-  uint32_t g_end = offsets[g + 1];
+  uint32_t g_start = offsets[g], g_end = offsets[g + 1];
+  uint32_t g_end2 = g + 2 <= total ? offsets[g + 2] : M;
   uint32_t run_start = p0;
   g1_proj28 acc = g1_identity28();
   // software pipeline, two deep: while entry p is added, the gather of entry p+1 is in flight AND the index of entry p+2 is
@@ -972,16 +976,19 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
   g1_affine28 q_next = load_affine28(&points[e_cur & 0x7fffffffu]);
   for (uint32_t p = p0; p < p1; p++) {
     if (p >= g_end) {                            // leave bucket g: flush its run [run_start, p)
-      const bool complete = run_start == offsets[g];    // it ended at g_end by construction
+      const bool complete = run_start == g_start;       // it ended at g_end by construction
       store_proj28(complete ? &bucket_sum[g] : &partial[2 * (size_t)t + (run_start == p0 ? 0 : 1)], acc);
       acc = g1_identity28();
       run_start = p;
-      g++;                                        // the next bucket, or -- when that one is empty -- a binary search: with
-      g_end = offsets[g + 1];                     // skewed scalars (all equal: 13 non-empty buckets of 2^19) a linear walk over
-      if (p >= g_end) {                           // the empty buckets took 40 000 dependent loads per boundary lane (14 ms)
+      g_start = g_end;                            // the next bucket, or -- when that one is empty -- a binary search: with
+      g++;                                        // skewed scalars (all equal: 13 non-empty buckets of 2^19) a linear walk over
+      g_end = g_end2;                             // the empty buckets took 40 000 dependent loads per boundary lane (14 ms)
+      if (p >= g_end) {
         g = bucket_of(offsets, total, p);
+        g_start = offsets[g];
         g_end = offsets[g + 1];
       }
+      g_end2 = g + 2 <= total ? offsets[g + 2] : M;
     }
     const uint32_t e = e_cur;
     const g1_affine28 q = q_next;
@@ -993,7 +1000,7 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
     for (int j = 0; j < N28; j++) nz |= q.x.l[j] | q.y.l[j];
     if (nz) g1_add_mixed28(acc, q.x, pt_y_signed(q.y, (e >> 31) != 0));     // identity points (x = y = 0) add nothing
   }
-  const bool complete = run_start == offsets[g] && p1 == g_end;
+  const bool complete = run_start == g_start && p1 == g_end;
   store_proj28(complete ? &bucket_sum[g] : &partial[2 * (size_t)t + (run_start == p0 ? 0 : 1)], acc);
 }
 
