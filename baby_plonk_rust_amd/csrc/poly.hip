@@ -84,7 +84,18 @@ int poly_div_run(bp_ctx* ctx, fr_t* d_a, size_t na, const fr_t* d_b, size_t nb, 
     hipLaunchKernelGGL(poly_div_binomial_local, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, d_a, nq, m, f,
                        lead_inv, K, chunks, d_q, head);
     if (chunks > 1) {
-      if (chunks > 64 && m <= 4096)          // long chains: a workgroup per chain
+      if (chunks > 4096 && m <= 16) {        // very long chains (x - zeta at 2^20): G segments per chain, a workgroup each
+        uint32_t G = (uint32_t)((chunks + 1023) / 1024);
+        if (G > 64) G = 64;
+        fr_t *seg_map, *seg_carry;
+        BP_TRY(ws_get(ctx, "poly.div_seg_map", 2 * m * G * sizeof(fr_t), (void**)&seg_map));
+        BP_TRY(ws_get(ctx, "poly.div_seg_carry", m * G * sizeof(fr_t), (void**)&seg_carry));
+        hipLaunchKernelGGL(poly_div_binomial_carry_seg<0>, dim3((unsigned)m, G), dim3(1024), 2048 * sizeof(fr_t), ctx->stream, nq, m, f, K, chunks, G,
+                           head, seg_map, seg_carry, carry);
+        hipLaunchKernelGGL(poly_div_seg_scan, dim3((unsigned)m), dim3(64), 0, ctx->stream, G, seg_map, seg_carry);
+        hipLaunchKernelGGL(poly_div_binomial_carry_seg<1>, dim3((unsigned)m, G), dim3(1024), 2048 * sizeof(fr_t), ctx->stream, nq, m, f, K, chunks, G,
+                           head, seg_map, seg_carry, carry);
+      } else if (chunks > 64 && m <= 4096)   // long chains: a workgroup per chain
         hipLaunchKernelGGL(poly_div_binomial_carry_wg, dim3((unsigned)m), dim3(1024), 2048 * sizeof(fr_t), ctx->stream, nq, m, f, K, chunks,
                            head, carry);
       else

@@ -203,6 +203,107 @@ __global__ void __launch_bounds__(1024) poly_div_binomial_carry_wg(size_t nq, si
     Fr::add(c, head, t);
   }
 }
+// Very long chains (x - zeta against 2^20 coefficients: 32 768 chunks): the chain is cut into G segments, a workgroup each.
+// PHASE 0 composes every segment into one affine map (seg_map[r * G + g] = A | B); poly_div_seg_scan turns the G maps into the
+// carry entering each segment; PHASE 1 replays the segments from those carries and writes the per-chunk carries.  Sequential
+// depth 2 S + log2(lanes) per phase with S = chunks / (G * lanes) instead of chunks / lanes: the single workgroup above took
+// 289 us per division (two per proof) on one CU of 256.
+template <int PHASE>
+__global__ void __launch_bounds__(1024) poly_div_binomial_carry_seg(size_t nq, size_t m, fr_t f, uint32_t K, size_t chunks_per_chain, uint32_t G,
+                                                                    const fr_t* __restrict__ chunk_head, fr_t* __restrict__ seg_map,
+                                                                    const fr_t* __restrict__ seg_carry, fr_t* __restrict__ carry) {
+  const size_t r = blockIdx.x, g = blockIdx.y;
+  if (r >= m || r >= nq) return;
+  const size_t len = (nq - r + m - 1) / m;
+  const size_t seg = (chunks_per_chain + G - 1) / G, s0 = g * seg, s1 = s0 + seg < chunks_per_chain ? s0 + seg : chunks_per_chain;
+  const size_t S = (seg + blockDim.x - 1) / blockDim.x;
+  const size_t ck0 = s0 + (size_t)threadIdx.x * S < s1 ? s0 + (size_t)threadIdx.x * S : s1, ck1 = ck0 + S < s1 ? ck0 + S : s1;
+  const fr_t fK = fr_pow_u64(f, K);
+  fr_t A = Fr::one(), B = Fr::zero();
+  for (size_t ck = ck0; ck < ck1; ck++) {
+    const size_t j_hi = len > ck * K ? len - ck * K : 0;
+    if (j_hi == 0) break;
+    const size_t j_lo = j_hi > K ? j_hi - K : 0;
+    fr_t head = load_fr(&chunk_head[ck * m + r]), fp = (j_hi - j_lo == K) ? fK : fr_pow_u64(f, j_hi - j_lo);
+    Fr::mul(A, A, fp);
+    Fr::mul(B, B, fp);
+    Fr::add(B, B, head);
+  }
+  fr_t* bufA = reinterpret_cast<fr_t*>(poly_lds_raw);
+  fr_t* bufB = bufA + blockDim.x;
+  bufA[threadIdx.x] = A;
+  bufB[threadIdx.x] = B;
+  __syncthreads();
+  for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
+    const bool has = threadIdx.x >= d;
+    fr_t a1, b1;
+    if (has) { a1 = bufA[threadIdx.x - d]; b1 = bufB[threadIdx.x - d]; }
+    __syncthreads();
+    if (has) {
+      fr_t t;
+      Fr::mul(t, A, b1);
+      Fr::add(B, B, t);
+      Fr::mul(A, A, a1);
+      bufA[threadIdx.x] = A;
+      bufB[threadIdx.x] = B;
+    }
+    __syncthreads();
+  }
+  if (PHASE == 0) {
+    if (threadIdx.x == blockDim.x - 1) {
+      store_fr(&seg_map[2 * (r * G + g)], A);
+      store_fr(&seg_map[2 * (r * G + g) + 1], B);
+    }
+    return;
+  }
+  const fr_t cin = load_fr(&seg_carry[r * G + g]);                      // carry entering this segment
+  fr_t c = cin;
+  if (threadIdx.x) {                                                    // through the lanes before this one: A x + B
+    fr_t t;
+    Fr::mul(t, bufA[threadIdx.x - 1], cin);
+    Fr::add(c, t, bufB[threadIdx.x - 1]);
+  }
+  for (size_t ck = ck0; ck < ck1; ck++) {
+    store_fr(&carry[ck * m + r], c);
+    const size_t j_hi = len > ck * K ? len - ck * K : 0;
+    if (j_hi == 0) break;
+    const size_t j_lo = j_hi > K ? j_hi - K : 0;
+    fr_t head = load_fr(&chunk_head[ck * m + r]), fp = (j_hi - j_lo == K) ? fK : fr_pow_u64(f, j_hi - j_lo), t;
+    Fr::mul(t, c, fp);
+    Fr::add(c, head, t);
+  }
+}
+// carries entering the G <= 64 segments of chain blockIdx.x: inclusive scan of the segments' affine maps (one lane each,
+// Hillis-Steele in LDS: six levels), applied to a zero carry; segment g receives the B of the scan up to g - 1
+__global__ void __launch_bounds__(64) poly_div_seg_scan(uint32_t G, const fr_t* __restrict__ seg_map, fr_t* __restrict__ seg_carry) {
+  __shared__ fr_t bufA[64], bufB[64];
+  const size_t r = blockIdx.x;
+  const uint32_t g = threadIdx.x;
+  fr_t A = Fr::one(), B = Fr::zero();
+  if (g < G) {
+    A = load_fr(&seg_map[2 * (r * G + g)]);
+    B = load_fr(&seg_map[2 * (r * G + g) + 1]);
+  }
+  bufA[g] = A;
+  bufB[g] = B;
+  __syncthreads();
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    const bool has = g >= d;
+    fr_t a1, b1;
+    if (has) { a1 = bufA[g - d]; b1 = bufB[g - d]; }
+    __syncthreads();
+    if (has) {
+      fr_t t;
+      Fr::mul(t, A, b1);
+      Fr::add(B, B, t);
+      Fr::mul(A, A, a1);
+      bufA[g] = A;
+      bufB[g] = B;
+    }
+    __syncthreads();
+  }
+  if (g < G) store_fr(&seg_carry[r * G + g], g ? bufB[g - 1] : Fr::zero());
+}
 __global__ void __launch_bounds__(256) poly_div_binomial_apply(size_t nq, size_t m, fr_t f, uint32_t K, size_t chunks_per_chain,
                                                                 const fr_t* __restrict__ carry, fr_t* __restrict__ q) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
