@@ -334,7 +334,13 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     BP_TRY(ws_get(ctx, "msm.run_off", ((size_t)3 * n_final + 16) * 4, (void**)&roff));
     BP_TRY(ws_get(ctx, "msm.run_cur", (size_t)n_final * 4, (void**)&cur));
     BP_TRY(ws_get(ctx, "msm.run_long", ((size_t)n_final + 2) * 4, (void**)&rlong_list));
-    hipLaunchKernelGGL(msm_part_count, dim3(n_slices), dim3(threads), 0, st, scalars_all, fmt, plan, slice, pb, rbits, ctl + 4, roff, cur, long_count + 1);
+    // the count pass keeps nothing per slice, so its slices are its own: fatter ones (~256 workgroups) flush their 2^pb partition
+    // sizes with a quarter of the global atomics (BP_MSM_COUNT_SLICE forces a size)
+    uint32_t slice1 = slice;
+    while (slice1 < 8192 && (uint64_t)slice1 * 256 < (uint64_t)n * J) slice1 <<= 1;      // measured at 2^20: 48 / 41 / 34 / 48 us at 1 024 / 2 048 / 4 096 / 8 192
+    slice1 = env_u32("BP_MSM_COUNT_SLICE", slice1, 64, 65536);
+    const uint32_t n_slices1 = (uint32_t)(((uint64_t)n * J + slice1 - 1) / slice1);
+    hipLaunchKernelGGL(msm_part_count, dim3(n_slices1), dim3(slice1 >= 1024 ? 1024u : threads), 0, st, scalars_all, fmt, plan, slice1, pb, rbits, ctl + 4, roff, cur, long_count + 1);
     // a slice's share of a partition: long -> partition-major write-out, short -> one lane per record (BP_MSM_PART_FLAT = 0 / 1 forces)
     const uint32_t flat_env = env_u32("BP_MSM_PART_FLAT", 2, 0, 2);
     const bool flat = flat_env == 2 ? (cap >> pb) < 8 : flat_env == 1;
