@@ -745,14 +745,19 @@ __global__ void __launch_bounds__(1024) msm_part_scatter(MsmScalars scalars, int
   const uint64_t all = (uint64_t)plan.J * plan.n, lo = (uint64_t)blockIdx.x * slice, hi = lo + slice < all ? lo + slice : all;
   msm_slice_entries(scalars, lo, hi, fmt, plan, nullptr, [&](uint32_t bucket, uint32_t) { atomicAdd(&h[bucket >> rbits], 1u); });
   __syncthreads();
-  // this slice's share of every partition: place in the staging area (lbase) and in the partition's final run (gbase)
+  // this slice's share of every partition: place in the staging area (lbase) and in the partition's final run (gbase).  The
+  // reservations (one returning global atomic per partition the slice touches) are all issued before the scan's barriers, so
+  // their latencies overlap each other and the scan instead of adding up over the 2^pb / lanes rounds
+  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x) {
+    const uint32_t v = h[p];
+    gbase[p] = v ? atomicAdd(&cursor[p], v) : 0u;
+  }
   for (uint32_t p0 = 0; p0 < P; p0 += blockDim.x) {
     const uint32_t p = p0 + threadIdx.x;
     const uint32_t v = p < P ? h[p] : 0u;
     const uint32_t ex = block_exclusive_scan_1024(v, scan16) + carry_s;
     if (p < P) {
       lbase[p] = ex;
-      gbase[p] = v ? atomicAdd(&cursor[p], v) : 0u;
       h[p] = 0;
     }
     __syncthreads();
