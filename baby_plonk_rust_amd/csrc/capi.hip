@@ -381,6 +381,12 @@ int bp_ctx_devices(bp_ctx* ctx, int* device_ids, int cap) {
 
 void bp_destroy(bp_ctx* ctx) {
   if (!ctx) return;
+  {                                          // circuits first: their coset shares live on the members, which go next
+    DeviceGuard guard(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->circuits) circuit_release(kv.second);
+    ctx->circuits.clear();
+  }
   for (MemberWorker* w : ctx->workers) delete w;
   ctx->workers.clear();
   for (size_t r = 1; r < ctx->members.size(); r++) {
@@ -1781,6 +1787,13 @@ int bp_circuit_load(bp_ctx* ctx, uint32_t log_n, const void* const columns[8], i
   if (rc != BP_OK) {
     (void)hipFree(lag);
     return rc;
+  }
+  if (is_group(ctx)) {                       // round 3 by coset over the members: their shares of the coset tables
+    rc = circuit_split_build(ctx, e);
+    if (rc != BP_OK) {
+      circuit_release(e);
+      return rc;
+    }
   }
   *handle = ctx->next_handle++;
   ctx->circuits[*handle] = e;

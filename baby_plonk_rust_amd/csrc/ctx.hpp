@@ -35,6 +35,20 @@ struct SrsEntry {
 
 // preprocessed circuit of the native prover (prover.hip): CommonPreprocessedInput (program.rs:34-50) resident in HBM,
 // with the derived forms the reference recomputes in every proof.  Column order: ql qr qm qo qc s1 s2 s3.
+// Round 3 of a proof split by COSET over the members of a group context: the quotient coset g <w_4n> is the
+// union of the four cosets s_j <w_n>, s_j = g w_4n^j; a member evaluates a, b, c, z, PI on its cosets from the five coefficient
+// vectors (size-n transforms), runs the quotient kernel there against its own quarter(s) of the circuit's coset tables and sends
+// n quotient coefficients per coset back.  One share per participating member (the first 2 or 4), resident from bp_circuit_load.
+struct CosetShare {
+  bp_ctx* member = nullptr;
+  uint32_t first = 0, count = 0;       // cosets [first, first + count) of the four
+  fr_t* pre = nullptr;                 // count x 9 x n: the eight circuit columns + L1 on each coset (coset j = entries 4 i + j of CircuitEntry::coset)
+  fr_t* xs = nullptr;                  // count x n: the coset's points s_j w_n^i
+  fr_t* spow = nullptr;                // count x n: s_j^i
+  fr_t* sinv = nullptr;                // count x n: s_j^-i
+  hipEvent_t done = nullptr;           // recorded on the member's stream behind the copy of its quotient coefficients to the leader
+};
+
 struct CircuitEntry {
   uint32_t log_n = 0;
   fr_t* lag = nullptr;        // 8 x n Lagrange columns as loaded
@@ -45,6 +59,7 @@ struct CircuitEntry {
   fr_t* g_pow = nullptr;      // g^i, i < n + 8
   fr_t* ginv_pow = nullptr;   // g^-i, i < 4n
   fr_t zh_inv[4];             // 1 / (X^n - 1) on the coset (period 4)
+  std::vector<CosetShare> split;       // group contexts only: round 3 by coset over the members (empty otherwise)
 };
 
 struct MemberWorker;     // persistent host thread of one member of a group context (capi.hip)
@@ -213,6 +228,7 @@ int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t
 
 int side_ctx_get(bp_ctx* ctx, bp_ctx** out);       // creates ctx->side and its events on first use (capi.hip)
 int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out);
+int circuit_split_build(bp_ctx* ctx, CircuitEntry& e);      // leader of a group: the members' coset shares (prover.hip)
 void circuit_release(CircuitEntry& e);
 int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_wit, const fr_t blind[11], uint8_t proof[624]);
 void transcript_test_vector(uint8_t out32[32]);

@@ -217,6 +217,147 @@ void circuit_release(CircuitEntry& e) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
+  for (CosetShare& sh : e.split) {
+    DeviceGuard guard(sh.member ? sh.member->device : 0);
+    if (sh.member) (void)hipStreamSynchronize(sh.member->stream);
+    fr_t** mine[4] = {&sh.pre, &sh.xs, &sh.spow, &sh.sinv};
+    for (fr_t** p : mine) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    if (sh.done) (void)hipEventDestroy(sh.done);
+    sh.done = nullptr;
+  }
+  e.split.clear();
+}
+
+// ------------------------------------------------------------------------------------------------ round 3 by coset (group contexts)
+static bool force_peer() {
+  const char* v = getenv("BP_FORCE_PEER_COPIES");
+  return v && *v && *v != '0';
+}
+// src (on device src_dev) -> dst (on m's device), n elements, on m's stream
+static hipError_t copy_to_member(bp_ctx* m, fr_t* dst, const fr_t* src, int src_dev, size_t n) {
+  if (src_dev == m->device && !force_peer()) return hipMemcpyAsync(dst, src, n * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream);
+  return hipMemcpyPeerAsync(dst, m->device, src, src_dev, n * sizeof(fr_t), m->stream);
+}
+
+// The members' coset shares of a circuit (leader of a group; called once per circuit).  Coset j of the four is entries 4 i + j of
+// the leader's tables over g <w_4n>, so a share is gathered there (strided) and copied to its member; the s_j^i / s_j^-i tables are
+// computed on the member.  The first 2 members (groups of 2 or 3) take two cosets each, the first 4 (groups of 4 and more) one.
+int circuit_split_build(bp_ctx* ctx, CircuitEntry& e) {
+  const size_t R = ctx->members.size();
+  if (R < 2) return BP_OK;
+  const uint32_t k = e.log_n;
+  const size_t n = (size_t)1 << k, N = 4 * n;
+  const uint32_t used = R >= 4 ? 4 : 2, per = 4 / used;
+  const fr_t g = from_u64(COSET_GEN), w4n = root_of_unity(N);
+  fr_t* tmp;
+  BP_TRY(ws_get(ctx, "prove.split_tmp", 10 * n * sizeof(fr_t), (void**)&tmp));
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  for (uint32_t r = 0; r < used; r++) {
+    CosetShare sh;
+    bp_ctx* m = ctx->members[r];
+    sh.member = m;
+    sh.first = r * per;
+    sh.count = per;
+    {
+      DeviceGuard guard(m->device);
+      hipError_t he = hipMalloc((void**)&sh.pre, (size_t)per * 9 * n * sizeof(fr_t));
+      if (he == hipSuccess) he = hipMalloc((void**)&sh.xs, (size_t)per * n * sizeof(fr_t));
+      if (he == hipSuccess) he = hipMalloc((void**)&sh.spow, (size_t)per * n * sizeof(fr_t));
+      if (he == hipSuccess) he = hipMalloc((void**)&sh.sinv, (size_t)per * n * sizeof(fr_t));
+      if (he == hipSuccess) he = hipEventCreateWithFlags(&sh.done, hipEventDisableTiming);
+      e.split.push_back(sh);                 // owned by the entry from here on (circuit_release frees what was allocated)
+      if (he != hipSuccess) return fail(ctx, BP_ERR_HIP, "coset share", he, __FILE__, __LINE__);
+    }
+    for (uint32_t c = 0; c < per; c++) {
+      const uint32_t j = sh.first + c;
+      {                                       // gather coset j on the leader, wait, copy to the member
+        DeviceGuard guard(ctx->device);
+        for (int col = 0; col < N_PRE; col++)
+          hipLaunchKernelGGL(fr_gather_stride, dim3(blocks), dim3(256), 0, ctx->stream, e.coset + (size_t)col * N, (size_t)4, (size_t)j, n, tmp + (size_t)col * n);
+        hipLaunchKernelGGL(fr_gather_stride, dim3(blocks), dim3(256), 0, ctx->stream, e.coset_x, (size_t)4, (size_t)j, n, tmp + (size_t)N_PRE * n);
+        BP_HIP(ctx, hipGetLastError());
+        BP_HIP(ctx, stream_wait(ctx->stream));
+      }
+      DeviceGuard guard(m->device);
+      BP_HIP(ctx, copy_to_member(m, sh.pre + (size_t)c * 9 * n, tmp, ctx->device, (size_t)N_PRE * n));
+      BP_HIP(ctx, copy_to_member(m, sh.xs + (size_t)c * n, tmp + (size_t)N_PRE * n, ctx->device, n));
+      const fr_t sj = fmul(g, fpow(w4n, j));
+      int rc = roots_run(m, sj, n, sh.spow + (size_t)c * n);
+      if (rc == BP_OK) rc = roots_run(m, finv(sj), n, sh.sinv + (size_t)c * n);
+      if (rc != BP_OK) {
+        ctx->last_error = m->last_error;
+        return rc;
+      }
+      BP_HIP(ctx, stream_wait(m->stream));    // tmp is reused for the next coset
+    }
+  }
+  return BP_OK;
+}
+
+// t (4n coefficients on the leader) = quotient of round 3, every member working on its cosets.  coefs5 / lens5: the coefficient
+// vectors a, b, c, z, PI on the leader, produced on the leader's stream.
+static int round3_by_coset(bp_ctx* ctx, const CircuitEntry& cir, const fr_t* const coefs5[5], const size_t lens5[5], const QuotientArgs& qa0, fr_t* t) {
+  const uint32_t k = cir.log_n;
+  const size_t n = (size_t)1 << k, N = 4 * n, cap = n + 8;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  const fr_t g = from_u64(COSET_GEN), w4n = root_of_unity(N), gn = fpow(g, n), i4 = fpow(w4n, n);
+  fr_t* v;                                                            // the four residues, one after the other
+  BP_TRY(ws_get(ctx, "prove.split_v", 4 * n * sizeof(fr_t), (void**)&v));
+  BP_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));              // the coefficient vectors are ready behind this event
+  for (const CosetShare& sh : cir.split) {
+    bp_ctx* m = sh.member;
+    DeviceGuard guard(m->device);
+    fr_t *cf, *ev, *tq;
+    int rc = ws_get(m, "prove.split_coef", 5 * cap * sizeof(fr_t), (void**)&cf);
+    if (rc == BP_OK) rc = ws_get(m, "prove.split_ev", 5 * n * sizeof(fr_t), (void**)&ev);
+    if (rc == BP_OK) rc = ws_get(m, "prove.split_tq", n * sizeof(fr_t), (void**)&tq);
+    if (rc != BP_OK) {
+      ctx->last_error = m->last_error;
+      return rc;
+    }
+    BP_HIP(ctx, hipStreamWaitEvent(m->stream, ctx->ev[4], 0));
+    for (int p = 0; p < 5; p++) BP_HIP(ctx, copy_to_member(m, cf + (size_t)p * cap, coefs5[p], ctx->device, lens5[p]));
+    for (uint32_t c = 0; c < sh.count; c++) {
+      const uint32_t j = sh.first + c;
+      fr_t sn = gn;                                                   // s_j^n = g^n i4^j
+      for (uint32_t q = 0; q < j; q++) sn = fmul(sn, i4);
+      for (int p = 0; p < 5; p++)
+        hipLaunchKernelGGL(fr_fold_scale, dim3(blocks), dim3(256), 0, m->stream, cf + (size_t)p * cap, lens5[p], n, sn, sh.spow + (size_t)c * n, ev + (size_t)p * n);
+      BP_HIP(ctx, hipGetLastError());
+      rc = ntt_run(m, ev, k, 0, 5, n);
+      QuotientArgs qa = qa0;
+      for (int q = 0; q < 4; q++) qa.zh_inv[q] = cir.zh_inv[j];       // X^n - 1 = s_j^n - 1 on the whole coset
+      if (rc == BP_OK) {
+        hipLaunchKernelGGL(quotient_coset, dim3(blocks), dim3(256), 0, m->stream, ev, sh.pre + (size_t)c * 9 * n, sh.xs + (size_t)c * n, n, qa, tq, 1u);
+        BP_HIP(ctx, hipGetLastError());
+        rc = ntt_run(m, tq, k, 1, 1, n);
+      }
+      if (rc == BP_OK) rc = fr_binary_run(m, tq, n, sh.sinv + (size_t)c * n, n, tq, n, 2);      // coefficients of t mod (x^n - s_j^n)
+      if (rc != BP_OK) {
+        ctx->last_error = m->last_error;
+        return rc;
+      }
+      // back to the leader: the copy is issued on the member's stream (it follows the kernels that produced tq)
+      hipError_t he = (m->device == ctx->device && !force_peer())
+                          ? hipMemcpyAsync(v + (size_t)j * n, tq, n * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream)
+                          : hipMemcpyPeerAsync(v + (size_t)j * n, ctx->device, tq, m->device, n * sizeof(fr_t), m->stream);
+      if (he != hipSuccess) return fail(ctx, BP_ERR_HIP, "coset quotient back to the leader", he, __FILE__, __LINE__);
+    }
+    BP_HIP(ctx, hipEventRecord(sh.done, m->stream));
+  }
+  DeviceGuard guard(ctx->device);
+  for (const CosetShare& sh : cir.split) BP_HIP(ctx, hipStreamWaitEvent(ctx->stream, sh.done, 0));
+  RecombineArgs ra;
+  const fr_t quarter = finv(from_u64(4)), gn_inv = finv(gn);
+  ra.scale[0] = quarter;
+  for (int mm = 1; mm < 4; mm++) ra.scale[mm] = fmul(ra.scale[mm - 1], gn_inv);
+  ra.iinv = finv(i4);
+  hipLaunchKernelGGL(coset_recombine, dim3(blocks), dim3(256), 0, ctx->stream, v, n, ra, t);
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ prove
@@ -251,7 +392,12 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   fr_t* ev;
   BP_TRY(ws_get(ctx, "prove.coset_wit", 5 * N * sizeof(fr_t), (void**)&ev));         // a | b | c | z | PI evaluations
   const unsigned blocks_N = (unsigned)((N + 255) / 256);
-  bool side_on = true;
+  bool split_on = !cir.split.empty();                                                // group context: round 3 by coset over the members
+  {
+    const char* v = getenv("BP_PROVE_COSET_SPLIT");
+    if (v && *v == '0') split_on = false;
+  }
+  bool side_on = !split_on;
   {
     const char* v = getenv("BP_PROVE_SIDE");
     if (v && *v == '0') side_on = false;
@@ -297,6 +443,15 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   // ---- round 3 (prover.rs:370-500): quotient on the coset g <w_4n>
   fr_t* t;
   BP_TRY(ws_get(ctx, "prove.t", (N + 16) * sizeof(fr_t), (void**)&t));
+  QuotientArgs qa;
+  qa.alpha = alpha; qa.alpha2 = fmul(alpha, alpha); qa.beta = beta; qa.gamma = gamma;
+  qa.beta_k1 = fmul(beta, k1); qa.beta_k2 = fmul(beta, k2); qa.one = one;
+  for (int j = 0; j < 4; j++) qa.zh_inv[j] = cir.zh_inv[j];
+  if (split_on) {
+    const fr_t* coefs5[5] = {poly_abc[0], poly_abc[1], poly_abc[2], z_coeff, coefs + 3 * n};
+    const size_t lens5[5] = {n + 2, n + 2, n + 2, n + 3, n};
+    BP_TRY(round3_by_coset(ctx, cir, coefs5, lens5, qa, t));                          // t = the 4n quotient coefficients
+  } else {
   if (side_on) {
     hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, z_coeff, n + 3, cir.g_pow, ev + 3 * N, N);
     BP_HIP(ctx, hipGetLastError());
@@ -309,14 +464,11 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
     BP_HIP(ctx, hipGetLastError());
     BP_TRY(ntt_run(ctx, ev, k + 2, 0, 5, N));
   }
-  QuotientArgs qa;
-  qa.alpha = alpha; qa.alpha2 = fmul(alpha, alpha); qa.beta = beta; qa.gamma = gamma;
-  qa.beta_k1 = fmul(beta, k1); qa.beta_k2 = fmul(beta, k2); qa.one = one;
-  for (int j = 0; j < 4; j++) qa.zh_inv[j] = cir.zh_inv[j];
-  hipLaunchKernelGGL(quotient_coset, dim3(blocks_N), dim3(256), 0, st, ev, cir.coset, cir.coset_x, N, qa, t);
+  hipLaunchKernelGGL(quotient_coset, dim3(blocks_N), dim3(256), 0, st, ev, cir.coset, cir.coset_x, N, qa, t, 4u);
   BP_HIP(ctx, hipGetLastError());
   BP_TRY(ntt_run(ctx, t, k + 2, 1, 1, N));
   BP_TRY(fr_binary_run(ctx, t, N, cir.ginv_pow, N, t, N, 2));
+  }
   size_t t_len, dummy;
   BP_TRY(fr_nonzero_stats_run(ctx, t, N, 0, 0, &t_len, &dummy));
   // deg(numerator) <= 4n + 5, so an exact quotient has at most 3n + 6 coefficients; anything longer means the division by

@@ -74,13 +74,15 @@ struct QuotientArgs {
   fr_t alpha, alpha2, beta, gamma, beta_k1, beta_k2, one;
   fr_t zh_inv[4];
 };
+// zshift: how many places further z(w X) sits -- 4 on the whole quotient coset g <w_4n> (w = w_4n^4), 1 on one of its four
+// cosets s_j <w_n> (the coset split of a group context, where N = n and the four zh_inv are that coset's one value)
 __global__ void __launch_bounds__(256) quotient_coset(const fr_t* __restrict__ wit, const fr_t* __restrict__ pre,
                                                        const fr_t* __restrict__ xs, size_t N, QuotientArgs q,
-                                                       fr_t* __restrict__ out) {
+                                                       fr_t* __restrict__ out, uint32_t zshift) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const fr_t a = load_fr(&wit[i]), b = load_fr(&wit[N + i]), c = load_fr(&wit[2 * N + i]), z = load_fr(&wit[3 * N + i]);
-  const fr_t zw = load_fr(&wit[3 * N + ((i + 4) & (N - 1))]);
+  const fr_t zw = load_fr(&wit[3 * N + ((i + zshift) & (N - 1))]);
   fr_t acc, t, u, v;
   // gate constraints
   Fr::mul(acc, a, load_fr(&pre[i]));                                   // a ql
@@ -123,6 +125,47 @@ __global__ void __launch_bounds__(256) quotient_coset(const fr_t* __restrict__ w
   Fr::add(acc, acc, t);
   Fr::mul(acc, acc, q.zh_inv[i & 3]);
   store_fr(&out[i], acc);
+}
+
+// ---- round 3 by coset (group contexts) ---------------------------------------------------------------------------------
+// out[i] = in[stride * i + offset]: one of the four cosets out of a table kept in the order of the whole quotient coset
+__global__ void __launch_bounds__(256) fr_gather_stride(const fr_t* __restrict__ in, size_t stride, size_t offset, size_t n, fr_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) store_fr(&out[i], load_fr(&in[i * stride + offset]));
+}
+// Coefficients c[0 .. len), len < 2 n, prepared for the size-n transform that evaluates the polynomial on s <w_n>:
+// out[i] = (c[i] + c[i + n] s^n) s^i  (x^(i+n) = s^n x^i on that coset), i < n; spow[i] = s^i
+__global__ void __launch_bounds__(256) fr_fold_scale(const fr_t* __restrict__ c, size_t len, size_t n, fr_t s_n, const fr_t* __restrict__ spow,
+                                                      fr_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fr_t v = i < len ? load_fr(&c[i]) : Fr::zero();
+  if (i + n < len) {
+    fr_t t;
+    Fr::mul(t, load_fr(&c[i + n]), s_n);
+    Fr::add(v, v, t);
+  }
+  Fr::mul(v, v, load_fr(&spow[i]));
+  store_fr(&out[i], v);
+}
+// t = sum_m x^(m n) t_m from its residues w_j = t mod (x^n - sigma_j), sigma_j = G i4^j (G = g^n, i4 a primitive fourth root of
+// unity): w_j = sum_m G^m i4^(j m) t_m, so G^m t_m = (1/4) sum_j i4^(-j m) w_j -- a radix-4 butterfly per coefficient index.
+// v[j * n + i] = coefficient i of w_j; scale[m] = G^-m / 4; iinv = i4^-1; out[m * n + i] = coefficient i of t_m.
+struct RecombineArgs { fr_t scale[4], iinv; };
+__global__ void __launch_bounds__(256) coset_recombine(const fr_t* __restrict__ v, size_t n, RecombineArgs a, fr_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const fr_t w0 = load_fr(&v[i]), w1 = load_fr(&v[n + i]), w2 = load_fr(&v[2 * n + i]), w3 = load_fr(&v[3 * n + i]);
+  fr_t e, o, d, f, r;
+  Fr::add(e, w0, w2);
+  Fr::add(o, w1, w3);
+  Fr::sub(d, w0, w2);
+  Fr::sub(f, w1, w3);
+  Fr::mul(f, f, a.iinv);                     // i4^-1 (w1 - w3)
+  Fr::add(r, e, o);  Fr::mul(r, r, a.scale[0]);  store_fr(&out[i], r);                 // m = 0: w0 + w1 + w2 + w3
+  Fr::add(r, d, f);  Fr::mul(r, r, a.scale[1]);  store_fr(&out[n + i], r);             // m = 1: w0 + i' w1 - w2 - i' w3
+  Fr::sub(r, e, o);  Fr::mul(r, r, a.scale[2]);  store_fr(&out[2 * n + i], r);         // m = 2: w0 - w1 + w2 - w3
+  Fr::sub(r, d, f);  Fr::mul(r, r, a.scale[3]);  store_fr(&out[3 * n + i], r);         // m = 3: w0 - i' w1 - w2 + i' w3
 }
 
 }  // namespace bp
