@@ -52,6 +52,51 @@ void host_compress48(uint8_t out[48], const g1_proj& p) {
   out[0] |= 0x80 | (larger ? 0x20 : 0);
 }
 
+// k points at once: their affine forms share ONE field inversion (Montgomery's trick, as G1Projective::batch_normalize does,
+// g1.rs:806-839) -- a Fermat inversion is ~570 field multiplications on the host, ~26 us; the identity (z = 0) is skipped
+static void host_compress48_many(uint8_t* out, const g1_proj* p, int k) {
+  fp_t prefix[16], acc = Fp::one();
+  bool inf[16];
+  for (int j = 0; j < k; j++) {
+    inf[j] = g1_is_identity(p[j]);
+    prefix[j] = acc;
+    if (!inf[j]) Fp::mul(acc, acc, p[j].z);
+  }
+  fp_t inv;
+  fp_invert(inv, acc);
+  for (int j = k; j-- > 0;) {
+    if (inf[j]) {
+      host_compress48(out + 48 * j, p[j]);
+      continue;
+    }
+    fp_t zinv;
+    Fp::mul(zinv, inv, prefix[j]);
+    Fp::mul(inv, inv, p[j].z);
+    g1_affine a;                               // encoded directly from the affine pair (host_compress48 would invert z again)
+    Fp::mul(a.x, p[j].x, zinv);
+    Fp::mul(a.y, p[j].y, zinv);
+    uint8_t* o = out + 48 * j;
+    memset(o, 0, 48);
+    fp_t x, y, ny;
+    Fp::from_mont(x, a.x);
+    Fp::from_mont(y, a.y);
+    Fp::neg(ny, a.y);
+    Fp::from_mont(ny, ny);
+    for (int i = 0; i < 12; i++) {
+      uint8_t* q = o + 4 * (11 - i);
+      q[0] = (uint8_t)(x.l[i] >> 24); q[1] = (uint8_t)(x.l[i] >> 16); q[2] = (uint8_t)(x.l[i] >> 8); q[3] = (uint8_t)x.l[i];
+    }
+    bool larger = false;                       // y > -y  (fp.rs:273-298)
+    for (int i = 11; i >= 0; i--) {
+      if (y.l[i] != ny.l[i]) {
+        larger = y.l[i] > ny.l[i];
+        break;
+      }
+    }
+    o[0] |= 0x80 | (larger ? 0x20 : 0);
+  }
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ host field helpers
@@ -98,6 +143,7 @@ struct PlonkTranscript {
     host_compress48(c, p);
     t.append_message(label, c, 48);
   }
+  void point48(const char* label, const uint8_t c[48]) { t.append_message(label, c, 48); }       // already compressed
   void scalar(const char* label, const fr_t& v) {
     uint8_t b[32];
     to_le32(b, v);
@@ -424,7 +470,8 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
     }
     BP_HIP(ctx, hipEventRecord(ctx->side_ev[1], ss));
   }
-  tr.point("a_1", cm[0]); tr.point("b_1", cm[1]); tr.point("c_1", cm[2]);
+  host_compress48_many(proof, &cm[0], 3);        // compressed once, into the proof; the transcript absorbs the same 48 bytes (transcript.rs:66-69)
+  tr.point48("a_1", proof); tr.point48("b_1", proof + 48); tr.point48("c_1", proof + 96);
   const fr_t beta = tr.challenge("beta"), gamma = tr.challenge("gamma");
   const double t_r1 = now_ms();
 
@@ -436,7 +483,8 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   hipLaunchKernelGGL(fr_blind, dim3(blocks_n), dim3(256), 0, st, z_lag, n, blind[8], blind[7], blind[6], 3u, z_coeff);
   BP_HIP(ctx, hipGetLastError());
   BP_TRY(commit(ctx, srs, z_coeff, n + 3, &cm[3]));
-  tr.point("z_1", cm[3]);
+  host_compress48_many(proof + 144, &cm[3], 1);
+  tr.point48("z_1", proof + 144);
   const fr_t alpha = tr.challenge("z_1");                                           // transcript.rs:24
   const double t_r2 = now_ms();
 
@@ -495,7 +543,8 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
     const size_t lens[3] = {n + 1, n + 1, hi_len};
     BP_TRY(commit_many(ctx, srs, polys, lens, 3, &cm[4]));
   }
-  tr.point("t_lo_1", cm[4]); tr.point("t_mid_1", cm[5]); tr.point("t_hi_1", cm[6]);
+  host_compress48_many(proof + 192, &cm[4], 3);
+  tr.point48("t_lo_1", proof + 192); tr.point48("t_mid_1", proof + 240); tr.point48("t_hi_1", proof + 288);
   const fr_t zeta = tr.challenge("zeta");
   const double t_r3 = now_ms();
 
@@ -581,7 +630,7 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   const double t_r5 = now_ms();
 
   // ---- Proof (verifier.rs:23-40 field order): 9 compressed points, then the 6 evaluations as 32-byte little-endian
-  for (int j = 0; j < 9; j++) host_compress48(proof + 48 * j, cm[j]);
+  host_compress48_many(proof + 336, &cm[7], 2);                   // the first seven were compressed when the transcript absorbed them
   const fr_t evals[6] = {a_bar, b_bar, c_bar, s1_bar, s2_bar, zw_bar};
   for (int j = 0; j < 6; j++) to_le32(proof + 432 + 32 * j, evals[j]);
   ctx->prove_ms[0] = (float)(t_r1 - t_start); ctx->prove_ms[1] = (float)(t_r2 - t_r1); ctx->prove_ms[2] = (float)(t_r3 - t_r2);
