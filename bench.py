@@ -592,8 +592,9 @@ def main():
                     prove["group"] = {"n_gpus": world, "latency_ms_per_proof": 1e3 * g_elapsed / args.prove_reps, "round_ms": gprover.last_stats()["round_ms"],
                                       "same_proof_bytes_as_one_gpu": gblob == blob,
                                       "how": "one bp_init_multi context in rank 0's process: SRS and the nine MSMs of a proof sharded by point "
-                                             "range over the %d GPUs (peer copies of the scalar slices, partial sums added on the host), "
-                                             "polynomial rounds on GPU 0" % world}
+                                             "range over the %d GPUs (peer copies of the scalar slices, one batched pipeline per member and round, "
+                                             "partial sums added on the host), round 3's quotient split by coset over the first %d "
+                                             "GPUs, the other polynomial work on GPU 0" % (world, 4 if world >= 4 else 2)}
                     # ONE host-to-host NTT through the same context (SURVEY 8e option ii): column slices over every GPU's PCIe link,
                     # block exchange between the GPUs, outputs back; beside it the same call on this rank's single-GPU context
                     if args.strong_log_n >= 22 and world in (2, 4, 8):
