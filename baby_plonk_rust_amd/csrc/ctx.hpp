@@ -41,12 +41,13 @@ struct SrsEntry {
 // n quotient coefficients per coset back.  One share per participating member (the first 2 or 4), resident from bp_circuit_load.
 struct CosetShare {
   bp_ctx* member = nullptr;
+  bp_ctx* work = nullptr;              // the member's side context (own stream, workspace, transform tables): where the share's round-3 work runs
   uint32_t first = 0, count = 0;       // cosets [first, first + count) of the four
   fr_t* pre = nullptr;                 // count x 9 x n: the eight circuit columns + L1 on each coset (coset j = entries 4 i + j of CircuitEntry::coset)
   fr_t* xs = nullptr;                  // count x n: the coset's points s_j w_n^i
   fr_t* spow = nullptr;                // count x n: s_j^i
   fr_t* sinv = nullptr;                // count x n: s_j^-i
-  hipEvent_t done = nullptr;           // recorded on the member's stream behind the copy of its quotient coefficients to the leader
+  hipEvent_t done = nullptr;           // recorded on the work stream behind the copy of its quotient coefficients to the leader
 };
 
 struct CircuitEntry {

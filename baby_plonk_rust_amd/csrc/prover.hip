@@ -266,6 +266,7 @@ void circuit_release(CircuitEntry& e) {
   for (CosetShare& sh : e.split) {
     DeviceGuard guard(sh.member ? sh.member->device : 0);
     if (sh.member) (void)hipStreamSynchronize(sh.member->stream);
+    if (sh.work) (void)hipStreamSynchronize(sh.work->stream);        // the work context itself is the member's side context: destroyed with the member
     fr_t** mine[4] = {&sh.pre, &sh.xs, &sh.spow, &sh.sinv};
     for (fr_t** p : mine) {
       if (*p) (void)hipFree(*p);
@@ -308,6 +309,13 @@ int circuit_split_build(bp_ctx* ctx, CircuitEntry& e) {
     sh.first = r * per;
     sh.count = per;
     {
+      int rc = side_ctx_get(m, &sh.work);      // a stream, workspace and transform tables of its own on the member's device: the share's work
+      if (rc != BP_OK) {                       // runs beside the member's MSM shards instead of queueing behind them
+        ctx->last_error = m->last_error;
+        return rc;
+      }
+    }
+    {
       DeviceGuard guard(m->device);
       hipError_t he = hipMalloc((void**)&sh.pre, (size_t)per * 9 * n * sizeof(fr_t));
       if (he == hipSuccess) he = hipMalloc((void**)&sh.xs, (size_t)per * n * sizeof(fr_t));
@@ -343,56 +351,106 @@ int circuit_split_build(bp_ctx* ctx, CircuitEntry& e) {
   return BP_OK;
 }
 
-// t (4n coefficients on the leader) = quotient of round 3, every member working on its cosets.  coefs5 / lens5: the coefficient
-// vectors a, b, c, z, PI on the leader, produced on the leader's stream.
-static int round3_by_coset(bp_ctx* ctx, const CircuitEntry& cir, const fr_t* const coefs5[5], const size_t lens5[5], const QuotientArgs& qa0, fr_t* t) {
+// Round 3 by coset, in two parts, both on the shares' work contexts (CosetShare::work).
+//  early: a, b, c and PI depend on no challenge (prover.rs:386-450 evaluates them after alpha only because the reference is
+//         sequential): the leader enqueues their copies, folds and size-n transforms right after round 1's blinding, so they run on
+//         the members beside the commitments of rounds 1 and 2 -- the members' GPUs only hold an MSM shard each then.
+//  late:  once z's coefficients exist, its copy / fold / transform, the quotient on each coset, the inverse transform, the
+//         unscaling by s_j^-i and the copy of the n coefficients back to the leader, which recombines the four residues.
+// slots: a, b, c, z, PI (the order quotient_coset reads); `which` selects the slots a call handles.
+static int coset_inputs(bp_ctx* ctx, const CircuitEntry& cir, const CosetShare& sh, const fr_t* const coefs5[5], const size_t lens5[5], unsigned which, fr_t** ev_out) {
   const uint32_t k = cir.log_n;
   const size_t n = (size_t)1 << k, N = 4 * n, cap = n + 8;
   const unsigned blocks = (unsigned)((n + 255) / 256);
   const fr_t g = from_u64(COSET_GEN), w4n = root_of_unity(N), gn = fpow(g, n), i4 = fpow(w4n, n);
-  fr_t* v;                                                            // the four residues, one after the other
-  BP_TRY(ws_get(ctx, "prove.split_v", 4 * n * sizeof(fr_t), (void**)&v));
-  BP_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));              // the coefficient vectors are ready behind this event
-  for (const CosetShare& sh : cir.split) {
-    bp_ctx* m = sh.member;
-    DeviceGuard guard(m->device);
-    fr_t *cf, *ev, *tq;
-    int rc = ws_get(m, "prove.split_coef", 5 * cap * sizeof(fr_t), (void**)&cf);
-    if (rc == BP_OK) rc = ws_get(m, "prove.split_ev", 5 * n * sizeof(fr_t), (void**)&ev);
-    if (rc == BP_OK) rc = ws_get(m, "prove.split_tq", n * sizeof(fr_t), (void**)&tq);
+  bp_ctx* w = sh.work;
+  fr_t *cf, *ev;
+  int rc = ws_get(w, "prove.split_coef", 5 * cap * sizeof(fr_t), (void**)&cf);
+  if (rc == BP_OK) rc = ws_get(w, "prove.split_ev", (size_t)sh.count * 5 * n * sizeof(fr_t), (void**)&ev);
+  if (rc != BP_OK) {
+    ctx->last_error = w->last_error;
+    return rc;
+  }
+  *ev_out = ev;
+  BP_HIP(ctx, hipStreamWaitEvent(w->stream, ctx->ev[4], 0));          // the coefficient vectors are ready behind the leader's event
+  for (int p = 0; p < 5; p++)
+    if (which >> p & 1) BP_HIP(ctx, copy_to_member(w, cf + (size_t)p * cap, coefs5[p], ctx->device, lens5[p]));
+  for (uint32_t c = 0; c < sh.count; c++) {
+    const uint32_t j = sh.first + c;
+    fr_t sn = gn;                                                     // s_j^n = g^n i4^j
+    for (uint32_t q = 0; q < j; q++) sn = fmul(sn, i4);
+    fr_t* e = ev + (size_t)c * 5 * n;
+    for (int p = 0; p < 5; p++)
+      if (which >> p & 1)
+        hipLaunchKernelGGL(fr_fold_scale, dim3(blocks), dim3(256), 0, w->stream, cf + (size_t)p * cap, lens5[p], n, sn, sh.spow + (size_t)c * n, e + (size_t)p * n);
+    BP_HIP(ctx, hipGetLastError());
+    // contiguous runs of selected slots are transformed together
+    for (int p = 0; p < 5 && rc == BP_OK;) {
+      if (!(which >> p & 1)) {
+        p++;
+        continue;
+      }
+      int q = p;
+      while (q < 5 && (which >> q & 1)) q++;
+      rc = ntt_run(w, e + (size_t)p * n, k, 0, (size_t)(q - p), n);
+      p = q;
+    }
     if (rc != BP_OK) {
-      ctx->last_error = m->last_error;
+      ctx->last_error = w->last_error;
       return rc;
     }
-    BP_HIP(ctx, hipStreamWaitEvent(m->stream, ctx->ev[4], 0));
-    for (int p = 0; p < 5; p++) BP_HIP(ctx, copy_to_member(m, cf + (size_t)p * cap, coefs5[p], ctx->device, lens5[p]));
+  }
+  return BP_OK;
+}
+
+static int round3_coset_early(bp_ctx* ctx, const CircuitEntry& cir, const fr_t* const coefs5[5], const size_t lens5[5]) {
+  BP_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  for (const CosetShare& sh : cir.split) {
+    DeviceGuard guard(sh.work->device);
+    fr_t* ev;
+    BP_TRY(coset_inputs(ctx, cir, sh, coefs5, lens5, 0x17u, &ev));    // a, b, c, PI
+  }
+  return BP_OK;
+}
+
+// t (4n coefficients on the leader) = quotient of round 3.  early_done: a, b, c, PI are already on the cosets (round3_coset_early).
+static int round3_by_coset(bp_ctx* ctx, const CircuitEntry& cir, const fr_t* const coefs5[5], const size_t lens5[5], const QuotientArgs& qa0, bool early_done, fr_t* t) {
+  const uint32_t k = cir.log_n;
+  const size_t n = (size_t)1 << k, N = 4 * n;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  const fr_t g = from_u64(COSET_GEN), w4n = root_of_unity(N), gn = fpow(g, n), i4 = fpow(w4n, n);
+  fr_t* v;                                                            // the four residues, one after the other
+  BP_TRY(ws_get(ctx, "prove.split_v", 4 * n * sizeof(fr_t), (void**)&v));
+  BP_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));              // z's coefficients (and the others, if not sent early) are ready behind this event
+  for (const CosetShare& sh : cir.split) {
+    bp_ctx* w = sh.work;
+    DeviceGuard guard(w->device);
+    fr_t *ev, *tq;
+    BP_TRY(coset_inputs(ctx, cir, sh, coefs5, lens5, early_done ? 0x08u : 0x1Fu, &ev));
+    int rc = ws_get(w, "prove.split_tq", n * sizeof(fr_t), (void**)&tq);
+    if (rc != BP_OK) {
+      ctx->last_error = w->last_error;
+      return rc;
+    }
     for (uint32_t c = 0; c < sh.count; c++) {
       const uint32_t j = sh.first + c;
-      fr_t sn = gn;                                                   // s_j^n = g^n i4^j
-      for (uint32_t q = 0; q < j; q++) sn = fmul(sn, i4);
-      for (int p = 0; p < 5; p++)
-        hipLaunchKernelGGL(fr_fold_scale, dim3(blocks), dim3(256), 0, m->stream, cf + (size_t)p * cap, lens5[p], n, sn, sh.spow + (size_t)c * n, ev + (size_t)p * n);
-      BP_HIP(ctx, hipGetLastError());
-      rc = ntt_run(m, ev, k, 0, 5, n);
       QuotientArgs qa = qa0;
       for (int q = 0; q < 4; q++) qa.zh_inv[q] = cir.zh_inv[j];       // X^n - 1 = s_j^n - 1 on the whole coset
-      if (rc == BP_OK) {
-        hipLaunchKernelGGL(quotient_coset, dim3(blocks), dim3(256), 0, m->stream, ev, sh.pre + (size_t)c * 9 * n, sh.xs + (size_t)c * n, n, qa, tq, 1u);
-        BP_HIP(ctx, hipGetLastError());
-        rc = ntt_run(m, tq, k, 1, 1, n);
-      }
-      if (rc == BP_OK) rc = fr_binary_run(m, tq, n, sh.sinv + (size_t)c * n, n, tq, n, 2);      // coefficients of t mod (x^n - s_j^n)
+      hipLaunchKernelGGL(quotient_coset, dim3(blocks), dim3(256), 0, w->stream, ev + (size_t)c * 5 * n, sh.pre + (size_t)c * 9 * n, sh.xs + (size_t)c * n, n, qa, tq, 1u);
+      BP_HIP(ctx, hipGetLastError());
+      rc = ntt_run(w, tq, k, 1, 1, n);
+      if (rc == BP_OK) rc = fr_binary_run(w, tq, n, sh.sinv + (size_t)c * n, n, tq, n, 2);      // coefficients of t mod (x^n - s_j^n)
       if (rc != BP_OK) {
-        ctx->last_error = m->last_error;
+        ctx->last_error = w->last_error;
         return rc;
       }
-      // back to the leader: the copy is issued on the member's stream (it follows the kernels that produced tq)
-      hipError_t he = (m->device == ctx->device && !force_peer())
-                          ? hipMemcpyAsync(v + (size_t)j * n, tq, n * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream)
-                          : hipMemcpyPeerAsync(v + (size_t)j * n, ctx->device, tq, m->device, n * sizeof(fr_t), m->stream);
+      // back to the leader: the copy is issued on the work stream (it follows the kernels that produced tq)
+      hipError_t he = (w->device == ctx->device && !force_peer())
+                          ? hipMemcpyAsync(v + (size_t)j * n, tq, n * sizeof(fr_t), hipMemcpyDeviceToDevice, w->stream)
+                          : hipMemcpyPeerAsync(v + (size_t)j * n, ctx->device, tq, w->device, n * sizeof(fr_t), w->stream);
       if (he != hipSuccess) return fail(ctx, BP_ERR_HIP, "coset quotient back to the leader", he, __FILE__, __LINE__);
     }
-    BP_HIP(ctx, hipEventRecord(sh.done, m->stream));
+    BP_HIP(ctx, hipEventRecord(sh.done, w->stream));
   }
   DeviceGuard guard(ctx->device);
   for (const CosetShare& sh : cir.split) BP_HIP(ctx, hipStreamWaitEvent(ctx->stream, sh.done, 0));
@@ -414,6 +472,10 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   const fr_t omega = root_of_unity(n), k1 = from_u64(2), k2 = from_u64(3), one = Fr::one();      // prover.rs:99-100
   hipStream_t st = ctx->stream;
   if (ctx->side) BP_HIP(ctx, stream_wait(ctx->side->stream));     // side work of a proof that was abandoned half way must not outlive its buffers
+  for (const CosetShare& sh : cir.split) {
+    DeviceGuard guard(sh.work->device);
+    BP_HIP(ctx, stream_wait(sh.work->stream));
+  }
   const double t_start = now_ms();
   PlonkTranscript tr;
   g1_proj cm[9];
@@ -448,6 +510,14 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
     const char* v = getenv("BP_PROVE_SIDE");
     if (v && *v == '0') side_on = false;
   }
+  bool early_on = split_on;                // a, b, c, PI to the members' cosets now, beside the commitments (BP_PROVE_COSET_EARLY=0: in round 3)
+  {
+    const char* v = getenv("BP_PROVE_COSET_EARLY");
+    if (v && *v == '0') early_on = false;
+  }
+  const fr_t* coefs5[5] = {poly_abc[0], poly_abc[1], poly_abc[2], zc + (n + 8), coefs + 3 * n};
+  const size_t lens5[5] = {n + 2, n + 2, n + 2, n + 3, n};
+  if (early_on) BP_TRY(round3_coset_early(ctx, cir, coefs5, lens5));
   {                                       // three independent commitments in flight together (commit_many)
     const fr_t* polys[3] = {poly_abc[0], poly_abc[1], poly_abc[2]};
     const size_t lens[3] = {n + 2, n + 2, n + 2};
@@ -496,9 +566,7 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   qa.beta_k1 = fmul(beta, k1); qa.beta_k2 = fmul(beta, k2); qa.one = one;
   for (int j = 0; j < 4; j++) qa.zh_inv[j] = cir.zh_inv[j];
   if (split_on) {
-    const fr_t* coefs5[5] = {poly_abc[0], poly_abc[1], poly_abc[2], z_coeff, coefs + 3 * n};
-    const size_t lens5[5] = {n + 2, n + 2, n + 2, n + 3, n};
-    BP_TRY(round3_by_coset(ctx, cir, coefs5, lens5, qa, t));                          // t = the 4n quotient coefficients
+    BP_TRY(round3_by_coset(ctx, cir, coefs5, lens5, qa, early_on, t));                // t = the 4n quotient coefficients
   } else {
   if (side_on) {
     hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, z_coeff, n + 3, cir.g_pow, ev + 3 * N, N);

@@ -29,8 +29,9 @@ for members in (1, args.members):
     prover = bp.Prover(setup, bp.Circuit(pk, ctx))
     wit = [torch.from_numpy(c.view(np.int64)).cuda() for c in cols]
     torch.cuda.synchronize()
-    for split in (("1", "0") if members > 1 else ("1",)):
+    for split, early in ((("1", "1"), ("1", "0"), ("0", "0")) if members > 1 else (("1", "1"),)):
         os.environ["BP_PROVE_COSET_SPLIT"] = split
+        os.environ["BP_PROVE_COSET_EARLY"] = early
         best = None
         for i in range(args.reps + 1):
             t0 = time.perf_counter()
@@ -40,6 +41,6 @@ for members in (1, args.members):
                 best = dt if best is None or dt < best else best
         ref = ref or blob
         assert blob == ref
-        print("2^%d gates, %d member(s), coset split %s: %.2f ms  rounds %s" % (args.log_n, members, split if members > 1 else "-", 1e3 * best,
+        print("2^%d gates, %d member(s), coset split %s early %s: %.2f ms  rounds %s" % (args.log_n, members, split if members > 1 else "-", early if members > 1 else "-", 1e3 * best,
                                                                                    ["%.2f" % r for r in prover.last_stats()["round_ms"]]), flush=True)
     ctx.close()
