@@ -598,7 +598,7 @@ class Setup:
         if tables and os.environ.get("BP_SRS_TABLES", "1") != "0":
             try:
                 ctx.srs_precompute(handle, 0)
-            except BpError as e:          # tables are an optimisation (they need windows x 112 B per point of HBM): commits work without
+            except BpError as e:          # tables are an optimisation (they need windows x 128 B per point of HBM): commits work without
                 self.tables_error = e
 
     @staticmethod

@@ -23,7 +23,7 @@ constexpr uint32_t MSM_NAF_FLAG = 0x100u, MSM_NAF_ROWS = 256;
 
 struct SrsEntry {
   g1_affine* d_points = nullptr;        // 96 B/point, reference Montgomery limbs (export, generic kernels)
-  g1_affine28* d_points28 = nullptr;    // 112 B/point, 14 x 28-bit limbs, R' = 2^392 (bucket accumulation)
+  g1_affine28* d_points28 = nullptr;    // 128-B slot per point (112 B used), 14 x 28-bit limbs, R' = 2^392 (bucket accumulation)
   g1_affine28* d_table = nullptr;       // optional fixed-base tables: row w = 2^(table_c w) * SRS, table_W rows of n points
   uint32_t table_c = 0, table_W = 0;
   size_t n = 0;                         // points resident on this device

@@ -22,7 +22,7 @@ BP_HD To widen28(const F28<A, VA>& a) {
 using C28 = F28<MASK28 + 8, 6>;
 using PtY28 = F28<MASK28 + 8, 2>;     // y or 2p - y after one normalisation
 
-struct g1_affine28 {                  // 112 bytes in HBM: x | y, 14 + 14 limbs; identity = all zero
+struct alignas(128) g1_affine28 {     // x | y, 14 + 14 limbs (112 B) in a 128-byte HBM slot: one cache line per gathered point; identity = all zero
   F28n x, y;
 };
 struct g1_proj28 {                    // 168 bytes of limbs (stored padded to 176 B = 11 x 16 B)

@@ -135,7 +135,7 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   plan.seg = env_u32("BP_MSM_SEG", seg, 1, 1024);
 }
 
-// 112-byte unsaturated copy of an SRS (allocated here, owned by the SRS entry)
+// unsaturated copy of an SRS (128-byte slots) (allocated here, owned by the SRS entry)
 int srs_to28_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28** d_out) {
   g1_affine28* d = nullptr;
   BP_HIP(ctx, hipMalloc((void**)&d, (n ? n : 1) * sizeof(g1_affine28)));

@@ -241,7 +241,7 @@ class Setup {
                             bool tables = true) {                                                                     // setup.rs:12-31
     uint64_t h = 0;
     c.check(bp_srs_generate(c.raw(), powers, tau_le.data(), &h), "generate_srs");
-    if (tables) (void)bp_srs_precompute(c.raw(), h, 0);      // an optimisation (windows x 112 B per point of HBM): commits work without it
+    if (tables) (void)bp_srs_precompute(c.raw(), h, 0);      // an optimisation (windows x 128 B per point of HBM): commits work without it
     return Setup(h, c);
   }
   std::vector<G1> powers_of_x() const {

@@ -35,7 +35,7 @@ def test_golden_fixture_with_tables(ctx, c):
     plain = ctx.msm(h, frs(sc))
     assert not ctx.msm_stats()["tables"]
     info = ctx.srs_precompute(h, c)
-    assert info["windows"] * 1000 * 112 == info["bytes"] and (c == 0 or info["window_bits"] == c)
+    assert info["windows"] * 1000 * 128 == info["bytes"] and (c == 0 or info["window_bits"] == c)
     got = ctx.msm(h, frs(sc))
     st = ctx.msm_stats()
     assert st["tables"] and st["window_bits"] == info["window_bits"]
@@ -147,10 +147,10 @@ def test_full_size_2p20_with_tables(ctx):
     plain = ctx.msm(h, sc)
     want = M.enc96(M.ec_mul(oracle_dot(sc, a, d)))
     info = ctx.srs_precompute(h, 16)                                 # the widest window whose buckets fit one LDS histogram (round 2's choice here)
-    assert info == {"window_bits": 16, "windows": 16, "bytes": 16 * n * 112}
+    assert info == {"window_bits": 16, "windows": 16, "bytes": 16 * n * 128}
     assert ctx.msm(h, sc) == want == plain and ctx.msm_stats()["tables"] and ctx.msm_stats()["window_bits"] == 16
     info = ctx.srs_precompute(h)                                     # auto: 13 windows of 20 bits from 2^20 points (profiles/r03_window_width_ab.txt)
-    assert info == {"window_bits": 20, "windows": 13, "bytes": 13 * n * 112}
+    assert info == {"window_bits": 20, "windows": 13, "bytes": 13 * n * 128}
     assert ctx.msm(h, sc) == want == plain and ctx.msm_stats()["tables"] and ctx.msm_stats()["window_bits"] == 20
     t = torch.from_numpy(sc.view(np.int64)).cuda()
     torch.cuda.synchronize()
@@ -180,11 +180,11 @@ def test_full_size_2p24_closed_form_both_paths(ctx):
     plain = bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n))
     assert plain == want and not ctx.msm_stats()["tables"]
     info = ctx.srs_precompute(h)                                     # auto width: 20 bits = 13 windows from 2^23 points (partitioned sort)
-    assert info["window_bits"] == 20 and info["windows"] == 13 and info["bytes"] == 13 * n * 112
+    assert info["window_bits"] == 20 and info["windows"] == 13 and info["bytes"] == 13 * n * 128
     assert bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n)) == want and ctx.msm_stats()["tables"]
     assert ctx.msm_stats()["window_bits"] == 20
     info = ctx.srs_precompute(h, 16)                                 # and the one-histogram-per-window width at the same size
-    assert info["window_bits"] == 16 and info["bytes"] == 16 * n * 112
+    assert info["window_bits"] == 16 and info["bytes"] == 16 * n * 128
     assert bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n)) == want and ctx.msm_stats()["tables"]
     # point-range shards as 8 GPUs would hold them (2^21 points each), combined on the host
     per = n // 8
@@ -243,7 +243,7 @@ def test_every_position_tables_naf_digits(ctx, w, log_n):
     want = M.enc96(M.ec_mul(oracle_dot(sc, a, d)))
     assert ctx.msm(h, sc) == want and not ctx.msm_stats()["tables"]
     info = ctx.srs_precompute(h, 256 + w)
-    assert info == {"window_bits": 256 + w, "windows": 256, "bytes": 256 * n * 112}
+    assert info == {"window_bits": 256 + w, "windows": 256, "bytes": 256 * n * 128}
     assert ctx.msm(h, sc) == want
     st = ctx.msm_stats()
     assert st["tables"] and st["window_bits"] == 256 + w

@@ -83,7 +83,7 @@ def test_group_context_msm_srs_and_tables(devs, peer):
     assert e.value.code == -4
     # fixed-base tables on every shard: same bytes, and the table path was taken
     info = many.srs_precompute(hm, 6)
-    assert info["window_bits"] == 6 and info["bytes"] == info["windows"] * 1000 * 112
+    assert info["window_bits"] == 6 and info["bytes"] == info["windows"] * 1000 * 128
     assert many.msm(hm, sc) == want and many.msm_stats()["tables"]
     many.srs_precompute(hm, bp.SRS_TABLES_OFF)
     assert many.msm(hm, sc) == want and not many.msm_stats()["tables"]
@@ -128,19 +128,22 @@ def test_group_context_round3_by_coset(members, peer, monkeypatch):
         cols, pk, public = synthetic_circuit(pn, seed)
         blinders = [random.Random(seed).randrange(1, Q) for _ in range(11)]
         want = None
-        for ctx, split in ((one, "1"), (many, "1"), (many, "0")):
+        for ctx, split, early in ((one, "1", "1"), (many, "1", "1"), (many, "1", "0"), (many, "0", "0")):
             monkeypatch.setenv("BP_PROVE_COSET_SPLIT", split)
+            monkeypatch.setenv("BP_PROVE_COSET_EARLY", early)      # a, b, c, PI to the members after round 1 (default) or in round 3
             setup = bp.Setup.generate_srs(pn + 6, 0xC05E7 + pn, ctx)
             circuit = bp.Circuit({k: PR.SV(v) for k, v in pk.items()}, ctx)
             blob = bp.Prover(setup, circuit).prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), None, blinders)
             want = want or blob
-            assert blob == want and len(blob) == 624, (pn, members, split)
+            assert blob == want and len(blob) == 624, (pn, members, split, early)
             if ctx is many and split == "1" and pn == 1 << 7:
                 bad = [list(c) for c in cols]
                 bad[2][3] = 12345                                         # c no longer equals a * b in row 3
                 with pytest.raises(bp.BpError) as e:
                     bp.Prover(setup, circuit).prove_with_blinding(PR.SV(bad[0]), PR.SV(bad[1]), PR.SV(bad[2]), None, blinders)
                 assert e.value.code == -11
+                # the abandoned proof's early work on the members must not leak into the next one
+                assert bp.Prover(setup, circuit).prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), None, blinders) == want
             circuit.free()
     many.close()
     one.close()
