@@ -9,7 +9,7 @@ FETCH.csv / WRITE.csv are the *_counter_collection.csv files of two separate run
 Counter values are KB per dispatch.  Corrections (MI355X_MICROARCH.md, HBM section, calibrated in round 1 on known byte counts):
 FETCH_SIZE tallies a 128-B coalesced read request at 64 B, so kernels that stream 16 B per lane in >= 128-B runs are doubled;
 64-B runs (the strided NTT pass of 2^19: 2^10 x 2 columns) are counted exactly; WRITE_SIZE is exact.  The gathers of msm_accumulate
-(7 x 16 B per lane from random 112-B points) are neither of the guide's calibrated cases: factor 1 is applied, which makes the
+(7 x 16 B per lane from random 112-B points in 128-B slots) are neither of the guide's calibrated cases: factor 1 is applied, which makes the
 reported traffic a LOWER bound -- the true figure lies between 1x and 2x of it (fetch_factor_range)."""
 import argparse
 import collections
@@ -64,7 +64,7 @@ def main():
             "fetch_kb_raw": f, "fetch_factor": 1, "fetch_factor_range": [1, 2], "write_kb": w, "hbm_bytes_per_launch": int((f + w) * 1024),
             "hbm_bytes_per_launch_upper": int((2 * f + w) * 1024),
             "algorithmic_bytes_per_launch": 128 << log_n, "source": src,
-            "note": "one 112-B point gathered per (scalar, window): W x 112 B + 64-B sector rounding; lower bound (scattered 7 x dwordx4 gathers are "
+            "note": "one 112-B point (in its 128-B slot, one cache line) gathered per (scalar, window): algorithmic W x 112 B; lower bound (scattered 7 x dwordx4 gathers are "
                     "uncalibrated: between 1x and 2x of FETCH_SIZE); integer-issue bound kernel"}
     passes, total = {}, 0.0
     for name in ("ntt_pass_strided", "ntt_pass_last", "ntt_small"):
