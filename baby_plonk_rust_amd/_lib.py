@@ -56,6 +56,7 @@ SIGNATURES = {
     "bp_prove_last_stats": (_int, [_vp, _vp, _pp(C.c_float)]),
     "bp_transcript_test_vector": (_int, [_vp]),
     "bp_msm_g1": (_int, [_vp, _u64, _vp, _sz, _int, _vp]),
+    "bp_msm_g1_projective144": (_int, [_vp, _vp, _sz, _vp, _sz, _int, _vp]),
     "bp_msm_g1_partial": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),
     "bp_msm_g1_blob_device": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),
     "bp_msm_g1_blob_device_async": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),

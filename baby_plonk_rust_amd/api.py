@@ -111,6 +111,16 @@ class Context:
         self.check(self._lib.bp_srs_load_projective144(self._h, buf.ctypes.data, n, C.byref(h)), "bp_srs_load_projective144")
         return h.value
 
+    def msm_projective144(self, points144, scalars, fmt=FR_MONT):
+        """BucketMSM::bucket_msm(&[G1Projective], &[Scalar]) in one call, nothing cached: upload in two pieces, multiply the first behind the upload of the second"""
+        buf = points144 if isinstance(points144, np.ndarray) else np.frombuffer(bytes(points144), dtype=np.uint8)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        s = _fr_array(scalars) if fmt == FR_MONT else np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        out = np.zeros(96, dtype=np.uint8)
+        self.check(self._lib.bp_msm_g1_projective144(self._h, buf.ctypes.data, len(buf) // 144, s.ctypes.data, len(s), fmt, out.ctypes.data),
+                   "bp_msm_g1_projective144")
+        return out.tobytes()
+
     def srs_generate(self, powers, tau_int):
         t, h = np.frombuffer((tau_int % Q).to_bytes(32, "little"), dtype=np.uint8).copy(), C.c_uint64()
         self.check(self._lib.bp_srs_generate(self._h, powers, t.ctypes.data, C.byref(h)), "bp_srs_generate")

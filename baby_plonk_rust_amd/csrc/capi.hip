@@ -406,6 +406,12 @@ void bp_destroy(bp_ctx* ctx) {
       (void)hipEventDestroy(e);
       e = nullptr;
     }
+  for (auto& e : ctx->seam_ev)
+    if (e) {
+      DeviceGuard guard(ctx->device);
+      (void)hipEventDestroy(e);
+      e = nullptr;
+    }
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)stream_wait(ctx->stream);
   for (auto& kv : ctx->ws)
@@ -1049,6 +1055,101 @@ int bp_msm_g1(bp_ctx* ctx, uint64_t srs_handle, const void* scalars, size_t n_sc
   g1_proj r;
   memcpy(&r, part, 144);
   host_encode96(out96, r);
+  return BP_OK;
+}
+
+// BucketMSM::bucket_msm(points: &[G1Projective], scalars: &[Scalar], ..) (src/msm.rs:76-81) with nothing cached.  From 2^17 pairs the
+// operands cross PCIe in pieces on the side context's stream (scalars, points, normalisation, 28-bit copy; the host blocks in the
+// pageable copies) while the main stream multiplies the piece before, out of workspaces instead of an SRS entry.  Measured at 2^20
+// pairs: the three calls 8.9 ms (upload 2.7 + normalise 1.1 + allocations, multiply 4.6 with the scalars' upload, free 0.4); one piece
+// 8.6, two pieces 8.3, three 10.2, four 11.6 -- a multiplication without tables pays ~0.8 ms of sort, running-sum reduction and
+// host epilogue per piece whatever its size, so two pieces (BP_SEAM_PIECES: 1..4) are where the overlap still wins.
+constexpr int SEAM_PIECES = 4;
+static double seam_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static_assert(SEAM_PIECES <= MSM_SLOTS, "one pinned result slot per piece");
+int bp_msm_g1_projective144(bp_ctx* ctx, const uint8_t* points144, size_t n_points, const void* scalars, size_t n_scalars, int scalar_fmt,
+                            uint8_t out96[96]) {
+  if (!ctx || !out96 || !fmt_ok(scalar_fmt) || (n_points && !points144) || (n_scalars && !scalars)) return BP_ERR_INVALID_ARG;
+  const size_t n = std::min(n_points, n_scalars);
+  if (is_group(ctx) || n < ((size_t)1 << 17)) {
+    uint64_t h = 0;
+    BP_TRY(bp_srs_load_projective144(ctx, points144, n, &h));
+    int rc = bp_msm_g1(ctx, h, scalars, n, scalar_fmt, out96);
+    const std::string msg = ctx->last_error;
+    (void)bp_srs_free(ctx, h);
+    if (rc != BP_OK) ctx->last_error = msg;
+    return rc;
+  }
+  DeviceGuard guard(ctx->device);
+  bp_ctx* side;
+  BP_TRY(side_ctx_get(ctx, &side));
+  for (auto& e : ctx->seam_ev)
+    if (!e) BP_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  int pieces = 2;
+  {
+    const char* v = getenv("BP_SEAM_PIECES");
+    if (v && *v >= '1' && *v <= '0' + SEAM_PIECES && !v[1]) pieces = *v - '0';
+  }
+  const bool trace = getenv("BP_SEAM_TRACE") != nullptr;
+  const double t_begin = seam_now_ms();
+  const size_t piece = (n + pieces - 1) / pieces;
+  uint8_t* d_proj;
+  g1_affine* d_aff;
+  g1_affine28* d_p28;
+  fr_t* d_scal;
+  BP_TRY(ws_get(ctx, "seam.proj", piece * 144, (void**)&d_proj));
+  BP_TRY(ws_get(ctx, "seam.affine", n * sizeof(g1_affine), (void**)&d_aff));
+  BP_TRY(ws_get(ctx, "seam.p28", n * sizeof(g1_affine28), (void**)&d_p28));
+  BP_TRY(ws_get(ctx, "seam.scalars", n * sizeof(fr_t), (void**)&d_scal));
+  BP_HIP(ctx, stream_wait(ctx->stream));                 // the workspaces may still be read by work the caller enqueued before
+  MsmPending pend[SEAM_PIECES];
+  int launched = 0, rc = BP_OK;
+  for (int k = 0; k < pieces && rc == BP_OK; k++) {
+    const size_t lo = (size_t)k * piece, cnt = lo < n ? std::min(piece, n - lo) : 0;
+    if (!cnt) break;
+    if (trace) fprintf(stderr, "seam piece %d: begin %.3f ms\n", k, seam_now_ms() - t_begin);
+    hipError_t he = hipMemcpyAsync(d_scal + lo, (const uint8_t*)scalars + lo * 32, cnt * 32, hipMemcpyHostToDevice, side->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_proj, points144 + lo * 144, cnt * 144, hipMemcpyHostToDevice, side->stream);
+    if (he != hipSuccess) {
+      rc = fail(ctx, BP_ERR_HIP, "bucket_msm operands upload", he, __FILE__, __LINE__);
+      break;
+    }
+    if (trace) fprintf(stderr, "seam piece %d: uploads returned %.3f ms\n", k, seam_now_ms() - t_begin);
+    rc = srs_from_projective_run(side, (const g1_proj*)d_proj, cnt, d_aff + lo);
+    if (rc == BP_OK) rc = srs_to28_into(side, d_aff + lo, cnt, d_p28 + lo);
+    if (rc != BP_OK) {
+      ctx->last_error = side->last_error;
+      break;
+    }
+    he = hipEventRecord(ctx->seam_ev[k], side->stream);
+    if (he == hipSuccess) he = hipStreamWaitEvent(ctx->stream, ctx->seam_ev[k], 0);
+    if (he != hipSuccess) {
+      rc = fail(ctx, BP_ERR_HIP, "bucket_msm piece order", he, __FILE__, __LINE__);
+      break;
+    }
+    rc = msm_launch(ctx, d_p28 + lo, cnt, d_scal + lo, scalar_fmt, 0, 0, k, nullptr, &pend[k]);
+    if (rc == BP_OK) launched = k + 1;
+    if (trace) fprintf(stderr, "seam piece %d: launched %.3f ms\n", k, seam_now_ms() - t_begin);
+  }
+  // every launched piece is finished (waited for) even after an error: the pinned slots and workspaces must be quiet on return
+  g1_proj acc = g1_identity();
+  uint64_t adds = 0;
+  for (int k = 0; k < launched; k++) {
+    g1_proj part;
+    const int r2 = msm_finish(ctx, pend[k], &part);
+    if (r2 != BP_OK && rc == BP_OK) rc = r2;
+    if (r2 == BP_OK) {
+      g1_add(acc, acc, part);
+      adds += pend[k].adds;
+    }
+    if (trace) fprintf(stderr, "seam piece %d: finished %.3f ms\n", k, seam_now_ms() - t_begin);
+  }
+  if (rc != BP_OK) {
+    (void)stream_wait(side->stream);
+    return rc;
+  }
+  ctx->msm_adds = adds;
+  host_encode96(out96, acc);
   return BP_OK;
 }
 

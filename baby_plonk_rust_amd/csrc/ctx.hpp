@@ -100,6 +100,7 @@ struct bp_ctx {
   // the commitments' latency-bound tails and the host's transcript steps leave idle.  side_ev: [0] inputs ready, [1] side work done.
   bp_ctx* side = nullptr;
   hipEvent_t side_ev[2] = {nullptr, nullptr};
+  hipEvent_t seam_ev[4] = {nullptr, nullptr, nullptr, nullptr};      // bp_msm_g1_projective144: piece k uploaded and normalised (recorded on the side stream)
   hipStream_t stream = nullptr;
   bool own_stream = true;
   std::string last_error;
@@ -199,6 +200,7 @@ int commit_many(bp_ctx* ctx, uint64_t srs_handle, const fr_t* const* d_coeffs, c
 int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points28, size_t n, uint32_t c, g1_affine28** d_table,
                    uint32_t* windows);
 int srs_to28_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28** d_out);
+int srs_to28_into(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28* d_out);      // the same into a buffer of the caller's, on ctx->stream
 int ntt_init_tables(bp_ctx* ctx);
 int ntt_run(bp_ctx* ctx, fr_t* d_data, uint32_t log_n, int inverse, size_t batch, size_t stride);
 // one transform in two phases over the members of a group context (ntt.hip)

@@ -145,6 +145,12 @@ int srs_to28_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28** d_o
   return BP_OK;
 }
 
+int srs_to28_into(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28* d_out) {
+  if (n) hipLaunchKernelGGL(srs_to28, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, n, d_out);
+  BP_HIP(ctx, hipGetLastError());
+  return BP_OK;
+}
+
 uint32_t msm_table_windows(uint32_t c) {
   if (c & MSM_NAF_FLAG) return MSM_NAF_ROWS;
   MsmPlan plan;

@@ -93,33 +93,43 @@ __global__ void __launch_bounds__(256) srs_encode96(const g1_affine* __restrict_
 }
 
 // G1Projective memory images (x | y | z Montgomery limbs, g1.rs:442-446) -> affine, the device side of
-// bp_srs_load_projective144.  One lane normalises PROJ_GROUP consecutive points with one shared inversion (Montgomery's
-// trick, G1Projective::batch_normalize g1.rs:806-839); z = 0 (the identity) becomes (0, 0).
-constexpr int PROJ_GROUP = 8;
-__global__ void __launch_bounds__(256) srs_from_projective(const g1_proj* __restrict__ in, size_t n, g1_affine* __restrict__ out) {
-  const size_t base = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * PROJ_GROUP;
-  if (base >= n) return;
-  const uint32_t cnt = n - base < (size_t)PROJ_GROUP ? (uint32_t)(n - base) : (uint32_t)PROJ_GROUP;
-  fp_t prefix[PROJ_GROUP];                          // prefix[j] = z'_0 ... z'_j with z' = z, or 1 where z = 0
-  for (uint32_t j = 0; j < cnt; j++) {
-    fp_t z = in[base + j].z;
-    if (big_is_zero(z)) z = Fp::one();
-    if (j == 0) prefix[0] = z; else Fp::mul(prefix[j], prefix[j - 1], z);
+// bp_srs_load_projective144.  One lane normalises `group` points with one shared inversion (Montgomery's trick,
+// G1Projective::batch_normalize g1.rs:806-839); z = 0 (the identity) becomes (0, 0).  The inversion (a 381-bit power, ~570
+// multiplications) is most of what the kernel costs: one per 8 points made 131 072 of them at 2^20 points, 1.77 ms; one per 16: 1.1 ms.  A lane's points are
+// `lanes` apart (lane, lane + lanes, ...: neighbouring lanes read neighbouring points) and the running products z'_0 ... z'_j wait in
+// the x field of the output slot j, so the group can be as long as the launch wants.
+__global__ void __launch_bounds__(256) srs_from_projective(const g1_proj* __restrict__ in, size_t n, uint32_t group, g1_affine* __restrict__ out) {
+  const size_t lanes = (n + group - 1) / group;
+  const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= lanes) return;
+  fp_t run = Fp::one();
+  uint32_t cnt = 0;
+  for (size_t i = lane; i < n; i += lanes, cnt++) {
+    fp_t z = in[i].z;
+    if (big_is_zero(z)) z = Fp::one();                  // z' = z, or 1 where z = 0
+    if (cnt == 0) run = z; else Fp::mul(run, run, z);
+    out[i].x = run;
   }
   fp_t inv;
-  fp_invert(inv, prefix[cnt - 1]);
+  fp_invert(inv, run);
   for (uint32_t j = cnt; j-- > 0;) {
-    const g1_proj p = in[base + j];
+    const size_t i = lane + (size_t)j * lanes;
+    const g1_proj p = in[i];
     const bool inf = big_is_zero(p.z);
     fp_t z = p.z, zinv;
     if (inf) z = Fp::one();
-    if (j) Fp::mul(zinv, inv, prefix[j - 1]); else zinv = inv;
+    if (j) {
+      const fp_t before = out[i - lanes].x;
+      Fp::mul(zinv, inv, before);
+    } else {
+      zinv = inv;
+    }
     Fp::mul(inv, inv, z);
     g1_affine r;
     Fp::mul(r.x, p.x, zinv);
     Fp::mul(r.y, p.y, zinv);
     if (inf) { r.x = Fp::zero(); r.y = Fp::zero(); }
-    out[base + j] = r;
+    out[i] = r;
   }
 }
 

@@ -218,17 +218,16 @@ struct BucketMSM {
 
 // G1Projective as the reference keeps it in memory (g1.rs:442-446): x | y | z, 6 x u64 Montgomery limbs each
 using G1ProjectiveImage = std::array<uint8_t, 144>;
-// the literal seam bucket_msm(points: &[G1Projective], scalars: &[Scalar], b, c) (msm.rs:76-81): upload, multiply, free
+// the literal seam bucket_msm(points: &[G1Projective], scalars: &[Scalar], b, c) (msm.rs:76-81), nothing cached: one call that
+// uploads the operands in two pieces and multiplies the first while the second is on its way
 inline G1 bucket_msm_projective(const std::vector<G1ProjectiveImage>& points, const std::vector<Scalar>& scalars, size_t b = 256,
                                 size_t c = 4, Context& ctx = Context::global()) {
   std::vector<uint8_t> eff;
   const int fmt = msm_scalars_as_walked(ctx, scalars, b, c, eff);
-  uint64_t h = 0;
-  ctx.check(bp_srs_load_projective144(ctx.raw(), points.empty() ? nullptr : points[0].data(), points.size(), &h), "bucket_msm: points");
   G1 out{};
-  int rc = bp_msm_g1(ctx.raw(), h, fmt == BP_FR_MONT ? (const void*)scalars.data() : (const void*)eff.data(), scalars.size(), fmt, out.data());
-  bp_srs_free(ctx.raw(), h);
-  ctx.check(rc, "bucket_msm");
+  ctx.check(bp_msm_g1_projective144(ctx.raw(), points.empty() ? nullptr : points[0].data(), points.size(),
+                                    fmt == BP_FR_MONT ? (const void*)scalars.data() : (const void*)eff.data(), scalars.size(), fmt, out.data()),
+            "bucket_msm");
   return out;
 }
 

@@ -95,6 +95,13 @@ int  bp_srs_load(bp_ctx* ctx, const uint8_t* points96, size_t n, uint64_t* srs_h
  * G1Projective::batch_normalize does on the host, g1.rs:806-839); z = 0 is the identity.  No curve check: the type
  * guarantees it (as G1Affine::from(&G1Projective) assumes). */
 int  bp_srs_load_projective144(bp_ctx* ctx, const uint8_t* points144, size_t n, uint64_t* srs_handle);
+/* The same seam as ONE call, nothing cached: result = sum_i scalars[i] * points[i] over min(n_points, n_scalars) pairs (the zip of
+ * msm.rs:85), both operands in host memory.  Equivalent to bp_srs_load_projective144 + bp_msm_g1 + bp_srs_free, but the operands cross
+ * PCIe in two pieces and the multiplication of the first runs while the second is uploaded and normalised, out of workspaces instead
+ * of an SRS entry (from 2^17 pairs; below that, and on bp_init_multi contexts, it is the three calls): 8.3 against 8.9 ms at 2^20.  Statistics afterwards (bp_msm_last_stats): additions of all pieces,
+ * times of the last piece. */
+int  bp_msm_g1_projective144(bp_ctx* ctx, const uint8_t* points144, size_t n_points, const void* scalars, size_t n_scalars, int scalar_fmt,
+                             uint8_t out96[96]);
 /* Setup::generate_srs(powers, tau) (setup.rs:12-31): P_i = tau^i * G, generated on the GPU. tau: 32-byte LE. */
 int  bp_srs_generate(bp_ctx* ctx, size_t powers, const uint8_t tau32[32], uint64_t* srs_handle);
 /* Synthetic benchmark points P_i = (a + i*d) * G, generated on the GPU. */

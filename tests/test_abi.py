@@ -189,4 +189,5 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.bp_msm_blobs_combine(out.ctypes.data, 0, None) == -1
     assert lib.bp_msm_g1_blob_device(None, 1, 0, None, 0, 1, 0, None) == -1
     assert lib.bp_srs_load_projective144(None, None, 0, None) == -1
+    assert lib.bp_msm_g1_projective144(None, None, 0, None, 0, 1, None) == -1
     assert lib.bp_srs_export_projective144(None, 1, 0, 0, None) == -1

@@ -303,6 +303,49 @@ def test_projective_image_seam():
     assert many.srs_export(hm) == ctx.srs_export(h) and many.msm(hm, sc) == ctx.msm(h, sc)
 
 
+def test_projective_seam_in_one_call(monkeypatch):
+    """bp_msm_g1_projective144 = bucket_msm(&[G1Projective], &[Scalar]) with nothing cached: from 2^17 pairs the operands go up in
+    pieces (two; BP_SEAM_PIECES) and the multiplication of a piece runs behind the upload of the next.  Same bytes as load + multiply + free and as
+    the closed form; the zip truncates to the shorter operand; the small-size and group-context forms are the three calls."""
+    ctx = bp.Context(0)
+    n, a, d = (1 << 17) + 77, Q - 99991, 0x0F1E2D3C4B5A6978
+    h = ctx.srs_generate_progression(n, a, d)
+    img = ctx.srs_export_projective144(h)                       # z = 1 images ...
+    g = O.g1_generator()
+    for at, k in ((0, 0), (5, 7), (n // 2, Q - 2), (n - 1, 0)):  # ... with an identity first and last and two really projective points inside
+        img[144 * at: 144 * (at + 1)] = np.frombuffer(O.g1_mul(g, O.fr_from_int(k)).tobytes(), dtype=np.uint8)
+    sc = O.splitmix_scalars(n, 0x5EA3)
+    ints = O.fr_array_to_ints(sc)
+    coef = {0: 0, 5: 7, n // 2: Q - 2, n - 1: 0}
+    want = M.enc96(M.ec_mul(sum(s * coef.get(i, (a + i * d) % Q) for i, s in enumerate(ints)) % Q))
+    h2 = ctx.srs_load_projective144(img)
+    assert ctx.msm(h2, sc) == want
+    for pieces in ("1", "2", "3", "4", "0"):                   # "0" is out of range: the default
+        monkeypatch.setenv("BP_SEAM_PIECES", pieces)
+        assert ctx.msm_projective144(img, sc) == want, pieces
+        assert 0 < ctx.msm_stats()["mixed_adds"] <= 64 * n
+    monkeypatch.setenv("BP_SEAM_PIECES", "4")                   # the most pieces for the edge cases below
+    # fewer scalars than points and fewer points than scalars
+    m = n - 12345
+    assert ctx.msm_projective144(img, sc[:m]) == ctx.msm(h2, sc[:m])
+    assert ctx.msm_projective144(img[: 144 * m], sc) == ctx.msm(h2, sc[:m])
+    # canonical bytes; a scalar >= q in the third piece of four is refused, and the next call is unaffected
+    le = np.frombuffer(b"".join(s.to_bytes(32, "little") for s in ints), dtype=np.uint8).reshape(-1, 32).copy()
+    assert ctx.msm_projective144(img, le, fmt=bp.FR_BYTES_LE) == want
+    le[(5 * n) // 8] = 0xFF
+    with pytest.raises(bp.BpError) as e:
+        ctx.msm_projective144(img, le, fmt=bp.FR_BYTES_LE)
+    assert e.value.code == -4
+    assert ctx.msm_projective144(img, sc) == want
+    # small sizes and a group context: the three calls underneath
+    assert ctx.msm_projective144(img[: 144 * 1000], sc[:1000]) == ctx.msm(h2, sc[:1000])
+    assert ctx.msm_projective144(img[:0], sc[:0]) == M.enc96(None)
+    many = bp.Context([0, 0])
+    assert many.msm_projective144(img, sc) == want
+    many.close()
+    ctx.close()
+
+
 def test_group_context_edges():
     """a one-device list is an ordinary context; a bad device id fails like bp_init; records are refused on a group context (it
     combines its own shards); handles of one context mean nothing to another"""

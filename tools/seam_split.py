@@ -23,6 +23,13 @@ sc = O.splitmix_scalars(n, 99)
 want = ctx.msm(h0, sc)
 for i in range(args.reps + 1):
     t0 = time.perf_counter()
+    r = ctx.msm_projective144(images, sc)
+    t1 = time.perf_counter()
+    assert r == want
+    if i:
+        print("2^%d: one call (pieces, multiply behind the upload) %.2f ms" % (args.log_n, 1e3 * (t1 - t0)), flush=True)
+for i in range(args.reps + 1):
+    t0 = time.perf_counter()
     h = ctx.srs_load_projective144(images)
     t1 = time.perf_counter()
     r = ctx.msm(h, sc)
