@@ -1065,7 +1065,6 @@ int bp_msm_g1(bp_ctx* ctx, uint64_t srs_handle, const void* scalars, size_t n_sc
 // 8.6, two pieces 8.3, three 10.2, four 11.6 -- a multiplication without tables pays ~0.8 ms of sort, running-sum reduction and
 // host epilogue per piece whatever its size, so two pieces (BP_SEAM_PIECES: 1..4) are where the overlap still wins.
 constexpr int SEAM_PIECES = 4;
-static double seam_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static_assert(SEAM_PIECES <= MSM_SLOTS, "one pinned result slot per piece");
 int bp_msm_g1_projective144(bp_ctx* ctx, const uint8_t* points144, size_t n_points, const void* scalars, size_t n_scalars, int scalar_fmt,
                             uint8_t out96[96]) {
@@ -1090,8 +1089,6 @@ int bp_msm_g1_projective144(bp_ctx* ctx, const uint8_t* points144, size_t n_poin
     const char* v = getenv("BP_SEAM_PIECES");
     if (v && *v >= '1' && *v <= '0' + SEAM_PIECES && !v[1]) pieces = *v - '0';
   }
-  const bool trace = getenv("BP_SEAM_TRACE") != nullptr;
-  const double t_begin = seam_now_ms();
   const size_t piece = (n + pieces - 1) / pieces;
   uint8_t* d_proj;
   g1_affine* d_aff;
@@ -1107,14 +1104,12 @@ int bp_msm_g1_projective144(bp_ctx* ctx, const uint8_t* points144, size_t n_poin
   for (int k = 0; k < pieces && rc == BP_OK; k++) {
     const size_t lo = (size_t)k * piece, cnt = lo < n ? std::min(piece, n - lo) : 0;
     if (!cnt) break;
-    if (trace) fprintf(stderr, "seam piece %d: begin %.3f ms\n", k, seam_now_ms() - t_begin);
     hipError_t he = hipMemcpyAsync(d_scal + lo, (const uint8_t*)scalars + lo * 32, cnt * 32, hipMemcpyHostToDevice, side->stream);
     if (he == hipSuccess) he = hipMemcpyAsync(d_proj, points144 + lo * 144, cnt * 144, hipMemcpyHostToDevice, side->stream);
     if (he != hipSuccess) {
       rc = fail(ctx, BP_ERR_HIP, "bucket_msm operands upload", he, __FILE__, __LINE__);
       break;
     }
-    if (trace) fprintf(stderr, "seam piece %d: uploads returned %.3f ms\n", k, seam_now_ms() - t_begin);
     rc = srs_from_projective_run(side, (const g1_proj*)d_proj, cnt, d_aff + lo);
     if (rc == BP_OK) rc = srs_to28_into(side, d_aff + lo, cnt, d_p28 + lo);
     if (rc != BP_OK) {
@@ -1129,7 +1124,6 @@ int bp_msm_g1_projective144(bp_ctx* ctx, const uint8_t* points144, size_t n_poin
     }
     rc = msm_launch(ctx, d_p28 + lo, cnt, d_scal + lo, scalar_fmt, 0, 0, k, nullptr, &pend[k]);
     if (rc == BP_OK) launched = k + 1;
-    if (trace) fprintf(stderr, "seam piece %d: launched %.3f ms\n", k, seam_now_ms() - t_begin);
   }
   // every launched piece is finished (waited for) even after an error: the pinned slots and workspaces must be quiet on return
   g1_proj acc = g1_identity();
@@ -1142,7 +1136,6 @@ int bp_msm_g1_projective144(bp_ctx* ctx, const uint8_t* points144, size_t n_poin
       g1_add(acc, acc, part);
       adds += pend[k].adds;
     }
-    if (trace) fprintf(stderr, "seam piece %d: finished %.3f ms\n", k, seam_now_ms() - t_begin);
   }
   if (rc != BP_OK) {
     (void)stream_wait(side->stream);
