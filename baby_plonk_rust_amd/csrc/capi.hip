@@ -681,7 +681,9 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
     uint32_t lg = 0;
     const uint64_t n = lead->n;
     while ((2ull << lg) <= n) lg++;                       // floor(log2 n)
-    if (lg >= 20) {                   // 13 windows instead of 16: pays once the sort and the 2^19-bucket tree are small against
+    if (lg >= 24) {                   // 12 windows: the 2^21-bucket tree (+0.8 ms) against n fewer additions (-1.8 ms at 2^24; a tie at 2^23)
+      c = 22;
+    } else if (lg >= 20) {            // 13 windows instead of 16: pays once the sort and the 2^19-bucket tree are small against
       c = 20;                         // 3 x n additions (round 3: -3 % at 2^20, -6 % at 2^21, -12 % at 2^22; profiles/r03_window_width_ab.txt)
     } else if (n >= (1u << 14)) {     // throughput regime: reduction work 2^c stays below the bucket-add work W * n
       c = lg + 2 > 16 ? 16 : lg + 2;

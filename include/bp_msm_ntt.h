@@ -117,7 +117,7 @@ int  bp_srs_free(bp_ctx* ctx, uint64_t srs_handle);
  * (windows x srs_len x 128 bytes -- a 112-byte point per 128-byte cache line: 1.7 GB at 2^20 points, 28 GB at 2^24).  With tables every window of an
  * MSM feeds one shared bucket set, so the bucket reduction and the Horner epilogue shrink from `windows`
  * passes to one; results are the same group element.  window_bits: 0 = chosen from srs_len (16 below 2^20 points, 20 -- thirteen
- * windows -- from 2^20 points), BP_SRS_TABLES_OFF = drop the tables, else 4..24 (above 16 the bucket sort is partitioned).  MSMs shorter than 2^window_bits / 8 scalars keep
+ * windows -- from 2^20 points, 22 from 2^24), BP_SRS_TABLES_OFF = drop the tables, else 4..24 (above 16 the bucket sort is partitioned).  MSMs shorter than 2^window_bits / 8 scalars keep
  * using the table-free path.  The reference has no counterpart (its MSM recomputes from the raw points).
  * window_bits = 256 + w (w = 6..22): tables of EVERY bit position, T[p][i] = 2^p * P_i for p < 256 (256 x srs_len x 128 bytes:
  * 32 GiB at 2^20 points), used with the scalars' width-w non-adjacent form: ~256 / (w + 1) + 0.5 bucket additions per scalar
