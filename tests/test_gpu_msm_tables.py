@@ -179,10 +179,13 @@ def test_full_size_2p24_closed_form_both_paths(ctx):
     want = M.enc96(M.ec_mul(O.dot_progression(sc, a, d)))
     plain = bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n))
     assert plain == want and not ctx.msm_stats()["tables"]
-    info = ctx.srs_precompute(h)                                     # auto width: 20 bits = 13 windows from 2^23 points (partitioned sort)
-    assert info["window_bits"] == 20 and info["windows"] == 13 and info["bytes"] == 13 * n * 128
+    info = ctx.srs_precompute(h)                                     # auto width at 2^24 points: 22 bits = 12 windows, 2^21 buckets (two-level radix sort)
+    assert info["window_bits"] == 22 and info["windows"] == 12 and info["bytes"] == 12 * n * 128
     assert bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n)) == want and ctx.msm_stats()["tables"]
-    assert ctx.msm_stats()["window_bits"] == 20
+    assert ctx.msm_stats()["window_bits"] == 22
+    info = ctx.srs_precompute(h, 20)                                 # the width of 2^20 .. 2^23 points
+    assert info["window_bits"] == 20 and info["windows"] == 13 and info["bytes"] == 13 * n * 128
+    assert bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n)) == want and ctx.msm_stats()["window_bits"] == 20
     info = ctx.srs_precompute(h, 16)                                 # and the one-histogram-per-window width at the same size
     assert info["window_bits"] == 16 and info["bytes"] == 16 * n * 128
     assert bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n)) == want and ctx.msm_stats()["tables"]
