@@ -31,3 +31,28 @@ for cycle in range(6):
     print("cycle", cycle, "device MiB in use: %.1f" % u, flush=True)
 assert abs(used() - base) < 8, "device memory grows across load/free cycles"
 print("no growth after warm-up")
+
+# group contexts come and go (members, worker threads, coset shares and their work contexts), and the one-call seam's workspaces
+from oracle import oracle as O
+base = None
+img = None
+for cycle in range(5):
+    many = bp.Context([0, 0, 0, 0])
+    setup = bp.Setup.generate_srs(n + 6, 777 + cycle, many)
+    circuit = bp.Circuit(pk, many)
+    prover = bp.Prover(setup, circuit)
+    for _ in range(3):
+        blob2 = prover.prove_with_blinding(cols[0], cols[1], cols[2], None, list(range(1, 12)))
+    m = (1 << 17) + 3
+    h = many.srs_generate_progression(m, 3, 5)
+    if img is None:
+        img = many.srs_export_projective144(h)
+    sc = O.splitmix_scalars(m, 5)
+    assert many.msm_projective144(img, sc) == ctx.msm_projective144(img, sc)
+    many.close()
+    u = used()
+    if cycle == 1:
+        base = u
+    print("group cycle", cycle, "device MiB in use: %.1f" % u, flush=True)
+assert abs(used() - base) < 8, "device memory grows across group-context cycles"
+print("no growth across group contexts")
