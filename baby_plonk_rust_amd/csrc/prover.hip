@@ -496,7 +496,10 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   // Round 3's evaluations of a, b, c and PI on the quotient coset (prover.rs:386-450) depend on no challenge: they are enqueued on the
   // side context's stream once round 1's commitments are in (beside them they only took the GPU from three concurrent pipelines:
   // +2.6 ms on round 1 for -1.9 on round 3) and run beside round 2 -- one commitment, whose sort and tree leave most of the chip idle,
-  // and the host's transcript steps.  Round 3 waits for the second event and transforms z alone.  BP_PROVE_SIDE=0: all five in round 3.
+  // and the host's transcript steps.  Round 3 waits for the second event and transforms z alone.  That pays while the commitment's
+  // accumulation leaves the chip partly idle: below 2^20 gates (-0.05 .. -0.15 ms per proof at 2^16 / 2^18).  From 2^20 msm_accumulate
+  // fills every SIMD for 2 ms and whatever runs beside it only delays its workgroups (+0.4 ms per proof), so all five transforms stay
+  // in round 3 there.  BP_PROVE_SIDE=0 / 1 forces either.
   fr_t* ev;
   BP_TRY(ws_get(ctx, "prove.coset_wit", 5 * N * sizeof(fr_t), (void**)&ev));         // a | b | c | z | PI evaluations
   const unsigned blocks_N = (unsigned)((N + 255) / 256);
@@ -505,10 +508,11 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
     const char* v = getenv("BP_PROVE_COSET_SPLIT");
     if (v && *v == '0') split_on = false;
   }
-  bool side_on = !split_on;
+  bool side_on = !split_on && k < 20;
   {
     const char* v = getenv("BP_PROVE_SIDE");
     if (v && *v == '0') side_on = false;
+    if (v && *v == '1') side_on = !split_on;
   }
   bool early_on = split_on;                // a, b, c, PI to the members' cosets now, beside the commitments (BP_PROVE_COSET_EARLY=0: in round 3)
   {

@@ -120,7 +120,7 @@ def test_witness_that_does_not_satisfy_the_circuit_is_rejected():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("logn", [4, 10])
-def test_synthetic_circuit_native_vs_oracle_restatement(logn):
+def test_synthetic_circuit_native_vs_oracle_restatement(logn, monkeypatch):
     from oracle import oracle as O
     from tests.test_gpu_prover_rounds import decode, g1_only_verify, prove_with_blinding, synthetic_circuit
     n, tau = 1 << logn, 0x1234567
@@ -143,6 +143,10 @@ def test_synthetic_circuit_native_vs_oracle_restatement(logn):
     t = [torch.from_numpy(PR.SV(c).view(np.int64)).cuda() for c in cols]
     torch.cuda.synchronize()
     assert prover.prove_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, blinders) == blob
+    # round 3's challenge-free coset transforms on the side stream (the default below 2^20 gates) or in round 3 itself (from 2^20)
+    for side in ("0", "1"):
+        monkeypatch.setenv("BP_PROVE_SIDE", side)
+        assert prover.prove_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, blinders) == blob, side
     circuit.free()
 
 
