@@ -1972,7 +1972,7 @@ int bp_prove(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_handle, const vo
     else BP_HIP(ctx, hipMemsetAsync(wit + (size_t)k * n, 0, n * sizeof(fr_t), ctx->stream));
   }
   if (scalar_fmt == BP_FR_BYTES_LE) BP_TRY(fr_convert_run(ctx, wit, 4 * n, 0));
-  return prove_run(ctx, srs_handle, it->second, wit, blind, proof);
+  return prove_run(ctx, srs_handle, it->second, wit, blind, proof, public_input == nullptr);
 }
 int bp_prove_last_stats(bp_ctx* ctx, float round_ms[5], float* total_ms) {
   if (!ctx) return BP_ERR_INVALID_ARG;

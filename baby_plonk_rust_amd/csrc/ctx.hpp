@@ -233,7 +233,8 @@ int side_ctx_get(bp_ctx* ctx, bp_ctx** out);       // creates ctx->side and its 
 int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out);
 int circuit_split_build(bp_ctx* ctx, CircuitEntry& e);      // leader of a group: the members' coset shares (prover.hip)
 void circuit_release(CircuitEntry& e);
-int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_wit, const fr_t blind[11], uint8_t proof[624]);
+// pi_zero: the caller passed no public inputs, so the PI column of d_wit is all zero (PI(X) = 0: its transforms are skipped, not computed)
+int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_wit, const fr_t blind[11], uint8_t proof[624], bool pi_zero = false);
 void transcript_test_vector(uint8_t out32[32]);
 
 // ---- host-side helpers (host.cpp part of capi.hip) ---------------------------------------------------

@@ -358,7 +358,8 @@ int circuit_split_build(bp_ctx* ctx, CircuitEntry& e) {
 //  late:  once z's coefficients exist, its copy / fold / transform, the quotient on each coset, the inverse transform, the
 //         unscaling by s_j^-i and the copy of the n coefficients back to the leader, which recombines the four residues.
 // slots: a, b, c, z, PI (the order quotient_coset reads); `which` selects the slots a call handles.
-static int coset_inputs(bp_ctx* ctx, const CircuitEntry& cir, const CosetShare& sh, const fr_t* const coefs5[5], const size_t lens5[5], unsigned which, fr_t** ev_out) {
+static int coset_inputs(bp_ctx* ctx, const CircuitEntry& cir, const CosetShare& sh, const fr_t* const coefs5[5], const size_t lens5[5], unsigned which, fr_t** ev_out,
+                        bool zero_pi = false) {
   const uint32_t k = cir.log_n;
   const size_t n = (size_t)1 << k, N = 4 * n, cap = n + 8;
   const unsigned blocks = (unsigned)((n + 255) / 256);
@@ -380,6 +381,7 @@ static int coset_inputs(bp_ctx* ctx, const CircuitEntry& cir, const CosetShare& 
     fr_t sn = gn;                                                     // s_j^n = g^n i4^j
     for (uint32_t q = 0; q < j; q++) sn = fmul(sn, i4);
     fr_t* e = ev + (size_t)c * 5 * n;
+    if (zero_pi) BP_HIP(ctx, hipMemsetAsync(e + 4 * n, 0, n * sizeof(fr_t), w->stream));      // PI(X) = 0 on every coset
     for (int p = 0; p < 5; p++)
       if (which >> p & 1)
         hipLaunchKernelGGL(fr_fold_scale, dim3(blocks), dim3(256), 0, w->stream, cf + (size_t)p * cap, lens5[p], n, sn, sh.spow + (size_t)c * n, e + (size_t)p * n);
@@ -403,18 +405,19 @@ static int coset_inputs(bp_ctx* ctx, const CircuitEntry& cir, const CosetShare& 
   return BP_OK;
 }
 
-static int round3_coset_early(bp_ctx* ctx, const CircuitEntry& cir, const fr_t* const coefs5[5], const size_t lens5[5]) {
+static int round3_coset_early(bp_ctx* ctx, const CircuitEntry& cir, const fr_t* const coefs5[5], const size_t lens5[5], bool pi_zero) {
   BP_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   for (const CosetShare& sh : cir.split) {
     DeviceGuard guard(sh.work->device);
     fr_t* ev;
-    BP_TRY(coset_inputs(ctx, cir, sh, coefs5, lens5, 0x17u, &ev));    // a, b, c, PI
+    BP_TRY(coset_inputs(ctx, cir, sh, coefs5, lens5, pi_zero ? 0x07u : 0x17u, &ev, pi_zero));    // a, b, c, PI
   }
   return BP_OK;
 }
 
 // t (4n coefficients on the leader) = quotient of round 3.  early_done: a, b, c, PI are already on the cosets (round3_coset_early).
-static int round3_by_coset(bp_ctx* ctx, const CircuitEntry& cir, const fr_t* const coefs5[5], const size_t lens5[5], const QuotientArgs& qa0, bool early_done, fr_t* t) {
+static int round3_by_coset(bp_ctx* ctx, const CircuitEntry& cir, const fr_t* const coefs5[5], const size_t lens5[5], const QuotientArgs& qa0, bool early_done,
+                           bool pi_zero, fr_t* t) {
   const uint32_t k = cir.log_n;
   const size_t n = (size_t)1 << k, N = 4 * n;
   const unsigned blocks = (unsigned)((n + 255) / 256);
@@ -426,7 +429,7 @@ static int round3_by_coset(bp_ctx* ctx, const CircuitEntry& cir, const fr_t* con
     bp_ctx* w = sh.work;
     DeviceGuard guard(w->device);
     fr_t *ev, *tq;
-    BP_TRY(coset_inputs(ctx, cir, sh, coefs5, lens5, early_done ? 0x08u : 0x1Fu, &ev));
+    BP_TRY(coset_inputs(ctx, cir, sh, coefs5, lens5, early_done ? 0x08u : (pi_zero ? 0x0Fu : 0x1Fu), &ev, pi_zero && !early_done));
     int rc = ws_get(w, "prove.split_tq", n * sizeof(fr_t), (void**)&tq);
     if (rc != BP_OK) {
       ctx->last_error = w->last_error;
@@ -466,7 +469,7 @@ static int round3_by_coset(bp_ctx* ctx, const CircuitEntry& cir, const fr_t* con
 
 // ------------------------------------------------------------------------------------------------ prove
 // d_wit: a | b | c | PI Lagrange columns (4 x n, Montgomery, device).  blinders: b1..b11 (prover.rs:110).
-int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_wit, const fr_t blind[11], uint8_t proof[624]) {
+int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_wit, const fr_t blind[11], uint8_t proof[624], bool pi_zero) {
   const uint32_t k = cir.log_n;
   const size_t n = (size_t)1 << k, N = 4 * n;
   const fr_t omega = root_of_unity(n), k1 = from_u64(2), k2 = from_u64(3), one = Fr::one();      // prover.rs:99-100
@@ -486,7 +489,7 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   BP_TRY(ws_get(ctx, "prove.abc", 3 * (n + 8) * sizeof(fr_t), (void**)&abc));        // a_coeff | b_coeff | c_coeff, n + 2 each
   BP_TRY(ws_get(ctx, "prove.z", 2 * (n + 8) * sizeof(fr_t), (void**)&zc));           // z (Lagrange -> coefficients) | z_coeff, n + 3
   BP_HIP(ctx, hipMemcpyAsync(coefs, d_wit, 4 * n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
-  BP_TRY(ntt_run(ctx, coefs, k, 1, 4, n));
+  BP_TRY(ntt_run(ctx, coefs, k, 1, pi_zero ? 3 : 4, n));          // no public inputs: PI's column is zero and so are its coefficients
   fr_t* poly_abc[3] = {abc, abc + (n + 8), abc + 2 * (n + 8)};
   const unsigned blocks_n = (unsigned)((n + 8 + 255) / 256);
   for (int j = 0; j < 3; j++)
@@ -521,7 +524,7 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   }
   const fr_t* coefs5[5] = {poly_abc[0], poly_abc[1], poly_abc[2], zc + (n + 8), coefs + 3 * n};
   const size_t lens5[5] = {n + 2, n + 2, n + 2, n + 3, n};
-  if (early_on) BP_TRY(round3_coset_early(ctx, cir, coefs5, lens5));
+  if (early_on) BP_TRY(round3_coset_early(ctx, cir, coefs5, lens5, pi_zero));
   {                                       // three independent commitments in flight together (commit_many)
     const fr_t* polys[3] = {poly_abc[0], poly_abc[1], poly_abc[2]};
     const size_t lens[3] = {n + 2, n + 2, n + 2};
@@ -534,10 +537,11 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
     hipStream_t ss = side->stream;
     BP_HIP(ctx, hipStreamWaitEvent(ss, ctx->side_ev[0], 0));
     for (int j = 0; j < 3; j++) hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, ss, poly_abc[j], n + 2, cir.g_pow, ev + (size_t)j * N, N);
-    hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, ss, coefs + 3 * n, n, cir.g_pow, ev + 4 * N, N);
+    if (pi_zero) BP_HIP(ctx, hipMemsetAsync(ev + 4 * N, 0, N * sizeof(fr_t), ss));
+    else hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, ss, coefs + 3 * n, n, cir.g_pow, ev + 4 * N, N);
     BP_HIP(ctx, hipGetLastError());
     int rc = ntt_run(side, ev, k + 2, 0, 3, N);
-    if (rc == BP_OK) rc = ntt_run(side, ev + 4 * N, k + 2, 0, 1, N);
+    if (rc == BP_OK && !pi_zero) rc = ntt_run(side, ev + 4 * N, k + 2, 0, 1, N);
     if (rc != BP_OK) {
       ctx->last_error = side->last_error;
       return rc;
@@ -570,7 +574,7 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   qa.beta_k1 = fmul(beta, k1); qa.beta_k2 = fmul(beta, k2); qa.one = one;
   for (int j = 0; j < 4; j++) qa.zh_inv[j] = cir.zh_inv[j];
   if (split_on) {
-    BP_TRY(round3_by_coset(ctx, cir, coefs5, lens5, qa, early_on, t));                // t = the 4n quotient coefficients
+    BP_TRY(round3_by_coset(ctx, cir, coefs5, lens5, qa, early_on, pi_zero, t));                // t = the 4n quotient coefficients
   } else {
   if (side_on) {
     hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, z_coeff, n + 3, cir.g_pow, ev + 3 * N, N);
@@ -580,9 +584,10 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   } else {
     for (int j = 0; j < 3; j++) hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, poly_abc[j], n + 2, cir.g_pow, ev + (size_t)j * N, N);
     hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, z_coeff, n + 3, cir.g_pow, ev + 3 * N, N);
-    hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, coefs + 3 * n, n, cir.g_pow, ev + 4 * N, N);
+    if (pi_zero) BP_HIP(ctx, hipMemsetAsync(ev + 4 * N, 0, N * sizeof(fr_t), st));
+    else hipLaunchKernelGGL(fr_mul_table_pad, dim3(blocks_N), dim3(256), 0, st, coefs + 3 * n, n, cir.g_pow, ev + 4 * N, N);
     BP_HIP(ctx, hipGetLastError());
-    BP_TRY(ntt_run(ctx, ev, k + 2, 0, 5, N));
+    BP_TRY(ntt_run(ctx, ev, k + 2, 0, pi_zero ? 4 : 5, N));
   }
   hipLaunchKernelGGL(quotient_coset, dim3(blocks_N), dim3(256), 0, st, ev, cir.coset, cir.coset_x, N, qa, t, 4u);
   BP_HIP(ctx, hipGetLastError());

@@ -136,6 +136,8 @@ def test_group_context_round3_by_coset(members, peer, monkeypatch):
             blob = bp.Prover(setup, circuit).prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), None, blinders)
             want = want or blob
             assert blob == want and len(blob) == 624, (pn, members, split, early)
+            # an explicit all-zero PI column takes the general path (PI sent, folded and transformed like the others): same bytes
+            assert bp.Prover(setup, circuit).prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), PR.SV([0] * pn), blinders) == want
             if ctx is many and split == "1" and pn == 1 << 7:
                 bad = [list(c) for c in cols]
                 bad[2][3] = 12345                                         # c no longer equals a * b in row 3
@@ -145,6 +147,20 @@ def test_group_context_round3_by_coset(members, peer, monkeypatch):
                 # the abandoned proof's early work on the members must not leak into the next one
                 assert bp.Prover(setup, circuit).prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), None, blinders) == want
             circuit.free()
+    # public inputs through the split (toy circuit of the reference's tests: PI != 0)
+    from tests.test_gpu_prover_rounds import toy_circuit
+    cols, pk, public = toy_circuit(8)
+    blinders = [random.Random(9).randrange(1, Q) for _ in range(11)]
+    want = None
+    for ctx, early in ((one, "1"), (many, "1"), (many, "0")):
+        monkeypatch.setenv("BP_PROVE_COSET_SPLIT", "1")
+        monkeypatch.setenv("BP_PROVE_COSET_EARLY", early)
+        setup = bp.Setup.generate_srs(8 + 6, 0xABCDE, ctx)
+        circuit = bp.Circuit({k: PR.SV(v) for k, v in pk.items()}, ctx)
+        blob = bp.Prover(setup, circuit).prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), PR.SV(public), blinders)
+        want = want or blob
+        assert blob == want, early
+        circuit.free()
     many.close()
     one.close()
 

@@ -143,10 +143,13 @@ def test_synthetic_circuit_native_vs_oracle_restatement(logn, monkeypatch):
     t = [torch.from_numpy(PR.SV(c).view(np.int64)).cuda() for c in cols]
     torch.cuda.synchronize()
     assert prover.prove_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, blinders) == blob
+    # no public inputs (None: PI's transforms are skipped) against an explicit all-zero PI column (the general path): same bytes
+    assert prover.prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), PR.SV([0] * n), blinders) == blob
     # round 3's challenge-free coset transforms on the side stream (the default below 2^20 gates) or in round 3 itself (from 2^20)
     for side in ("0", "1"):
         monkeypatch.setenv("BP_PROVE_SIDE", side)
         assert prover.prove_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, blinders) == blob, side
+        assert prover.prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), PR.SV([0] * n), blinders) == blob, side
     circuit.free()
 
 
