@@ -48,7 +48,11 @@ def scalars(n, kind):
     raise ValueError(kind)
 
 
+t_note = time.time() + 60
 while time.time() < t_end:
+    if time.time() > t_note:                 # a line a minute: a silent GPU command is taken to be hung after seven
+        print("...", counts, flush=True)
+        t_note = time.time() + 60
     which = rnd.choice(["msm", "msm", "ntt", "poly"])
     if which == "msm":
         n = rnd.choice([rnd.randrange(1, 40), rnd.randrange(1, 3000), rnd.randrange(1, 70000), rnd.randrange(60000, 300000)])

@@ -24,7 +24,11 @@ ap.add_argument("--seed", type=int, default=1)
 args = ap.parse_args()
 rnd = random.Random(args.seed)
 t_end, done = time.time() + args.seconds, 0
+t_note = time.time() + 60
 while time.time() < t_end:
+    if time.time() > t_note:
+        print("... %d circuits" % done, flush=True)
+        t_note = time.time() + 60
     n = rnd.choice([8, 8, 16, 32, 64, 128])
     n_pub = rnd.choice([0, 0, 1, 2])
     n_gates = rnd.randrange(1, n - n_pub + 1)
