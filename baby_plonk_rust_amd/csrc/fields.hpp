@@ -56,19 +56,99 @@ BP_HD fr_t fr_root_of_unity(bool inverse) {
   for (int i = 0; i < 8; i++) r.l[i] = inverse ? FrParams::root_of_unity_inv(i) : FrParams::root_of_unity(i);
   return r;
 }
-// a^-1 by Fermat (scalar.rs:416-511 uses an addition chain for the same exponent q-2)
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host path of the two inversions below: binary extended Euclid on 64-bit limbs instead of the 255- / 381-bit power (65 us per Fp
+// inversion on the build container's CPU, one per MSM result and per transcript point: most of the host epilogue).  The value
+// inverted is the Montgomery image a R; (a R)^-1 = a^-1 R^-1 as a plain residue, and two products with R^2 bring it back to a^-1 R.
+// Same unique representative in [0, p) as the power gives; 0 -> 0.
+template <class F>
+inline void invert_host(typename F::V& r, const typename F::V& a) {
+  constexpr int N = F::N, M = N / 2;
+  typedef unsigned __int128 u128;
+  struct W { uint64_t w[M]; };
+  auto is_zero = [](const W& x) { uint64_t o = 0; for (int i = 0; i < M; i++) o |= x.w[i]; return o == 0; };
+  auto is_one = [](const W& x) { uint64_t o = x.w[0] ^ 1; for (int i = 1; i < M; i++) o |= x.w[i]; return o == 0; };
+  auto shr1 = [](W& x, uint64_t top) {
+    for (int i = 0; i + 1 < M; i++) x.w[i] = (x.w[i] >> 1) | (x.w[i + 1] << 63);
+    x.w[M - 1] = (x.w[M - 1] >> 1) | (top << 63);
+  };
+  auto add = [](W& x, const W& y) -> uint64_t {
+    u128 c = 0;
+    for (int i = 0; i < M; i++) { c += (u128)x.w[i] + y.w[i]; x.w[i] = (uint64_t)c; c >>= 64; }
+    return (uint64_t)c;
+  };
+  auto sub = [](W& x, const W& y) -> uint64_t {                // x -= y, returns the borrow
+    uint64_t b = 0;
+    for (int i = 0; i < M; i++) {
+      const u128 d = (u128)x.w[i] - y.w[i] - b;
+      x.w[i] = (uint64_t)d;
+      b = (uint64_t)(d >> 64) & 1;
+    }
+    return b;
+  };
+  auto geq = [](const W& x, const W& y) {
+    for (int i = M - 1; i >= 0; i--)
+      if (x.w[i] != y.w[i]) return x.w[i] > y.w[i];
+    return true;
+  };
+  W u, v, x1, x2, p;
+  const typename F::V mod = F::modulus();
+  for (int i = 0; i < M; i++) {
+    u.w[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+    p.w[i] = (uint64_t)mod.l[2 * i] | ((uint64_t)mod.l[2 * i + 1] << 32);
+    x1.w[i] = i == 0;
+    x2.w[i] = 0;
+  }
+  v = p;
+  if (is_zero(u)) {
+    for (int i = 0; i < N; i++) r.l[i] = 0;
+    return;
+  }
+  auto halve = [&](W& x) {                                      // x / 2 mod p, x in [0, p)
+    if (x.w[0] & 1) { const uint64_t c = add(x, p); shr1(x, c); } else shr1(x, 0);
+  };
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u.w[0] & 1)) { shr1(u, 0); halve(x1); }
+    while (!(v.w[0] & 1)) { shr1(v, 0); halve(x2); }
+    if (geq(u, v)) {
+      sub(u, v);
+      if (sub(x1, x2)) add(x1, p);
+    } else {
+      sub(v, u);
+      if (sub(x2, x1)) add(x2, p);
+    }
+  }
+  const W& res = is_one(u) ? x1 : x2;
+  typename F::V t;
+  for (int i = 0; i < M; i++) {
+    t.l[2 * i] = (uint32_t)res.w[i];
+    t.l[2 * i + 1] = (uint32_t)(res.w[i] >> 32);
+  }
+  F::to_mont(t, t);
+  F::to_mont(r, t);
+}
+#endif
+// a^-1 by Fermat (scalar.rs:416-511 uses an addition chain for the same exponent q-2); on the host by binary Euclid (above)
 BP_HD void fr_invert(fr_t& r, const fr_t& a) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  invert_host<Fr>(r, a);
+#else
   uint32_t e[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) e[i] = FrParams::mod_minus_2(i);
   Fr::pow(r, a, e, 8);
+#endif
 }
 // fp.rs:346-358
 BP_HD void fp_invert(fp_t& r, const fp_t& a) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  invert_host<Fp>(r, a);
+#else
   uint32_t e[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) e[i] = FpParams::mod_minus_2(i);
   Fp::pow(r, a, e, 12);
+#endif
 }
 
 }  // namespace bp

@@ -49,8 +49,10 @@ def test_fr_ops(hc):
         assert (call(hc, "hc_fr_sub", 8, a, b) == O.fr_bin("fr_sub", a, b)).all()
         assert (call(hc, "hc_fr_neg", 8, a) == O.fr_un("fr_neg", a)).all()
         assert O.unlimbs(call(hc, "hc_fr_from_mont", 8, a)) == vals[i]
-    a = O.fr_from_int(vals[7])
-    assert (call(hc, "hc_fr_inv", 8, a) == O.fr_invert(a)[0]).all()
+    # host inversion (binary Euclid on 64-bit limbs, fields.hpp) against the oracle's power, edge values included; 0 -> 0
+    for v in vals + [2, 3, Q // 2, 2**64, 2**128 - 1, 2**254 % Q]:
+        a = O.fr_from_int(v)
+        assert (call(hc, "hc_fr_inv", 8, a) == O.fr_invert(a)[0]).all(), v
 
 
 def test_fp_ops(hc):
@@ -62,8 +64,9 @@ def test_fp_ops(hc):
         assert (call(hc, "hc_fp_add", 12, a, b) == O.fp_bin("fp_add", a, b)).all()
         assert (call(hc, "hc_fp_sub", 12, a, b) == O.fp_bin("fp_sub", a, b)).all()
         assert (call(hc, "hc_fp_neg", 12, a) == O.fp_un("fp_neg", a)).all()
-    a = O.fp_from_int(vals[9])
-    assert (call(hc, "hc_fp_inv", 12, a) == O.fp_invert(a)[0]).all()
+    for v in vals + [2, 3, P // 2, 2**64, 2**192 - 1, 2**380]:
+        a = O.fp_from_int(v)
+        assert (call(hc, "hc_fp_inv", 12, a) == O.fp_invert(a)[0]).all(), v
 
 
 def test_g1_ops(hc):
