@@ -58,6 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20, help="weak-scaling MSM points per GPU = 2^log_n")
     ap.add_argument("--ntt-log-n", type=int, default=20, help="NTT length per GPU = 2^ntt_log_n")
+    ap.add_argument("--group-legs-child", default="", help=argparse.SUPPRESS)       # internal: JSON job of the child that runs the bp_init_multi legs
     ap.add_argument("--strong-log-n", type=int, default=24, help="strong-scaling leg: ONE 2^strong_log_n-point MSM over all GPUs (0 = skip)")
     ap.add_argument("--strong-steps", type=int, default=0, help="steps of the strong-scaling leg (0 = min(steps, 10))")
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
@@ -199,8 +200,128 @@ def cpu_baseline(sample_log_n, threads_all):
     }
 
 
+def group_legs_child(job):
+    """The two legs that drive ONE bp_init_multi context over all N GPUs (group_commit, one proof + one NTT over all GPUs), in a process
+    of their own: started by rank 0 with a timeout, while the ranks wait on the host.  They are the only part of the bench whose
+    GPU-to-GPU branches have not run on distinct GPUs yet, so a fault or a hang there must cost these two entries, not the line."""
+    import hashlib
+    import random
+    import numpy as np
+    import torch
+    import baby_plonk_rust_amd as bp
+    devs, world = job["devices"], len(job["devices"])
+    torch.cuda.set_device(devs[0])
+    dev = torch.device("cuda", devs[0])
+    ctx = bp.Context(devs[0])
+    out = {}
+
+    def synthetic(count, seed, first=0):
+        t = torch.empty(count * 4, dtype=torch.int64, device=dev)
+        ctx.synthetic_scalars_device(t.data_ptr(), count, (seed + GOLDEN * 8 * first) & MASK64)
+        return t
+
+    if job.get("commit"):
+        c = job["commit"]
+        try:
+            total, k = c["total"], c["k"]
+            gctx = bp.Context(devs)
+            t0 = time.perf_counter()
+            gsrs = gctx.srs_generate_progression(total, A0, D0)
+            ginfo = gctx.srs_precompute(gsrs, bp.SRS_TABLES_OFF if job["no_tables"] else 0)
+            g_setup = time.perf_counter() - t0
+            hs = synthetic(total, 0x5EED0000 + c["log_n"], 0).cpu().numpy().view(np.uint64).reshape(total, 4)    # pageable, as a Vec<Scalar> is
+            for _ in range(2):
+                gres = gctx.msm(gsrs, hs)
+            t0 = time.perf_counter()
+            for _ in range(k):
+                gres = gctx.msm(gsrs, hs)
+            g_dt = time.perf_counter() - t0
+            members = gctx.msm_member_stats()
+            out["group_commit"] = {
+                "metric": "g1_msm_scalar_muls_per_s", "value": total * k / g_dt, "unit": "scalar-muls/s", "n_gpus": world, "steps": k,
+                "ms_per_step": 1e3 * g_dt / k, "scalars": "pageable host memory, %d MiB per step, one slice per member over its own PCIe link" % (32 * total >> 20),
+                "window_bits": ginfo["window_bits"], "table_bytes_all_gpus": ginfo["bytes"], "srs_and_tables_s": g_setup,
+                "per_member": members, "upload_ms_max": max(m["upload_ms"] for m in members), "device_ms_max": max(m["device_ms"] for m in members),
+                "same_result": gres.hex() == c["expect"], "result_sha": hashlib.sha256(gres).hexdigest()[:16],
+                "how": "one bp_init_multi context in a process of its own beside the ranks (the drop-in for Setup::commit, setup.rs:32-37): SRS "
+                       "sharded by point range, one persistent host thread per member, partial sums added on the host; no collective"}
+            gctx.srs_free(gsrs)
+            gctx.close()
+            del hs
+        except Exception as e:
+            out["group_commit"] = {"n_gpus": world, "error": repr(e)[:300]}
+    if job.get("prove"):
+        pj = job["prove"]
+        try:
+            from baby_plonk_rust_amd.synthetic import Q as FR_Q, chained_multiplications
+            pn = 1 << pj["log_n"]
+            cols, pk = chained_multiplications(pn, 1000)                      # rank 0's circuit
+            blinders = [random.Random(5).randrange(1, FR_Q) for _ in range(11)]
+            gctx = bp.Context(devs)
+            gsetup = bp.Setup.generate_srs(pn + 6, 0x1234567 + pj["log_n"], gctx, tables=not job["no_tables"])
+            gprover = bp.Prover(gsetup, bp.Circuit(pk, gctx))
+            gwit = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
+            gp = [w.data_ptr() for w in gwit]
+            gblob = gprover.prove_device(gp[0], gp[1], gp[2], None, blinders)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(pj["reps"]):
+                gblob = gprover.prove_device(gp[0], gp[1], gp[2], None, blinders)
+            g_elapsed = time.perf_counter() - t0
+            out["group_proof"] = {"n_gpus": world, "latency_ms_per_proof": 1e3 * g_elapsed / pj["reps"], "round_ms": gprover.last_stats()["round_ms"],
+                                  "same_proof_bytes_as_one_gpu": hashlib.sha256(gblob).hexdigest() == pj["expect_sha256"],
+                                  "how": "one bp_init_multi context in a process of its own beside the ranks: SRS and the nine MSMs of a proof sharded by "
+                                         "point range over the %d GPUs (peer copies of the scalar slices, one batched pipeline per member and round, "
+                                         "partial sums added on the host), round 3's quotient split by coset over the first %d GPUs (a, b, c sent "
+                                         "right after round 1), the other polynomial work on GPU 0" % (world, 4 if world >= 4 else 2)}
+            # ONE host-to-host NTT through the same context (SURVEY 8e option ii): column slices over every GPU's PCIe link,
+            # block exchange between the GPUs, outputs back; beside it the same call on a single-GPU context
+            if pj.get("ntt_log_n", 0) >= 22 and world in (2, 4, 8):
+                try:
+                    hx = synthetic(1 << pj["ntt_log_n"], 0xF40000 + pj["ntt_log_n"]).cpu().numpy().view(np.uint64).reshape(-1, 4)
+                    ms = {}
+                    for name, c in (("one_gpu", ctx), ("all_gpus", gctx)):
+                        best = None
+                        for _ in range(3):
+                            t0 = time.perf_counter()
+                            hy = c.ntt(hx)
+                            dt = time.perf_counter() - t0
+                            best = dt if best is None or dt < best else best
+                        ms[name] = {"ms_host_to_host": 1e3 * best, "kernel_ms": c.ntt_stats()["device_ms"], "members": c.ntt_stats()["members"],
+                                    "sha": hashlib.sha256(hy.tobytes()).hexdigest()[:16]}
+                    ms["same_output"] = ms["one_gpu"]["sha"] == ms["all_gpus"]["sha"]
+                    ms["log_n"] = pj["ntt_log_n"]
+                    out["group_proof"]["one_ntt_over_all_gpus"] = ms
+                except Exception as e:
+                    out["group_proof"]["one_ntt_over_all_gpus"] = {"error": repr(e)[:300]}
+            gctx.close()
+        except Exception as e:
+            out["group_proof"] = {"n_gpus": world, "error": repr(e)[:300]}
+    print("GROUP_LEGS " + json.dumps(out), flush=True)
+
+
+def run_group_legs(job, timeout_s):
+    """rank 0: the child of group_legs_child; whatever happens to it, an entry per requested leg comes back"""
+    want = [k for k, leg in (("group_commit", "commit"), ("group_proof", "prove")) if job.get(leg)]
+    try:
+        cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--group-legs-child", json.dumps(job)], capture_output=True, text=True, timeout=timeout_s)
+        for line in cp.stdout.splitlines():
+            if line.startswith("GROUP_LEGS "):
+                got = json.loads(line[len("GROUP_LEGS "):])
+                return {k: got.get(k, {"n_gpus": len(job["devices"]), "error": "leg missing from the child's answer"}) for k in want}
+        err = "child exited with %d: %s" % (cp.returncode, (cp.stderr or cp.stdout)[-300:])
+    except subprocess.TimeoutExpired:
+        err = "child killed after %d s" % timeout_s
+    except Exception as e:
+        err = repr(e)[:300]
+    return {k: {"n_gpus": len(job["devices"]), "error": err} for k in want}
+
+
 def main():
     args = parse_args()
+    if args.group_legs_child:
+        group_legs_child(json.loads(args.group_legs_child))
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
 
@@ -503,35 +624,10 @@ def main():
         torch.cuda.synchronize()
         host_barrier()
         if rank == 0:
-            try:
-                total = strong["total"]
-                gctx = bp.Context(list(range(world)) if args.backend == "nccl" else [dev_index] * world)
-                t0 = time.perf_counter()
-                gsrs = gctx.srs_generate_progression(total, A0, D0)
-                ginfo = gctx.srs_precompute(gsrs, bp.SRS_TABLES_OFF if args.no_tables else 0)
-                g_setup = time.perf_counter() - t0
-                hs = synthetic(total, 0x5EED0000 + args.strong_log_n, 0).cpu().numpy().view(np.uint64).reshape(total, 4)    # pageable, as a Vec<Scalar> is
-                for _ in range(2):
-                    gres = gctx.msm(gsrs, hs)
-                k = strong["k"]
-                t0 = time.perf_counter()
-                for _ in range(k):
-                    gres = gctx.msm(gsrs, hs)
-                g_dt = time.perf_counter() - t0
-                members = gctx.msm_member_stats()
-                group_commit = {
-                    "metric": "g1_msm_scalar_muls_per_s", "value": total * k / g_dt, "unit": "scalar-muls/s", "n_gpus": world, "steps": k,
-                    "ms_per_step": 1e3 * g_dt / k, "scalars": "pageable host memory, %d MiB per step, one slice per member over its own PCIe link" % (32 * total >> 20),
-                    "window_bits": ginfo["window_bits"], "table_bytes_all_gpus": ginfo["bytes"], "srs_and_tables_s": g_setup,
-                    "per_member": members, "upload_ms_max": max(m["upload_ms"] for m in members), "device_ms_max": max(m["device_ms"] for m in members),
-                    "same_result": gres == strong["r"]["result"], "result_sha": hashlib.sha256(gres).hexdigest()[:16],
-                    "how": "one bp_init_multi context in rank 0's process (the drop-in for Setup::commit, setup.rs:32-37): SRS sharded by point "
-                           "range, one persistent host thread per member, partial sums added on the host; no collective"}
-                gctx.srs_free(gsrs)
-                gctx.close()
-                del hs
-            except Exception as e:                                # never lose the line over this leg
-                group_commit = {"n_gpus": world, "error": repr(e)[:300]}
+            group_devs = list(range(world)) if args.backend == "nccl" else [dev_index] * world      # a gloo rehearsal lists its one card once per rank
+            group_commit = run_group_legs({"devices": group_devs, "no_tables": bool(args.no_tables),
+                                           "commit": {"total": strong["total"], "k": strong["k"], "log_n": args.strong_log_n,
+                                                      "expect": strong["r"]["result"].hex()}}, 420)["group_commit"]
         host_barrier()
 
     # ---------------------------------------------------------------- prover leg (BASELINE configs[4])
@@ -587,49 +683,10 @@ def main():
             torch.cuda.empty_cache()
             dist.barrier(group=ctl)
             if rank == 0:
-                try:
-                    # one shard per GPU; a gloo rehearsal (ranks sharing a card) lists that card once per rank
-                    gctx = bp.Context(list(range(world)) if args.backend == "nccl" else [dev_index] * world)
-                    gsetup = bp.Setup.generate_srs(pn + 6, 0x1234567 + args.prove_log_n, gctx, tables=not args.no_tables)
-                    gprover = bp.Prover(gsetup, bp.Circuit(pk, gctx))
-                    gwit = [torch.from_numpy(c.view(np.int64)).to(dev) for c in cols]
-                    gp = [w.data_ptr() for w in gwit]
-                    gblob = gprover.prove_device(gp[0], gp[1], gp[2], None, blinders)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for _ in range(args.prove_reps):
-                        gblob = gprover.prove_device(gp[0], gp[1], gp[2], None, blinders)
-                    g_elapsed = time.perf_counter() - t0
-                    prove["group"] = {"n_gpus": world, "latency_ms_per_proof": 1e3 * g_elapsed / args.prove_reps, "round_ms": gprover.last_stats()["round_ms"],
-                                      "same_proof_bytes_as_one_gpu": gblob == blob,
-                                      "how": "one bp_init_multi context in rank 0's process: SRS and the nine MSMs of a proof sharded by point "
-                                             "range over the %d GPUs (peer copies of the scalar slices, one batched pipeline per member and round, "
-                                             "partial sums added on the host), round 3's quotient split by coset over the first %d "
-                                             "GPUs, the other polynomial work on GPU 0" % (world, 4 if world >= 4 else 2)}
-                    # ONE host-to-host NTT through the same context (SURVEY 8e option ii): column slices over every GPU's PCIe link,
-                    # block exchange between the GPUs, outputs back; beside it the same call on this rank's single-GPU context
-                    if args.strong_log_n >= 22 and world in (2, 4, 8):
-                        try:
-                            hx = synthetic(1 << args.strong_log_n, 0xF40000 + args.strong_log_n).cpu().numpy().view(np.uint64).reshape(-1, 4)
-                            ms = {}
-                            for name, c in (("one_gpu", ctx), ("all_gpus", gctx)):
-                                best = None
-                                for _ in range(3):
-                                    t0 = time.perf_counter()
-                                    hy = c.ntt(hx)
-                                    dt = time.perf_counter() - t0
-                                    best = dt if best is None or dt < best else best
-                                ms[name] = {"ms_host_to_host": 1e3 * best, "kernel_ms": c.ntt_stats()["device_ms"], "members": c.ntt_stats()["members"],
-                                            "sha": hashlib.sha256(hy.tobytes()).hexdigest()[:16]}
-                            ms["same_output"] = ms["one_gpu"]["sha"] == ms["all_gpus"]["sha"]
-                            ms["log_n"] = args.strong_log_n
-                            prove["group"]["one_ntt_over_all_gpus"] = ms
-                            del hx, hy
-                        except Exception as e:
-                            prove["group"]["one_ntt_over_all_gpus"] = {"error": repr(e)[:300]}
-                    gctx.close()
-                except Exception as e:                            # never lose the line over the optional leg
-                    prove["group"] = {"n_gpus": world, "error": repr(e)[:300]}
+                group_devs = list(range(world)) if args.backend == "nccl" else [dev_index] * world
+                prove["group"] = run_group_legs({"devices": group_devs, "no_tables": bool(args.no_tables),
+                                                 "prove": {"log_n": args.prove_log_n, "reps": args.prove_reps, "ntt_log_n": args.strong_log_n,
+                                                           "expect_sha256": hashlib.sha256(blob).hexdigest()}}, 420)["group_proof"]
             dist.barrier(group=ctl)
 
     # ---------------------------------------------------------------- reduce over ranks, print the line
