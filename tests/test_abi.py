@@ -29,6 +29,31 @@ def test_library_exports_every_header_symbol():
     assert sorted(_lib.SIGNATURES) == names          # python binding table and header agree
 
 
+def test_rust_bindings_follow_the_header():
+    """include/bp_msm_ntt.rs (the extern "C" block a maintainer of the Rust reference drops in as src/gpu.rs) is
+    generated from the header: it is current, declares every entry point, and its arity agrees with the ctypes table the parity
+    tests call through (same count of arguments, same pointer-vs-value pattern)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_bindings", os.path.join(ROOT, "tools", "gen_rust_bindings.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = open(os.path.join(ROOT, "include", "bp_msm_ntt.rs")).read()
+    assert text == gen.generate(), "run python tools/gen_rust_bindings.py"
+    protos = {name: (args, ret) for name, args, ret in gen.prototypes(open(gen.HEADER).read())}
+    assert sorted(protos) == header_symbols()
+    import ctypes as C
+    for name, (args, ret) in protos.items():
+        res, argtypes = _lib.SIGNATURES[name]
+        assert len(args) == len(argtypes), name
+        for (pname, rty), cty in zip(args, argtypes):
+            is_ptr_rust = rty.startswith("*")
+            is_ptr_c = cty in (C.c_void_p, C.c_char_p) or hasattr(cty, "contents") or getattr(cty, "_type_", None) == "P"
+            assert is_ptr_rust == is_ptr_c, (name, pname, rty, cty)
+        assert (ret is None) == (res is None), name
+    for const in ("BP_FR_MONT: c_int = 1", "BP_FR_BYTES_LE: c_int = 0", "BP_ERR_ASSERT: c_int = -11", "BP_MSM_BLOB_BYTES: usize = %d" % _lib.MSM_BLOB_BYTES):
+        assert "pub const " + const + ";" in text, const
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     if torch.cuda.is_available():
