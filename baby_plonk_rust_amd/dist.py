@@ -78,6 +78,8 @@ class ShardedMsm:
         self.record_done = torch.cuda.Event(enable_timing=True)
         self.all_done = torch.cuda.Event(enable_timing=True)
         self.exchange_s = 0.0
+        # The wait is bp_synchronize (the library polls its stream, which IS this torch stream): torch's Event.synchronize() came back
+        # ~90 us after the GPU had finished (tools/exchange_split.py: 2 786 us per 2^20-point step against 2 650 without the exchange).
         # (no synchronize: the fills above and the first record are on the same stream)
 
     def __call__(self, srs_handle_local, scalars_local=None, device_ptr=None, n=None, first=0):
@@ -89,21 +91,21 @@ class ShardedMsm:
             if not self.collective:
                 one.copy_(self.mine, non_blocking=True)
                 self.all_done.record()
-                self.all_done.synchronize()                                                   # the only host wait
+                self.ctx.synchronize()                                                        # the only host wait (see __init__)
                 host = one
             elif self.on_gpu:
                 dist.all_gather_into_tensor(self.gathered, self.mine, group=self.group)       # the path's single collective
                 self.ctx.msm_blobs_sum_device(self.gathered.data_ptr(), self.world, self.summed.data_ptr(), wait=False)     # equal layouts: one record
                 one.copy_(self.summed, non_blocking=True)                                     # the path's single D2H (22 KB)
                 self.all_done.record()
-                self.all_done.synchronize()                                                   # the only host wait
+                self.ctx.synchronize()                                                        # the only host wait (see __init__)
                 host = one
                 if int.from_bytes(host[:4].numpy().tobytes(), "little") == 0:                # layouts differ: all records to the host
                     host = self.gathered.cpu()
             else:
                 one.copy_(self.mine, non_blocking=True)
                 self.all_done.record()
-                self.all_done.synchronize()
+                self.ctx.synchronize()
                 dist.all_gather_into_tensor(self.gathered, one.clone(), group=self.group)
                 host = self.gathered
         out = api.combine_blobs(host.numpy().tobytes())
