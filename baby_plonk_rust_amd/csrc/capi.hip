@@ -1037,6 +1037,27 @@ int commit_many(bp_ctx* ctx, uint64_t srs_handle, const fr_t* const* d_coeffs, c
   }
   return BP_OK;
 }
+
+int commit_lane_launch(bp_ctx* ctx, int j, uint64_t srs_handle, const fr_t* d_coeffs, size_t n, hipEvent_t ready, MsmPending* pend) {
+  *pend = MsmPending();
+  if (j < 0 || j >= MAX_LANES || is_group(ctx)) return fail(ctx, BP_ERR_INVALID_ARG, "commit lane", hipSuccess, __FILE__, __LINE__);
+  SrsEntry* e;
+  BP_TRY(srs_find(ctx, srs_handle, &e));
+  DeviceGuard guard(ctx->device);
+  while ((int)ctx->lanes.size() < j) {
+    bp_ctx* lane = nullptr;
+    int rc = ctx_create(&lane, ctx->device);
+    if (rc != BP_OK) return fail(ctx, rc, "commit lane", hipSuccess, __FILE__, __LINE__);
+    ctx->lanes.push_back(lane);
+  }
+  bp_ctx* lane = j == 0 ? ctx : ctx->lanes[j - 1];
+  BP_HIP(ctx, hipStreamWaitEvent(lane->stream, ready, 0));
+  return lift(ctx, lane, msm_shard_launch(lane, e, 0, d_coeffs, std::min(n, e->n), BP_FR_MONT, 1, ctx->device, nullptr, 0, nullptr, pend));     // zip() truncation, msm.rs:29
+}
+int commit_lane_finish(bp_ctx* ctx, int j, const MsmPending& pend, g1_proj* out) {
+  bp_ctx* lane = j == 0 ? ctx : ctx->lanes[j - 1];
+  return lift(ctx, lane, msm_finish(lane, pend, out));
+}
 }  // namespace bp
 
 extern "C" {
@@ -1966,6 +1987,17 @@ int bp_prove(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_handle, const vo
   fr_t* wit;
   BP_TRY(ws_get(ctx, "prove.witness", 4 * n * sizeof(fr_t), (void**)&wit));
   const void* cols[4] = {a, b, c, public_input};
+  // host witness of 2^18 gates and more on one device: round 1 stages the columns itself, uploads beside the commitments (BP_PROVE_STAGED=0: off)
+  bool staged = !witness_on_device && !is_group(ctx) && it->second.log_n >= 18;
+  {
+    const char* v = getenv("BP_PROVE_STAGED");
+    if (v && *v == '0') staged = false;
+    if (v && *v == '1') staged = !witness_on_device && !is_group(ctx);
+  }
+  if (staged) {
+    const ProveStaged hw = {{a, b, c, public_input}, scalar_fmt};
+    return prove_run(ctx, srs_handle, it->second, wit, blind, proof, public_input == nullptr, &hw);
+  }
   const hipMemcpyKind kind = witness_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   for (int k = 0; k < 4; k++) {
     if (cols[k]) BP_HIP(ctx, hipMemcpyAsync(wit + (size_t)k * n, cols[k], n * sizeof(fr_t), kind, ctx->stream));

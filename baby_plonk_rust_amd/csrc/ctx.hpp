@@ -233,8 +233,19 @@ int side_ctx_get(bp_ctx* ctx, bp_ctx** out);       // creates ctx->side and its 
 int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out);
 int circuit_split_build(bp_ctx* ctx, CircuitEntry& e);      // leader of a group: the members' coset shares (prover.hip)
 void circuit_release(CircuitEntry& e);
+// Witness columns still in host memory (the Rust caller's Vec<Scalar>s): round 1 uploads them itself on the side context's stream, one
+// column at a time, and starts each column's commitment as soon as its coefficients exist -- the pageable copies of b and c (and the
+// host thread blocked in them) run beside the commitment of a.  cols: a, b, c, PI (PI may be null); fmt: BP_FR_MONT / BP_FR_BYTES_LE.
+struct ProveStaged {
+  const void* cols[4];
+  int fmt;
+};
+// one commitment on lane j (< 3) of a single-device context, enqueued behind `ready`; waits for nothing.  commit_lane_finish waits.
+int commit_lane_launch(bp_ctx* ctx, int j, uint64_t srs_handle, const fr_t* d_coeffs, size_t n, hipEvent_t ready, MsmPending* pend);
+int commit_lane_finish(bp_ctx* ctx, int j, const MsmPending& pend, g1_proj* out);
 // pi_zero: the caller passed no public inputs, so the PI column of d_wit is all zero (PI(X) = 0: its transforms are skipped, not computed)
-int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_wit, const fr_t blind[11], uint8_t proof[624], bool pi_zero = false);
+int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_wit, const fr_t blind[11], uint8_t proof[624], bool pi_zero = false,
+              const ProveStaged* staged = nullptr);
 void transcript_test_vector(uint8_t out32[32]);
 
 // ---- host-side helpers (host.cpp part of capi.hip) ---------------------------------------------------

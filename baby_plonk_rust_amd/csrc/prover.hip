@@ -469,7 +469,8 @@ static int round3_by_coset(bp_ctx* ctx, const CircuitEntry& cir, const fr_t* con
 
 // ------------------------------------------------------------------------------------------------ prove
 // d_wit: a | b | c | PI Lagrange columns (4 x n, Montgomery, device).  blinders: b1..b11 (prover.rs:110).
-int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_wit, const fr_t blind[11], uint8_t proof[624], bool pi_zero) {
+int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_wit, const fr_t blind[11], uint8_t proof[624], bool pi_zero,
+              const ProveStaged* staged) {
   const uint32_t k = cir.log_n;
   const size_t n = (size_t)1 << k, N = 4 * n;
   const fr_t omega = root_of_unity(n), k1 = from_u64(2), k2 = from_u64(3), one = Fr::one();      // prover.rs:99-100
@@ -488,14 +489,70 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   BP_TRY(ws_get(ctx, "prove.coefs", 4 * n * sizeof(fr_t), (void**)&coefs));          // iNTT of a | b | c | PI
   BP_TRY(ws_get(ctx, "prove.abc", 3 * (n + 8) * sizeof(fr_t), (void**)&abc));        // a_coeff | b_coeff | c_coeff, n + 2 each
   BP_TRY(ws_get(ctx, "prove.z", 2 * (n + 8) * sizeof(fr_t), (void**)&zc));           // z (Lagrange -> coefficients) | z_coeff, n + 3
-  BP_HIP(ctx, hipMemcpyAsync(coefs, d_wit, 4 * n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
-  BP_TRY(ntt_run(ctx, coefs, k, 1, pi_zero ? 3 : 4, n));          // no public inputs: PI's column is zero and so are its coefficients
   fr_t* poly_abc[3] = {abc, abc + (n + 8), abc + 2 * (n + 8)};
   const unsigned blocks_n = (unsigned)((n + 8 + 255) / 256);
-  for (int j = 0; j < 3; j++)
-    hipLaunchKernelGGL(fr_blind, dim3(blocks_n), dim3(256), 0, st, coefs + (size_t)j * n, n, blind[2 * j + 1], blind[2 * j], Fr::zero(), 2u,
-                       poly_abc[j]);
-  BP_HIP(ctx, hipGetLastError());
+  bool r1_committed = false;
+  if (staged) {
+    // Host witness (ctx.hpp, ProveStaged): per column  upload -> (bytes -> Montgomery) -> inverse transform -> blinding  on the side
+    // context's stream, an event, and the column's commitment on its lane behind the event.  The host blocks in the pageable copy of
+    // column j + 1 while the GPU commits to column j: 2.2 ms of uploads at 2^20 gates leave 0.8 on the proof's path.
+    bp_ctx* sd;
+    BP_TRY(side_ctx_get(ctx, &sd));
+    hipStream_t ss = sd->stream;
+    for (auto& e : ctx->seam_ev)
+      if (!e) BP_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    fr_t* wit = const_cast<fr_t*>(d_wit);                           // the caller's "prove.witness" workspace: filled here
+    BP_HIP(ctx, hipEventRecord(ctx->seam_ev[3], st));               // behind whatever the context's stream still holds
+    BP_HIP(ctx, hipStreamWaitEvent(ss, ctx->seam_ev[3], 0));
+    MsmPending pend[3];
+    int launched = 0, rc = BP_OK;
+    for (int j = 0; j < 4 && rc == BP_OK; j++) {
+      fr_t *w_j = wit + (size_t)j * n, *c_j = coefs + (size_t)j * n;
+      hipError_t he;
+      if (staged->cols[j]) {
+        he = hipMemcpyAsync(w_j, staged->cols[j], n * sizeof(fr_t), hipMemcpyHostToDevice, ss);
+        if (he == hipSuccess && staged->fmt == BP_FR_BYTES_LE && fr_convert_run(sd, w_j, n, 0) != BP_OK) he = hipErrorUnknown;
+        if (he == hipSuccess) he = hipMemcpyAsync(c_j, w_j, n * sizeof(fr_t), hipMemcpyDeviceToDevice, ss);
+        if (he == hipSuccess && ntt_run(sd, c_j, k, 1, 1, n) != BP_OK) he = hipErrorUnknown;
+      } else {                                                      // only PI may be absent: a zero column and zero coefficients
+        he = hipMemsetAsync(w_j, 0, n * sizeof(fr_t), ss);
+        if (he == hipSuccess) he = hipMemsetAsync(c_j, 0, n * sizeof(fr_t), ss);
+      }
+      if (he == hipSuccess && j < 3) {
+        hipLaunchKernelGGL(fr_blind, dim3(blocks_n), dim3(256), 0, ss, c_j, n, blind[2 * j + 1], blind[2 * j], Fr::zero(), 2u, poly_abc[j]);
+        he = hipGetLastError();
+      }
+      if (he == hipSuccess) he = hipEventRecord(ctx->seam_ev[j], ss);
+      if (he != hipSuccess) {
+        rc = fail(ctx, BP_ERR_HIP, "round 1: staging of a witness column", he, __FILE__, __LINE__);
+        break;
+      }
+      if (j < 3) {
+        rc = commit_lane_launch(ctx, j, srs, poly_abc[j], n + 2, ctx->seam_ev[j], &pend[j]);
+        if (rc == BP_OK) launched = j + 1;
+      }
+    }
+    if (rc == BP_OK) {                                              // rounds 2.. read the columns and coefficients on the context's stream
+      const hipError_t he = hipStreamWaitEvent(st, ctx->seam_ev[3], 0);
+      if (he != hipSuccess) rc = fail(ctx, BP_ERR_HIP, "round 1: order", he, __FILE__, __LINE__);
+    }
+    for (int j = 0; j < launched; j++) {                            // every launched lane is waited for, also after a failure
+      const int r2 = commit_lane_finish(ctx, j, pend[j], &cm[j]);
+      if (rc == BP_OK) rc = r2;
+    }
+    if (rc != BP_OK) {
+      (void)stream_wait(ss);
+      return rc;
+    }
+    r1_committed = true;
+  } else {
+    BP_HIP(ctx, hipMemcpyAsync(coefs, d_wit, 4 * n * sizeof(fr_t), hipMemcpyDeviceToDevice, st));
+    BP_TRY(ntt_run(ctx, coefs, k, 1, pi_zero ? 3 : 4, n));          // no public inputs: PI's column is zero and so are its coefficients
+    for (int j = 0; j < 3; j++)
+      hipLaunchKernelGGL(fr_blind, dim3(blocks_n), dim3(256), 0, st, coefs + (size_t)j * n, n, blind[2 * j + 1], blind[2 * j], Fr::zero(), 2u,
+                         poly_abc[j]);
+    BP_HIP(ctx, hipGetLastError());
+  }
   // Round 3's evaluations of a, b, c and PI on the quotient coset (prover.rs:386-450) depend on no challenge: they are enqueued on the
   // side context's stream once round 1's commitments are in (beside them they only took the GPU from three concurrent pipelines:
   // +2.6 ms on round 1 for -1.9 on round 3) and run beside round 2 -- one commitment, whose sort and tree leave most of the chip idle,
@@ -525,7 +582,7 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   const fr_t* coefs5[5] = {poly_abc[0], poly_abc[1], poly_abc[2], zc + (n + 8), coefs + 3 * n};
   const size_t lens5[5] = {n + 2, n + 2, n + 2, n + 3, n};
   if (early_on) BP_TRY(round3_coset_early(ctx, cir, coefs5, lens5, pi_zero));
-  {                                       // three independent commitments in flight together (commit_many)
+  if (!r1_committed) {                    // three independent commitments in flight together (commit_many)
     const fr_t* polys[3] = {poly_abc[0], poly_abc[1], poly_abc[2]};
     const size_t lens[3] = {n + 2, n + 2, n + 2};
     BP_TRY(commit_many(ctx, srs, polys, lens, 3, &cm[0]));

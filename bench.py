@@ -660,6 +660,15 @@ def main():
         barrier()
         single_elapsed = time.perf_counter() - t0
         round_ms = provers[0].last_stats()["round_ms"]
+        # the same proof with the witness in pageable host memory -- what the Rust caller's Vec<Scalar>s are:
+        # round 1 uploads the columns itself, b and c beside the commitment to a
+        host_witness_s = None
+        if rank == 0:
+            assert provers[0].prove_with_blinding(cols[0], cols[1], cols[2], None, blinders) == blob
+            t0 = time.perf_counter()
+            for _ in range(args.prove_reps):
+                provers[0].prove_with_blinding(cols[0], cols[1], cols[2], None, blinders)
+            host_witness_s = (time.perf_counter() - t0) / args.prove_reps
 
         # throughput: all provers of this GPU at once (one host thread each; the library calls release the GIL), so one
         # proof's latency-bound tails (bucket reduction, scans, host transcript) overlap another proof's bulk kernels
@@ -675,7 +684,7 @@ def main():
             th.join()
         barrier()
         prove = {"elapsed": time.perf_counter() - t0, "single_elapsed": single_elapsed, "round_ms": round_ms, "sha": hashlib.sha256(blob).hexdigest()[:16],
-                 "setup_s": t_setup, "circuit_host_s": t_circuit_host, "streams": len(provers), "group": None}
+                 "setup_s": t_setup, "circuit_host_s": t_circuit_host, "streams": len(provers), "group": None, "host_witness_s": host_witness_s}
         # one proof on ONE context over all N GPUs (bp_init_multi): the nine commitments of prover.rs are sharded by point range,
         # everything else runs on GPU 0.  Rank 0 drives it; the other ranks have freed their memory and wait on the host.
         if world > 1:
@@ -773,6 +782,7 @@ def main():
             line["prove"] = {"metric": "plonk_proofs_per_s", "value": world * prove["streams"] * args.prove_reps / prove_elapsed, "unit": "proofs/s",
                              "gates": 1 << args.prove_log_n, "concurrent_provers_per_gpu": prove["streams"],
                              "latency_ms_per_proof_single_prover": 1e3 * prove_single / args.prove_reps,
+                             "latency_ms_per_proof_host_witness": None if prove["host_witness_s"] is None else 1e3 * prove["host_witness_s"],
                              "proofs_per_s_single_prover_per_gpu": args.prove_reps / prove_single,
                              "round_ms": prove["round_ms"], "proofs_timed_per_gpu": prove["streams"] * args.prove_reps,
                              "parallelism": "independent proofs x%d" % world,

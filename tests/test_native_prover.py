@@ -145,6 +145,20 @@ def test_synthetic_circuit_native_vs_oracle_restatement(logn, monkeypatch):
     assert prover.prove_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), None, blinders) == blob
     # no public inputs (None: PI's transforms are skipped) against an explicit all-zero PI column (the general path): same bytes
     assert prover.prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), PR.SV([0] * n), blinders) == blob
+    # host witness staged column by column inside round 1 (the default from 2^18 gates) or copied in front of it, Montgomery limbs and
+    # canonical bytes, with and without a PI column: same bytes
+    le = [np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in c), dtype=np.uint8).copy() for c in cols]
+    for staged_env in ("1", "0"):
+        monkeypatch.setenv("BP_PROVE_STAGED", staged_env)
+        assert prover.prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), None, blinders) == blob, staged_env
+        assert prover.prove_with_blinding(PR.SV(cols[0]), PR.SV(cols[1]), PR.SV(cols[2]), PR.SV([0] * n), blinders) == blob, staged_env
+        out = np.zeros(624, dtype=np.uint8)
+        bl = np.frombuffer(b"".join((int(v) % Q).to_bytes(32, "little") for v in blinders), dtype=np.uint8).copy()
+        c_ = prover.ctx
+        c_.check(c_._lib.bp_prove(c_._h, setup.handle, circuit.handle, le[0].ctypes.data, le[1].ctypes.data, le[2].ctypes.data, None, bp.FR_BYTES_LE, 0,
+                                  bl.ctypes.data, out.ctypes.data), "bp_prove")
+        assert bytes(out) == blob, staged_env
+    monkeypatch.delenv("BP_PROVE_STAGED")
     # round 3's challenge-free coset transforms on the side stream (the default below 2^20 gates) or in round 3 itself (from 2^20)
     for side in ("0", "1"):
         monkeypatch.setenv("BP_PROVE_SIDE", side)
