@@ -28,7 +28,9 @@ if "group_commit" in d:
     print("group_commit", d["group_commit"])
 p = d.get("prove")
 if p:
-    print("prove: %.2f ms single, %.2f proofs/s with %d provers, rounds %s" % (p["latency_ms_per_proof_single_prover"], p["value"], p["concurrent_provers_per_gpu"], ["%.2f" % r for r in p["round_ms"]]))
+    print("prove: %.2f ms single (%s ms from a host witness), %.2f proofs/s with %d provers, rounds %s" % (
+        p["latency_ms_per_proof_single_prover"], "%.2f" % p["latency_ms_per_proof_host_witness"] if p.get("latency_ms_per_proof_host_witness") else "-",
+        p["value"], p["concurrent_provers_per_gpu"], ["%.2f" % r for r in p["round_ms"]]))
     if p.get("one_proof_over_all_gpus"):
         print("  group:", p["one_proof_over_all_gpus"])
 if "cpu_baseline" in d:
