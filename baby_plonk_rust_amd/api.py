@@ -77,6 +77,7 @@ class Context:
             raise BpError(rc, "bp_init", "no usable GPU: this package has no CPU fallback")
         self._h = h
         self.device = self.devices[0]
+        self._async_keepalive = []       # host buffers handed to *_async calls: referenced until the next synchronize()
 
     def n_shards(self):
         return self._lib.bp_ctx_devices(self._h, None, 0)
@@ -191,6 +192,8 @@ class Context:
             rc = fn(self._h, handle, first, device_ptr, n, fmt, 1, d_blob_ptr)
         else:
             s = _fr_array(scalars) if fmt == FR_MONT else np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+            if not wait:
+                self._async_keepalive.append(s)      # the copy is stream-ordered (bp_msm_ntt.h): alive until synchronize()
             rc = fn(self._h, handle, first, s.ctypes.data, len(s), fmt, 0, d_blob_ptr)
         self.check(rc, "bp_msm_g1_blob_device" if wait else "bp_msm_g1_blob_device_async")
 
@@ -257,6 +260,7 @@ class Context:
 
     def synchronize(self):
         self.check(self._lib.bp_synchronize(self._h), "bp_synchronize")
+        self._async_keepalive.clear()
 
 
 _default_ctx = {}

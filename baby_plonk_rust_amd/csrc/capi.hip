@@ -28,15 +28,20 @@ int fail(bp_ctx* ctx, int code, const char* what, hipError_t e, const char* file
   return code;
 }
 
+static thread_local bool tl_member_worker = false;     // set by the persistent member threads of a group context
+
 hipError_t stream_wait(hipStream_t st) {
   static const bool block = [] { const char* v = getenv("BP_WAIT_BLOCK"); return v && *v == '1'; }();
   if (!block) {
+    // the calling thread polls for up to 6 ms (a blocked hipStreamSynchronize wakes up ~20 us late, and a call waits several times);
+    // a member's worker thread polls for 50 us only and then blocks: N members must not spin N host cores through the GPU phase
+    const auto limit = tl_member_worker ? std::chrono::microseconds(50) : std::chrono::microseconds(6000);
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t spins = 0;; spins++) {
       const hipError_t e = hipStreamQuery(st);
       if (e != hipErrorNotReady) return e;
       __builtin_ia32_pause();
-      if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(6)) break;
+      if ((spins & 15) == 15 && std::chrono::steady_clock::now() - t0 > limit) break;
     }
   }
   return hipStreamSynchronize(st);
@@ -210,6 +215,7 @@ struct MemberWorker {
     th.join();
   }
   void loop() {
+    tl_member_worker = true;
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
       cv.wait(lk, [&] { return has_job || stop; });
@@ -445,6 +451,7 @@ const char* bp_last_error(bp_ctx* ctx) { return ctx ? ctx->last_error.c_str() : 
 int bp_set_stream(bp_ctx* ctx, void* hip_stream) {
   if (!ctx) return BP_ERR_INVALID_ARG;
   DeviceGuard guard(ctx->device);
+  if (hip_stream != nullptr && !ctx->own_stream && ctx->stream == (hipStream_t)hip_stream) return BP_OK;     // already there: no wait (callers re-assert per call)
   BP_HIP(ctx, stream_wait(ctx->stream));
   if (hip_stream == nullptr) {
     if (!ctx->own_stream) {
@@ -697,6 +704,50 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
                 __FILE__, __LINE__);
   const std::vector<bp_ctx*> sh = shards_of(ctx);
   const std::vector<uint64_t> hs = lead->member_handle;
+  // Memory budget: the tables (rows x points x 128 B: 25.8 GB per GPU at 2^24 points) must fit beside whatever else lives on the
+  // device -- a second prover context, the caller's tensors -- together with the workspaces the first MSM against them allocates.
+  // The old tables go first (their memory counts as free).  An automatic width that does not fit falls back to wider windows
+  // (fewer rows: 22 -> 12, 24 -> 11) and then to NO tables (the MSM runs on the raw points, same bytes out: bp_srs_table_info
+  // reports what was built); an explicit width that does not fit is an error that says how much is missing, not an
+  // out-of-memory failure halfway through the build.
+  for (size_t r = 0; r < sh.size(); r++) BP_TRY(lift(ctx, sh[r], srs_precompute_one(sh[r], hs.empty() ? srs_handle : hs[r], BP_SRS_TABLES_OFF)));
+  if (c == BP_SRS_TABLES_OFF) return BP_OK;
+  auto fits = [&](uint32_t cc, size_t* need_out, size_t* free_out) -> int {
+    for (size_t r = 0; r < sh.size(); r++) {
+      SrsEntry* e;
+      BP_TRY(lift(ctx, sh[r], srs_find(sh[r], hs.empty() ? srs_handle : hs[r], &e)));
+      DeviceGuard guard(sh[r]->device);
+      size_t free_b = 0, total_b = 0;
+      BP_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+      const size_t rows = srs_table_rows(cc);
+      const size_t need = rows * e->n * (sizeof(g1_affine28) + 24) + ((size_t)256 << 20);      // + sort records, lists, partial slots of one MSM
+      if (need > free_b) {
+        *need_out = need;
+        *free_out = free_b;
+        return 1;
+      }
+    }
+    return 0;
+  };
+  size_t need = 0, free_b = 0;
+  int rc = fits(c, &need, &free_b);
+  if (rc < 0) return rc;
+  if (rc == 1) {
+    if (window_bits != 0) {
+      char msg[200];
+      snprintf(msg, sizeof msg, "fixed-base tables of width %u need %.1f GiB on a device with %.1f GiB free", c & 0xffu, need / 1073741824.0, free_b / 1073741824.0);
+      return fail(ctx, BP_ERR_TOO_LARGE, msg, hipSuccess, __FILE__, __LINE__);
+    }
+    uint32_t pick = BP_SRS_TABLES_OFF;
+    for (uint32_t cc : {22u, 24u}) {
+      if (cc <= c) continue;
+      rc = fits(cc, &need, &free_b);
+      if (rc < 0) return rc;
+      if (rc == 0) { pick = cc; break; }
+    }
+    c = pick;
+    if (c == BP_SRS_TABLES_OFF) return BP_OK;
+  }
   for (size_t r = 0; r < sh.size(); r++) BP_TRY(lift(ctx, sh[r], srs_precompute_one(sh[r], hs.empty() ? srs_handle : hs[r], c)));
   return BP_OK;
 }

@@ -135,9 +135,14 @@ int fail(bp_ctx* ctx, int code, const char* what, hipError_t e, const char* file
 
 // Every entry point that takes a ctx runs under one of these: the calling thread's current device is restored on return
 // (torch shares this HIP runtime; a library call must not leave the thread on another GPU).
+// It also drops the thread's pending HIP error first: hipGetLastError() after a launch reports the LAST error of the calling
+// thread, whoever caused it -- the embedding process (torch, RCCL, the Rust host's own HIP calls) or a previous context's
+// teardown (gpurun_out/r3_t37.log: "invalid device ordinal" surfacing in the next bp_init) -- and an innocent bp_* call must
+// not return it as BP_ERR_HIP.  The post-launch checks keep their meaning: what they see was raised inside this call.
 struct DeviceGuard {
   int prev = -1;
   explicit DeviceGuard(int device) {
+    (void)hipGetLastError();
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device) (void)hipSetDevice(device);
   }
@@ -199,6 +204,7 @@ int msm_init_device(bp_ctx* ctx);
 int commit_many(bp_ctx* ctx, uint64_t srs_handle, const fr_t* const* d_coeffs, const size_t* n, int k, g1_proj* out);
 int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points28, size_t n, uint32_t c, g1_affine28** d_table,
                    uint32_t* windows);
+uint32_t srs_table_rows(uint32_t c);                 // rows of the fixed-base tables of window width c (msm.hip)
 int srs_to28_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28** d_out);
 int srs_to28_into(bp_ctx* ctx, const g1_affine* d_in, size_t n, g1_affine28* d_out);      // the same into a buffer of the caller's, on ctx->stream
 int ntt_init_tables(bp_ctx* ctx);

@@ -100,6 +100,9 @@ inline void invert_host(typename F::V& r, const typename F::V& a) {
     x2.w[i] = 0;
   }
   v = p;
+  // caller-supplied limbs are not always canonical (a peer's record, a divisor's leading coefficient): reduce first, so that
+  // a non-zero multiple of the modulus is the 0 it represents and gcd(u, p) = 1 holds below (u = p made the loop spin forever)
+  while (geq(u, p)) sub(u, p);
   if (is_zero(u)) {
     for (int i = 0; i < N; i++) r.l[i] = 0;
     return;

@@ -159,6 +159,8 @@ uint32_t msm_table_windows(uint32_t c) {
 }
 
 // table[w * n + i] = 2^(c w) P_i; row 0 is the unsaturated SRS copy itself
+uint32_t srs_table_rows(uint32_t c) { return msm_table_windows(c); }
+
 int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points28, size_t n, uint32_t c, g1_affine28** d_table,
                    uint32_t* windows) {
   const uint32_t W = msm_table_windows(c);

@@ -83,6 +83,9 @@ class ShardedMsm:
         # (no synchronize: the fills above and the first record are on the same stream)
 
     def __call__(self, srs_handle_local, scalars_local=None, device_ptr=None, n=None, first=0):
+        # another ShardedMsm on the same context (or its close()) may have moved the context to a different stream since __init__:
+        # the record below must be written in THIS object's stream order, or the all-gather behind it reads a stale record
+        self.ctx.set_stream(self.stream.cuda_stream)
         self.stream.wait_stream(torch.cuda.current_stream(self.gpu))        # behind whatever produced the scalars; enqueue only
         self.ctx.msm_blob_device(srs_handle_local, self.mine.data_ptr(), scalars_local, first=first, device_ptr=device_ptr, n=n, wait=False)
         with torch.cuda.stream(self.stream):

@@ -17,6 +17,8 @@ with W warm-up steps and exactly K steps between barrier + synchronize, max over
                          is the same for every N.
   ntt / sizes            2^20 Fr NTT per rank (independent columns, no collective); at N = 1 also the metric's other sizes
                          (2^16 = configs[1], 2^24) with their own roofline objects.
+  ntt_columns (ranks)    23 independent 2^20-element columns dealt over the ranks (column j -> rank j mod N), every rank transforms
+                         its share, ONE all-gather of the finished columns over RCCL; elements/s and the all-gather's ms.
   seams (N = 1)          msm_host_scalars: pageable host scalars in (what Setup::commit(&Polynomial) hands over, PCIe
                          inclusive); msm_uncached_seam: upload 2^log_n points + multiply + free (bucket_msm(&[G1Projective])).
   prove                  BASELINE configs[4]: bp_prove on a synthetic 2^20-gate circuit; independent proofs per GPU
@@ -46,6 +48,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 RATE_QUARTER, RATE_FULL, N_CU, CLOCK_HZ = 57.0, 90.0, 256, 2.4e9
 MSM_BYTES_PER_UNIT = 128         # 32 B scalar + 96 B affine point per scalar-mul
 NTT_BYTES_PER_UNIT = 64          # 32 B read + 32 B write per element
+NTT_COLUMNS = 23                 # independent transforms of one proof (prover.rs:386-450): the batch of the N > 1 columns leg
 GOLDEN = 0x9E3779B97F4A7C15
 A0, D0 = 0x1F2E3D4C5B6A79881122334455667788, 0x0102030405060708090A0B0C0D0E0F10
 MASK64 = 2**64 - 1
@@ -126,6 +129,9 @@ def msm_roofline(n, acc_s, adds, window_bits, tables, traffic_key=None):
     hbm = {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None, "traffic_source": traffic.get("source") if traffic else None,
            "kernel_ms": acc_s * 1e3, "algorithmic_bytes_per_launch": MSM_BYTES_PER_UNIT * n,
+           "designed_bytes_per_launch": (128 * adds + 4 * adds) if adds else None,       # one 128-byte table slot + one sorted index per bucket addition
+           "designed_bytes_note": "what the fixed-base path moves by design: a gathered 128-B slot and a 4-B list entry per bucket addition "
+                                  "(13 per scalar at 20-bit windows), not the 128 B per scalar of the algorithmic figure",
            "note": "integer-issue bound by design (11 Fp products + 8 reductions per bucket addition); see roofline_valu_issue"}
     mix = profile_lookup("r03_msm_accumulate_instr_mix.json", "msm_accumulate<2>")
     issue = None
@@ -133,8 +139,11 @@ def msm_roofline(n, acc_s, adds, window_bits, tables, traffic_key=None):
         # lane-cycles of one loop iteration at the measured issue rates, times the additions actually performed
         per_add_s = (mix["quarter_rate"] / RATE_QUARTER + mix["full_rate"] / RATE_FULL) / (N_CU * CLOCK_HZ)
         ideal_s = adds * per_add_s
-        issue = {"bound": "valu_issue", "kernel": "msm_accumulate", "achieved": adds / acc_s, "peak": 1.0 / per_add_s, "unit": "bucket additions/s",
-                 "frac": ideal_s / acc_s, "additions_per_launch": adds,
+        issue = {"bound": "valu_issue", "kernel": "msm_accumulate", "achieved": adds / acc_s, "own_formula_register_only_rate": 1.0 / per_add_s,
+                 "unit": "bucket additions/s", "frac": ideal_s / acc_s, "additions_per_launch": adds,
+                 "frac_is": "a fraction of what THIS addition formula (complete mixed addition, 14 x 28-bit limbs: 11 products + 8 reductions) "
+                            "reaches on registers only -- it says the loop is well scheduled, not that ~5 150 instructions per addition are "
+                            "necessary; not a hardware peak",
                  "valu_per_addition": {"quarter_rate": mix["quarter_rate"], "full_rate": mix["full_rate"], "v_mad_u64_u32": mix.get("v_mad_u64_u32")},
                  "note": "additions counted by the kernel pipeline (non-zero digits) x static instruction classes of the loop body "
                          "(tools/instr_mix.py on the shipped code object) at the issue rates tools/ubench_int.hip measured "
@@ -214,6 +223,10 @@ def group_legs_child(job):
     dev = torch.device("cuda", devs[0])
     ctx = bp.Context(devs[0])
     out = {}
+    # which pairs of the listed devices can address each other directly (hipDeviceCanAccessPeer): a missing link or a wrong cross-device
+    # dependency must show up as a number in the line, not as a hang
+    uniq = sorted(set(devs))
+    peer = {"devices": devs, "can_access_peer": {"%d->%d" % (a, b): bool(torch.cuda.can_device_access_peer(a, b)) for a in uniq for b in uniq if a != b}}
 
     def synthetic(count, seed, first=0):
         t = torch.empty(count * 4, dtype=torch.int64, device=dev)
@@ -242,6 +255,7 @@ def group_legs_child(job):
                 "ms_per_step": 1e3 * g_dt / k, "scalars": "pageable host memory, %d MiB per step, one slice per member over its own PCIe link" % (32 * total >> 20),
                 "window_bits": ginfo["window_bits"], "table_bytes_all_gpus": ginfo["bytes"], "srs_and_tables_s": g_setup,
                 "per_member": members, "upload_ms_max": max(m["upload_ms"] for m in members), "device_ms_max": max(m["device_ms"] for m in members),
+                "peer_access": peer,
                 "same_result": gres.hex() == c["expect"], "result_sha": hashlib.sha256(gres).hexdigest()[:16],
                 "how": "one bp_init_multi context in a process of its own beside the ranks (the drop-in for Setup::commit, setup.rs:32-37): SRS "
                        "sharded by point range, one persistent host thread per member, partial sums added on the host; no collective"}
@@ -269,6 +283,7 @@ def group_legs_child(job):
                 gblob = gprover.prove_device(gp[0], gp[1], gp[2], None, blinders)
             g_elapsed = time.perf_counter() - t0
             out["group_proof"] = {"n_gpus": world, "latency_ms_per_proof": 1e3 * g_elapsed / pj["reps"], "round_ms": gprover.last_stats()["round_ms"],
+                                  "peer_access": peer, "last_commit_per_member": gctx.msm_member_stats(),
                                   "same_proof_bytes_as_one_gpu": hashlib.sha256(gblob).hexdigest() == pj["expect_sha256"],
                                   "how": "one bp_init_multi context in a process of its own beside the ranks: SRS and the nine MSMs of a proof sharded by "
                                          "point range over the %d GPUs (peer copies of the scalar slices, one batched pipeline per member and round, "
@@ -549,6 +564,49 @@ def main():
     assert ntt_ok, "NTT spot check failed"
     ntt = timed_ntt(vec, args.ntt_log_n, args.steps, args.warmup)
 
+    # ---------------------------------------------------------------- NTT columns over the ranks + ONE all-gather (north_star: "NTT by independent
+    # columns across the GPUs with a single RCCL all-gather"; callers: the 23 transforms of prover.rs:386-450, utils.rs:106-129).  Column j
+    # of NTT_COLUMNS belongs to rank j mod world (dist.my_columns); a step = every rank transforms its columns (enqueued back to back),
+    # then one all_gather_columns brings every finished column to every rank.  Runs whenever a process group exists (a world of one included).
+    ntt_cols = None
+    if use_dist:
+        mine_j = bpd.my_columns(NTT_COLUMNS, rank, world)
+        fresh = {j: synthetic(nn, 0xC0100000 + 977 * j).view(nn, 4) for j in mine_j}
+        colbuf = {j: t.clone() for j, t in fresh.items()}
+
+        def cols_step():
+            for j in mine_j:
+                ctx.ntt_device_async(colbuf[j].data_ptr(), args.ntt_log_n)
+            ctx.synchronize()
+            t_t = time.perf_counter()
+            got = bpd.all_gather_columns(colbuf, NTT_COLUMNS)
+            torch.cuda.synchronize()
+            return got, time.perf_counter() - t_t
+
+        got, _ = cols_step()                                    # first pass on fresh data: checked below
+        probe = (rank + 1) % NTT_COLUMNS                        # a column another rank owns (its own when world = 1): transform it here and compare
+        ref = synthetic(nn, 0xC0100000 + 977 * probe)
+        ctx.ntt_device(ref.data_ptr(), args.ntt_log_n)
+        torch.cuda.synchronize()
+        cols_ok = bool(torch.equal(got[probe].to(dev).reshape(-1), ref)) and len(got) == NTT_COLUMNS
+        digest = hashlib.sha256()
+        for c in got:
+            digest.update(c[:64].cpu().numpy().tobytes())
+        cols_digest = digest.hexdigest()[:16]
+        del got, ref, fresh
+        for _ in range(max(0, args.warmup - 1)):
+            cols_step()
+        barrier()
+        t0 = time.perf_counter()
+        gather_s = 0.0
+        for _ in range(args.steps):
+            _, g = cols_step()
+            gather_s += g
+        barrier()
+        ntt_cols = {"elapsed": time.perf_counter() - t0, "gather_s": gather_s, "ok": cols_ok, "digest": cols_digest, "mine": len(mine_j)}
+        del colbuf
+        torch.cuda.empty_cache()
+
     # ---------------------------------------------------------------- the metric's other sizes, N = 1 (2^16 = configs[1]; 2^24 rides on the strong leg)
     sizes = {}
 
@@ -700,8 +758,9 @@ def main():
 
     # ---------------------------------------------------------------- reduce over ranks, print the line
     times = [head["elapsed"], ntt["elapsed"], other["elapsed"], prove["elapsed"] if prove else 0.0, prove["single_elapsed"] if prove else 0.0,
-             strong["r"]["elapsed"] if strong else 0.0]
-    elapsed, ntt_elapsed, other_elapsed, prove_elapsed, prove_single, strong_elapsed = max_over_ranks(times)
+             strong["r"]["elapsed"] if strong else 0.0, ntt_cols["elapsed"] if ntt_cols else 0.0, ntt_cols["gather_s"] if ntt_cols else 0.0]
+    elapsed, ntt_elapsed, other_elapsed, prove_elapsed, prove_single, strong_elapsed, cols_elapsed, cols_gather = max_over_ranks(times)
+    cols_all = gather_objects({"ok": ntt_cols["ok"], "digest": ntt_cols["digest"], "columns": ntt_cols["mine"]} if ntt_cols else None)
     per_rank = gather_objects({"rank": rank, "device": dev_index, "weak_accumulate_ms": head["acc_ms"], "weak_device_ms": head["dev_ms"],
                                "weak_exchange_ms": head["exchange_ms"],
                                "strong_points": strong["m"] if strong else 0, "strong_accumulate_ms": strong["r"]["acc_ms"] if strong else 0.0,
@@ -727,6 +786,15 @@ def main():
                        "srs_tables": {"used": stats["tables"], "window_bits": table_info["window_bits"], "windows": table_info["windows"],
                                       "bytes_per_gpu": table_info["bytes"], "build_s": table_build_s},
                        "parallelism": "point-range x%d" % world, "ranks": world, "backend": args.backend if use_dist else None},
+            # the headline is a FIXED-BASE MSM (the SRS of a Setup with its window tables resident); the reference-shaped figures beside it:
+            "value_without_tables": None if args.no_tables else units / other_elapsed,
+            "ms_per_step_without_tables": None if args.no_tables else 1e3 * other_elapsed / args.steps,
+            "first_commit_ms": None if args.no_tables else 1e3 * (table_build_s + elapsed / args.steps),
+            "uncached_seam_ms_per_call": seams["msm_uncached_seam"]["ms_per_call"] if "msm_uncached_seam" in seams else None,
+            "host_scalars_ms_per_step": seams["msm_host_scalars"]["ms_per_step"] if "msm_host_scalars" in seams else None,
+            "headline_note": "value = scalars resident in HBM against an SRS whose fixed-base tables (config.srs_tables) were built once outside "
+                             "the timed region; first_commit_ms = table build + one MSM; value_without_tables = the same MSM on raw points; "
+                             "uncached_seam_ms_per_call = bucket_msm(&[G1Projective], &[Scalar]) literally, nothing cached, PCIe inclusive",
             "roofline": hbm,
             "roofline_valu_issue": issue,
             "msm_device_ms": head["dev_ms"],
@@ -748,6 +816,17 @@ def main():
             "result_sha": hashlib.sha256(head["result"]).hexdigest()[:16],
             "per_rank": per_rank,
         }
+        if ntt_cols:
+            line["ntt_columns"] = {
+                "metric": "fr_ntt_elements_per_s", "value": NTT_COLUMNS * nn * args.steps / cols_elapsed, "unit": "elements/s", "n_gpus": world,
+                "columns": NTT_COLUMNS, "column_len": nn, "columns_per_rank": [c["columns"] for c in cols_all], "steps": args.steps,
+                "ms_per_step": 1e3 * cols_elapsed / args.steps, "allgather_ms_per_step": 1e3 * cols_gather / args.steps,
+                "allgather_bytes_per_rank_out": 32 * nn * ((NTT_COLUMNS + world - 1) // world) * world,
+                "backend": args.backend, "foreign_column_matches_local_transform": all(c["ok"] for c in cols_all),
+                "same_on_all_ranks": len({c["digest"] for c in cols_all}) == 1,
+                "how": "column j of %d belongs to rank j mod N (dist.my_columns); per step every rank transforms its columns "
+                       "(bp_ntt_fr_device_async, one wait) and ONE all_gather_columns (a [columns per rank, 2^%d, 4] tensor over RCCL) "
+                       "brings every column to every rank; allgather_ms = that collective alone, max over ranks" % (NTT_COLUMNS, args.ntt_log_n)}
         line.update(seams)
         if sizes:
             line["other_sizes"] = sizes

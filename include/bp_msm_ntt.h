@@ -119,6 +119,10 @@ int  bp_srs_free(bp_ctx* ctx, uint64_t srs_handle);
  * passes to one; results are the same group element.  window_bits: 0 = chosen from srs_len (16 below 2^20 points, 20 -- thirteen
  * windows -- from 2^20 points, 22 from 2^24), BP_SRS_TABLES_OFF = drop the tables, else 4..24 (above 16 the bucket sort is partitioned).  MSMs shorter than 2^window_bits / 8 scalars keep
  * using the table-free path.  The reference has no counterpart (its MSM recomputes from the raw points).
+ * Memory budget (hipMemGetInfo per device, after the previous tables of this SRS are released): window_bits = 0 never fails for lack
+ * of memory -- a width that does not fit beside what else lives on the device falls back to wider windows (fewer rows) and then to no
+ * tables at all (bp_srs_table_info reports what was built; results are the same bytes either way); an explicit width that does not
+ * fit returns BP_ERR_TOO_LARGE with the sizes in bp_last_error(), before anything is allocated.
  * window_bits = 256 + w (w = 6..22): tables of EVERY bit position, T[p][i] = 2^p * P_i for p < 256 (256 x srs_len x 128 bytes:
  * 32 GiB at 2^20 points), used with the scalars' width-w non-adjacent form: ~256 / (w + 1) + 0.5 bucket additions per scalar
  * and 2^(w-2) buckets.  Measured slower than the 16-bit windows at 2^20 as shipped; never chosen by 0. */
@@ -154,7 +158,10 @@ int  bp_msm_g1_blob_device(bp_ctx* ctx, uint64_t srs_handle, size_t first, const
  * record is written in that stream's order: behind whatever the caller enqueued on d_blob or the scalars before (a zero fill,
  * a producer kernel), in front of whatever it enqueues next (the RCCL all-gather of dist.ShardedMsm) -- no host wait, and
  * ordering is a property of the call, not of prose.  Errors that need the result (a canonical-bytes scalar >= q) travel in
- * the record's header and surface in bp_msm_blobs_combine.  bp_msm_last_stats reads the timing once the stream has passed it. */
+ * the record's header and surface in bp_msm_blobs_combine.  bp_msm_last_stats reads the timing once the stream has passed it.
+ * Host scalars (scalars_on_device == 0) are copied by a stream-ordered hipMemcpyAsync: from pageable memory the runtime has
+ * staged them when the call returns, from PINNED memory (hipHostMalloc, a torch pinned tensor) the DMA reads them later --
+ * the buffer must stay valid and unchanged until the stream has passed the call (bp_synchronize, or an event of the caller's). */
 int  bp_msm_g1_blob_device_async(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
                                  int scalars_on_device, void* d_blob);
 /* Optional device-side pre-sum of the gathered records (n_blobs of them in HBM, BP_MSM_BLOB_BYTES apart): records of equal

@@ -74,7 +74,13 @@ def test_bench_self_launches_two_ranks():
     assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["points_per_rank"] == 1 << 14 and st["value"] > 0
     assert len(st["accumulate_ms_per_rank"]) == 2 and all(v > 0 for v in st["accumulate_ms_per_rank"])
     assert line["prove"]["gates"] == 1 << 10 and line["prove"]["value"] > 0 and line["prove"]["parallelism"] == "independent proofs x2"
+    cols = line["ntt_columns"]                              # the NTT half of the N > 1 contract: columns over the ranks + ONE all-gather
+    assert cols["n_gpus"] == 2 and cols["columns"] == 23 and cols["columns_per_rank"] == [12, 11] and cols["value"] > 0
+    assert cols["foreign_column_matches_local_transform"] is True and cols["same_on_all_ranks"] is True and cols["allgather_ms_per_step"] > 0
+    gc = line["group_commit"]                               # the bp_init_multi seam beside the ranks: peer matrix + per-member split in the line
+    assert gc.get("same_result") is True and len(gc["per_member"]) == 2 and gc["peer_access"]["devices"] == [0, 0], gc
     grp = line["prove"]["one_proof_over_all_gpus"]          # one proof on a context spanning all ranks' GPUs (here: two shards on one card)
+    assert len(grp["last_commit_per_member"]) == 2 and "can_access_peer" in grp["peer_access"], grp
     assert grp["n_gpus"] == 2 and grp.get("same_proof_bytes_as_one_gpu") is True and grp["latency_ms_per_proof"] > 0, grp
     # the strong-scaling problem is the same for every N: one rank must get the same bytes
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "14", "--ntt-log-n", "14",

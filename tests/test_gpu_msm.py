@@ -233,3 +233,38 @@ def test_bucket_msm_any_window_parameters_vs_oracle(ctx, b, c):
     for bad_b, bad_c in ((256, 0), (3, 4), (300, 4), (256, 64)):
         with pytest.raises(bp.BpError):
             bp.BucketMSM.bucket_msm(bytes(O.points_to_bytes96(aff)), sc, bad_b, bad_c, ctx)
+
+
+def _loaded_hip_runtime():
+    """ctypes handle of the HIP runtime this process has ALREADY loaded (the one libbp_msm_ntt.so and torch call into)"""
+    import ctypes as C
+    with open("/proc/self/maps") as f:
+        paths = sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    assert paths, "no HIP runtime mapped"
+    return [C.CDLL(p) for p in paths]
+
+
+def test_stale_hip_error_of_the_calling_thread_is_not_ours(ctx):
+    """hipGetLastError() reports the calling thread's LAST error whoever caused it (torch, RCCL, a previous context's
+    teardown: gpurun_out/r3_t37.log).  Plant one -- hipSetDevice(9999) -- in front of bp_init and of an MSM: both must succeed."""
+    def plant():
+        for hip in _loaded_hip_runtime():
+            hip.hipSetDevice.restype = int
+            assert hip.hipSetDevice(9999) != 0                 # invalid device ordinal: now pending in this thread
+    plant()
+    fresh = bp.Context(0)                                       # bp_init: stream / events / LDS-limit launches behind a stale error
+    try:
+        h = fresh.srs_generate_progression(64, 3, 5)
+        sc = [7 * i + 1 for i in range(64)]
+        plant()
+        assert fresh.msm(h, frs(sc)) == closed_form(sc, 3, 5)
+        plant()
+        v = bp.scalars_from_ints(list(range(1, 257)))
+        assert (fresh.ntt(fresh.ntt(v), inverse=True) == v).all()
+    finally:
+        fresh.close()
+    plant()
+    h = ctx.srs_generate_progression(32, 2, 1)
+    plant()
+    assert ctx.msm(h, frs(list(range(32)))) == closed_form(list(range(32)), 2, 1)
+    ctx.srs_free(h)

@@ -293,3 +293,32 @@ def test_every_position_tables_naf_digits(ctx, w, log_n):
     assert many.msm(hm, sc) == want
     assert many.msm_stats()["tables"] == (8 * (n // 3) >= (1 << (w - 2)))      # short shards keep to the plain points
     many.close()
+
+
+def test_table_memory_budget(ctx):
+    """bp_srs_precompute checks hipMemGetInfo before it builds: with the device nearly full, the automatic width
+    falls back to no tables (same bytes out), an explicit width is refused with BP_ERR_TOO_LARGE and the sizes -- never an
+    out-of-memory failure halfway through"""
+    import torch
+    n = 1 << 18
+    h = ctx.srs_generate_progression(n, 9, 4)
+    rnd = random.Random(77)
+    sc = [rnd.randrange(Q) for _ in range(n)]
+    want = closed_form(sc, 9, 4)
+    assert ctx.msm(h, frs(sc)) == want                            # workspaces of this size exist before the device is filled
+    free_b, _ = torch.cuda.mem_get_info(ctx.device)
+    hog = torch.empty(free_b - (400 << 20), dtype=torch.uint8, device="cuda:%d" % ctx.device)      # leave 400 MiB: 2^18 x 16 rows x 128 B = 512 MiB does not fit
+    try:
+        info = ctx.srs_precompute(h, 0)
+        assert info["bytes"] == 0 and info["windows"] == 0, info
+        assert ctx.msm(h, frs(sc)) == want
+        with pytest.raises(bp.BpError) as ei:
+            ctx.srs_precompute(h, 16)
+        assert ei.value.code == -10 and "GiB" in str(ei.value), ei.value
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    info = ctx.srs_precompute(h, 0)
+    assert info["bytes"] > 0 and info["window_bits"] == 16
+    assert ctx.msm(h, frs(sc)) == want
+    ctx.srs_free(h)

@@ -53,6 +53,10 @@ def test_fr_ops(hc):
     for v in vals + [2, 3, Q // 2, 2**64, 2**128 - 1, 2**254 % Q]:
         a = O.fr_from_int(v)
         assert (call(hc, "hc_fr_inv", 8, a) == O.fr_invert(a)[0]).all(), v
+    # non-canonical limbs (a caller's record): multiples of q are the zero they represent -- 0 -> 0, and the loop terminates
+    for k in (1, 2):
+        assert not call(hc, "hc_fr_inv", 8, np.array(O.limbs(k * Q, 4), dtype=np.uint64)).any()
+    assert (call(hc, "hc_fr_inv", 8, np.array(O.limbs(Q + 5, 4), dtype=np.uint64)) == call(hc, "hc_fr_inv", 8, np.array(O.limbs(5, 4), dtype=np.uint64))).all()
 
 
 def test_fp_ops(hc):
@@ -67,6 +71,9 @@ def test_fp_ops(hc):
     for v in vals + [2, 3, P // 2, 2**64, 2**192 - 1, 2**380]:
         a = O.fp_from_int(v)
         assert (call(hc, "hc_fp_inv", 12, a) == O.fp_invert(a)[0]).all(), v
+    for k in (1, 2, 9):                                   # 9p < 2^384: the largest multiple twelve limbs can hold
+        assert not call(hc, "hc_fp_inv", 12, np.array(O.limbs(k * P, 6), dtype=np.uint64)).any()
+    assert (call(hc, "hc_fp_inv", 12, np.array(O.limbs(P + 5, 6), dtype=np.uint64)) == call(hc, "hc_fp_inv", 12, np.array(O.limbs(5, 6), dtype=np.uint64))).all()
 
 
 def test_g1_ops(hc):
