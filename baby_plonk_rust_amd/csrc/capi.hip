@@ -31,7 +31,7 @@ int fail(bp_ctx* ctx, int code, const char* what, hipError_t e, const char* file
 static thread_local bool tl_member_worker = false;     // set by the persistent member threads of a group context
 
 hipError_t stream_wait(hipStream_t st) {
-  static const bool block = [] { const char* v = getenv("BP_WAIT_BLOCK"); return v && *v == '1'; }();
+  static const bool block = [] { const char* v = knob("BP_WAIT_BLOCK"); return v && *v == '1'; }();
   if (!block) {
     // the calling thread polls for up to 6 ms (a blocked hipStreamSynchronize wakes up ~20 us late, and a call waits several times);
     // a member's worker thread polls for 50 us only and then blocks: N members must not spin N host cores through the GPU phase
@@ -262,13 +262,6 @@ static void over_members(bp_ctx* ctx, size_t R, const std::function<bool(size_t)
   if (R > 0 && use(0)) work(0);
   for (size_t r : sent) lead->workers[r - 1]->wait();
 }
-// test hook (BP_FORCE_PEER_COPIES=1): take the GPU-to-GPU copy branch (hipMemcpyPeerAsync behind the leader's event) even when
-// both ends are the same device, so that a one-GPU box executes the lines a multi-GPU node runs
-static bool force_peer_copies() {
-  const char* v = getenv("BP_FORCE_PEER_COPIES");
-  return v && *v && *v != '0';
-}
-
 // contiguous point range [lo, hi) of shard r of R over n points; the first n % R shards get one extra point
 static void shard_range(size_t n, size_t r, size_t R, size_t* lo, size_t* hi) {
   const size_t base = n / R, extra = n % R;
@@ -337,7 +330,7 @@ int side_ctx_get(bp_ctx* ctx, bp_ctx** out) {
 
 extern "C" {
 
-const char* bp_version(void) { return "bp_msm_ntt 0.2 (gfx950)"; }
+const char* bp_version(void) { return EXPERIMENT_BUILD ? "bp_msm_ntt 0.3 (gfx950) +experiment" : "bp_msm_ntt 0.3 (gfx950)"; }
 
 int bp_init(bp_ctx** out, int device_id) {
   if (!out) return BP_ERR_INVALID_ARG;
@@ -369,6 +362,9 @@ int bp_init_multi(bp_ctx** out, const int* device_ids, int n_devices) {
       }
     }
     m[0]->members = m;
+    for (int a = 0; a < n_devices; a++)
+      for (int b = a + 1; b < n_devices; b++)
+        if (device_ids[a] == device_ids[b]) m[0]->rehearsal = true;
     for (int r = 1; r < n_devices; r++) {
       m[r]->leader = m[0];
       m[0]->workers.push_back(new MemberWorker());
@@ -699,6 +695,8 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
     }
   }
   const bool naf = (c & MSM_NAF_FLAG) != 0;
+  if (naf && !EXPERIMENT_BUILD)        // every-position tables with NAF digits: measured slower twice, experiment builds only
+    return fail(ctx, BP_ERR_INVALID_ARG, "window_bits must be 0 (auto), 1 (off) or 4..24", hipSuccess, __FILE__, __LINE__);
   if (naf ? ((c & 0xffu) < 6 || (c & 0xffu) > 22 || (c >> 9)) : (c != BP_SRS_TABLES_OFF && (c < 4 || c > 24)))
     return fail(ctx, BP_ERR_INVALID_ARG, "window_bits must be 0 (auto), 1 (off), 4..24, or 256 + w (w = 6..22: every-position tables)", hipSuccess,
                 __FILE__, __LINE__);
@@ -786,7 +784,7 @@ static int msm_shard_launch(bp_ctx* m, SrsEntry* e, size_t local_first, const vo
       BP_HIP(m, hipMemcpyAsync(d, scalars, n * sizeof(fr_t), hipMemcpyHostToDevice, m->stream));
     } else {
       BP_HIP(m, hipStreamWaitEvent(m->stream, ready, 0));
-      if (src_device == m->device && !force_peer_copies()) BP_HIP(m, hipMemcpyAsync(d, scalars, n * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream));
+      if (!peer_path(m, src_device)) BP_HIP(m, hipMemcpyAsync(d, scalars, n * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream));
       else BP_HIP(m, hipMemcpyPeerAsync(d, m->device, scalars, src_device, n * sizeof(fr_t), m->stream));
     }
     d_scalars = d;
@@ -962,7 +960,7 @@ static int commit_many_group_batched(bp_ctx* ctx, uint64_t srs_handle, SrsEntry*
         for (int j = 0; j < cnt && he == hipSuccess; j++) {
           if (lens[j]) {
             const fr_t* src = d_coeffs[base + j] + e->first;
-            if (ctx->device == m->device && !force_peer_copies()) he = hipMemcpyAsync(d + at, src, lens[j] * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream);
+            if (!peer_path(m, ctx->device)) he = hipMemcpyAsync(d + at, src, lens[j] * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream);
             else he = hipMemcpyPeerAsync(d + at, m->device, src, ctx->device, lens[j] * sizeof(fr_t), m->stream);
           }
           ptrs[j] = d + at;
@@ -999,7 +997,7 @@ int commit_many(bp_ctx* ctx, uint64_t srs_handle, const fr_t* const* d_coeffs, c
   SrsEntry* e;
   BP_TRY(srs_find(ctx, srs_handle, &e));
   if (is_group(ctx) && k > 1 && e->d_table) {   // group: ONE pipeline per member over its slices of up to MSM_BATCH_MAX commitments
-    const char* v = getenv("BP_COMMIT_BATCH");
+    const char* v = knob("BP_COMMIT_BATCH");
     if (!(v && *v == '0')) {
       int rc = commit_many_group_batched(ctx, srs_handle, e, d_coeffs, n, k, out);
       if (rc != BP_ERR_TOO_LARGE) return rc;       // too long for one pipeline somewhere: queue the commitments one by one below
@@ -1029,7 +1027,7 @@ int commit_many(bp_ctx* ctx, uint64_t srs_handle, const fr_t* const* d_coeffs, c
   // so the batch runs only on request there (BP_COMMIT_BATCH=1).  The members of a group context, whose shards are short and whose
   // pipelines share one stream each, use it by default (above).
   {
-    const char* v = getenv("BP_COMMIT_BATCH");
+    const char* v = knob("BP_COMMIT_BATCH");
     size_t n_max = 0;
     for (int j = 0; j < k; j++) n_max = std::max(n_max, std::min(n[j], e->n));
     const bool tables = e->d_table && 8 * (uint64_t)n_max >= (1ull << ((e->table_c & MSM_NAF_FLAG) ? (e->table_c & 0xffu) - 2 : e->table_c));
@@ -1160,7 +1158,7 @@ int bp_msm_g1_projective144(bp_ctx* ctx, const uint8_t* points144, size_t n_poin
     if (!e) BP_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   int pieces = 2;
   {
-    const char* v = getenv("BP_SEAM_PIECES");
+    const char* v = knob("BP_SEAM_PIECES");
     if (v && *v >= '1' && *v <= '0' + SEAM_PIECES && !v[1]) pieces = *v - '0';
   }
   const size_t piece = (n + pieces - 1) / pieces;
@@ -1440,13 +1438,6 @@ static int ntt_columns_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, 
 // Returns 1 (not an error code of the ABI) when the shape does not split; only then does the caller run the transform on the
 // leader.  Any other failure is returned as it is: the download phase writes `data` from every member at once, so after a
 // failed copy the buffer may be part input, part output, and must not be transformed again.
-static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {        // out-of-range or malformed: the default
-  const char* v = getenv(name);
-  if (!v || !*v) return dflt;
-  char* end = nullptr;
-  const unsigned long x = strtoul(v, &end, 10);
-  return (end == v || *end || x < lo || x > hi) ? dflt : (uint32_t)x;
-}
 static int ntt_one_over_members(bp_ctx* ctx, uint8_t* data, uint32_t log_n, int inverse, int scalar_fmt) {
   const std::vector<bp_ctx*> sh = shards_of(ctx);
   const uint32_t R = (uint32_t)sh.size();
@@ -1531,7 +1522,7 @@ int bp_ntt_fr(bp_ctx* ctx, void* data, uint32_t log_n, int inverse, int scalar_f
   if (batch > 1 && stride < N) return fail(ctx, BP_ERR_INVALID_ARG, "NTT stride < N", hipSuccess, __FILE__, __LINE__);
   if (batch > 65535) return fail(ctx, BP_ERR_TOO_LARGE, "NTT batch > 65535", hipSuccess, __FILE__, __LINE__);
   if (is_group(ctx) && batch > 1) return ntt_columns_over_members(ctx, (uint8_t*)data, log_n, inverse, scalar_fmt, batch, stride);
-  if (is_group(ctx) && log_n >= env_u32("BP_NTT_GROUP_SPLIT_FROM", 22, 11, 29)) {     // one large transform: every member's PCIe link and a share of the work
+  if (is_group(ctx) && log_n >= knob_u32("BP_NTT_GROUP_SPLIT_FROM", 22, 11, 29)) {     // one large transform: every member's PCIe link and a share of the work
     const int rc = ntt_one_over_members(ctx, (uint8_t*)data, log_n, inverse, scalar_fmt);
     if (rc != 1) return rc;                 // done, or a real failure (reported, never papered over: host data may be partly written);
   }                                         // 1 = the shape does not split over this many members: on the leader
@@ -2041,7 +2032,7 @@ int bp_prove(bp_ctx* ctx, uint64_t srs_handle, uint64_t circuit_handle, const vo
   // host witness of 2^18 gates and more on one device: round 1 stages the columns itself, uploads beside the commitments (BP_PROVE_STAGED=0: off)
   bool staged = !witness_on_device && !is_group(ctx) && it->second.log_n >= 18;
   {
-    const char* v = getenv("BP_PROVE_STAGED");
+    const char* v = knob("BP_PROVE_STAGED");
     if (v && *v == '0') staged = false;
     if (v && *v == '1') staged = !witness_on_device && !is_group(ctx);
   }

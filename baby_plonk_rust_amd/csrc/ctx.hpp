@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -12,6 +13,27 @@
 #include "g1_28.hpp"
 
 namespace bp {
+
+// Experiment knobs.  The shipped library reads NO environment variable: every default is the measured best and nothing in the
+// embedding process's environment can change a kernel shape.  A build with -DBP_EXPERIMENT (`make exp` -> libbp_msm_ntt_exp.so,
+// loaded by the tests under tests/ that are marked `experiment`, and by the A/B tools) reads the BP_* variables of DESIGN.md
+// section 12, compiles the alternative builds they select (the one-histogram counting sort, every-position NAF tables) and
+// honours the test hook BP_FORCE_PEER_COPIES.
+#ifdef BP_EXPERIMENT
+inline const char* knob(const char* name) { return getenv(name); }
+constexpr bool EXPERIMENT_BUILD = true;
+#else
+inline const char* knob(const char*) { return nullptr; }
+constexpr bool EXPERIMENT_BUILD = false;
+#endif
+// numeric knob: taken only inside [lo, hi]; absent, malformed or out of range leaves the default
+inline uint32_t knob_u32(const char* name, uint32_t dflt, uint32_t lo = 0, uint32_t hi = 0xffffffffu) {
+  const char* v = knob(name);
+  if (!v || !*v) return dflt;
+  char* end = nullptr;
+  const unsigned long x = strtoul(v, &end, 10);
+  return (end == v || *end || x < lo || x > hi) ? dflt : (uint32_t)x;
+}
 
 struct DevBuf {
   void* p = nullptr;
@@ -88,6 +110,10 @@ struct bp_ctx {
   // Every member is a full single-device context (own stream, workspaces, NTT tables) driven by the leader's host thread.
   std::vector<bp_ctx*> members;
   bp_ctx* leader = nullptr;                        // set on members[1..]
+  // a group whose device list names a GPU more than once ({0, 0}: what a one-GPU box can rehearse; production lists are distinct):
+  // its members beyond the leader take the GPU-to-GPU branches -- hipMemcpyPeerAsync behind the leader's event -- exactly as
+  // members on other cards do, so the lines a multi-GPU node executes run in the default test suite, with no knob
+  bool rehearsal = false;
   // leader only: workers[r - 1] is the host thread that drives member r whenever the members work from or to host memory, or
   // wait for their streams: created once in bp_init_multi, reused by every call (no thread is spawned per MSM or per transform)
   std::vector<bp::MemberWorker*> workers;
@@ -154,6 +180,13 @@ struct DeviceGuard {
   DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 inline bool is_group(const bp_ctx* ctx) { return ctx->members.size() > 1; }
+// does a copy between the leader's memory and member m's cross devices?  (m on another GPU, or a rehearsal group's member)
+inline bool peer_path(const bp_ctx* m, int other_device) {
+  if (m->device != other_device) return true;
+  if (m->leader && m->leader->rehearsal) return true;
+  const char* v = knob("BP_FORCE_PEER_COPIES");
+  return v && *v && *v != '0';
+}
 
 #define BP_HIP(ctx, call)                                                              \
   do {                                                                                 \

@@ -14,16 +14,6 @@ static uint32_t ilog2_floor(size_t n) {
   while ((n >> (l + 1)) != 0) l++;
   return l;
 }
-// Experiment knobs (A/B runs, tests): read from the environment, and taken only inside [lo, hi] -- a stray or mistyped
-// variable in the embedding process leaves the default in place instead of changing kernel shapes or dividing by zero.
-static uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo = 0, uint32_t hi = 0xffffffffu) {
-  const char* v = getenv(name);
-  if (!v || !*v) return dflt;
-  char* end = nullptr;
-  const unsigned long x = strtoul(v, &end, 10);
-  return (end == v || *end || x < lo || x > hi) ? dflt : (uint32_t)x;
-}
-
 // Window width: minimise W * (n + 2 * 2^(c-1)) (bucket adds + reduction adds).  Per-window bucket sets (any point set) are
 // bounded by the 128 KiB LDS histogram of one window (c <= 16); with fixed-base tables wider windows go through the
 // partitioned sort (plan.parts > 1), up to MSM_MAX_TABLE_C.
@@ -48,8 +38,8 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
     uint32_t chunk = (uint32_t)(((uint64_t)plan.W * n * J + 131071) / 131072);
     if (chunk < 4) chunk = 4;
     if (chunk > 1024) chunk = 1024;
-    plan.chunk = env_u32("BP_MSM_CHUNK", chunk, 1, 1024);
-    plan.lanes = env_u32("BP_MSM_CHUNK", 0, 1, 1024) ? 0u : (uint32_t)(((uint64_t)plan.W * n * J + plan.chunk - 1) / plan.chunk);
+    plan.chunk = knob_u32("BP_MSM_CHUNK", chunk, 1, 1024);
+    plan.lanes = knob_u32("BP_MSM_CHUNK", 0, 1, 1024) ? 0u : (uint32_t)(((uint64_t)plan.W * n * J + plan.chunk - 1) / plan.chunk);
     plan.slices = 1;
     plan.seg = 1;
     return;
@@ -57,7 +47,7 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   uint32_t c = n < 32 ? 4 : ilog2_floor(n) - 3;
   if (c < 4) c = 4;
   if (c > MSM_MAX_C) c = MSM_MAX_C;
-  c = env_u32("BP_MSM_C", c, 2, MSM_MAX_C);
+  c = knob_u32("BP_MSM_C", c, 2, MSM_MAX_C);
   if (c > (uint32_t)MSM_MAX_C) c = MSM_MAX_C;          // per-window bucket sets: one LDS histogram per window
   if (table_c) c = table_c;                          // tables: up to MSM_MAX_TABLE_C through the partitioned sort
   if (c < 2) c = 2;
@@ -120,8 +110,8 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   else chunk = (uint32_t)((entries + 262143) / 262144);
   if (chunk < 4) chunk = 4;
   if (chunk > chunk_cap) chunk = chunk_cap;
-  plan.chunk = env_u32("BP_MSM_CHUNK", chunk, 1, 1024);
-  plan.lanes = env_u32("BP_MSM_CHUNK", 0, 1, 1024) ? 0u : (uint32_t)((entries + plan.chunk - 1) / plan.chunk);      // = the host's n_chunks
+  plan.chunk = knob_u32("BP_MSM_CHUNK", chunk, 1, 1024);
+  plan.lanes = knob_u32("BP_MSM_CHUNK", 0, 1, 1024) ? 0u : (uint32_t)((entries + plan.chunk - 1) / plan.chunk);      // = the host's n_chunks
   // count/scatter workgroups per window: each flushes its whole LDS histogram with global atomics, so fewer, fatter
   // slices are cheaper (~32 Ki points each) as long as >= 256 workgroups remain to fill the CUs (measured: 2^16, 2^20, 2^24)
   uint32_t slices = (uint32_t)(n >> 15), lo = 256 / W, hi = 1024 / W;
@@ -129,10 +119,10 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
   if (slices > hi) slices = hi;
   if (slices < 1) slices = 1;
   while (slices > 1 && n / slices < 1024) slices >>= 1;
-  plan.slices = env_u32("BP_MSM_SLICES", slices, 1, 4096);
+  plan.slices = knob_u32("BP_MSM_SLICES", slices, 1, 4096);
   uint32_t seg = 1;
   while (seg < 32 && plan.total / seg > 65536) seg <<= 1;
-  plan.seg = env_u32("BP_MSM_SEG", seg, 1, 1024);
+  plan.seg = knob_u32("BP_MSM_SEG", seg, 1, 1024);
 }
 
 // unsaturated copy of an SRS (128-byte slots) (allocated here, owned by the SRS entry)
@@ -194,8 +184,10 @@ static g1_proj slot_to_proj(const proj28_slot* slot) {
 // dynamic-LDS limits are per function AND per device: set them for every context at creation (bp_init), after hipSetDevice
 int msm_init_device(bp_ctx* ctx) {
   // a full-window histogram at c = 16 needs 128 KiB of dynamic LDS
+#ifdef BP_EXPERIMENT
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_count, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
   // these two also hold a few KiB of static LDS: the dynamic limit must leave room for it
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   BP_HIP(ctx, hipFuncSetAttribute((const void*)msm_radix_final<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
@@ -258,7 +250,6 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   const uint32_t blocks_per_window = table_c ? 0 : ((B + plan.seg - 1) / plan.seg + 255) / 256;
   const uint32_t per_window = table_c ? plan.c : 1;     // slots per window that go to the host
 
-  int16_t* digits = nullptr;
   uint32_t *counts, *offsets, *cursors, *sorted;
   proj28_slot *bucket_sum, *partial, *block_out, *window_sum;
   // a bucket is "long" when it spans >= FIXUP_LONG chunks, so at most n_chunks / FIXUP_LONG + 1 buckets can be long
@@ -294,9 +285,6 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   proj28_slot* h_windows = reinterpret_cast<proj28_slot*>(h_base + (size_t)slot * slot_bytes);
   hipStream_t st = ctx->stream;
   BP_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-  const size_t hist_bytes = (size_t)B * 4;
-  const unsigned hist_threads = B >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
-  const uint32_t n_tiles = (total + SCAN_TILE - 1) / SCAN_TILE;      // <= 4096 (total <= 2^24)
   // Bucket sort, three builds: the partition sort (default wherever its 2^pb <= 2^11 partitions leave final runs
   // that one workgroup sorts: up to ~5 * 10^7 entries), the two-level radix sort (beyond), the one-histogram counting sort of
   // round 1 (c <= 16 only; kept selectable for A/B: BP_MSM_SORT=0 histogram, 1 two-level, 2 partition).
@@ -305,7 +293,7 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   while ((1ull << kb) < total) kb++;
   uint32_t pb = 0;
   while (pb < kb && (max_entries >> (pb + 1)) >= 12288) pb++;             // final runs of ~12-24 Ki entries
-  pb = env_u32("BP_MSM_RADIX_BITS", pb, 0, 16);
+  pb = knob_u32("BP_MSM_RADIX_BITS", pb, 0, 16);
   if (pb + MSM_HIST_LOG < kb) pb = kb - MSM_HIST_LOG;                   // a final run's buckets must fit one LDS histogram
   if (pb > kb) pb = kb;
   if (pb > 16) pb = 16;
@@ -317,11 +305,11 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   const uint64_t idx_max = (uint64_t)(n - 1) + (uint64_t)(plan.naf ? 255u : W - 1) * plan.wpoints;
   uint32_t vb = 1;
   while ((idx_max >> (vb - 1)) != 0) vb++;                              // vb - 1 = bits of the largest entry, + 1 for the sign
-  const uint32_t packed_env = env_u32("BP_MSM_PACKED", 1, 0, 2);
-  if (packed_env == 1 && kb + vb > 32 + pb && kb + vb - 32 <= PART_MAX_BITS && env_u32("BP_MSM_RADIX_BITS", 99, 0, 16) == 99) pb = kb + vb - 32;
-  const uint32_t sort_env = env_u32("BP_MSM_SORT", 2, 0, 2);
+  const uint32_t packed_env = knob_u32("BP_MSM_PACKED", 1, 0, 2);
+  if (packed_env == 1 && kb + vb > 32 + pb && kb + vb - 32 <= PART_MAX_BITS && knob_u32("BP_MSM_RADIX_BITS", 99, 0, 16) == 99) pb = kb + vb - 32;
+  const uint32_t sort_env = knob_u32("BP_MSM_SORT", 2, 0, 2);
   const bool hist_ok = plan.parts == 1 && !plan.naf && J == 1;
-  const int sort_mode = (sort_env == 0 && hist_ok) ? 0 : (((sort_env == 1 && J == 1) || pb > PART_MAX_BITS) ? 1 : 2);
+  const int sort_mode = (EXPERIMENT_BUILD && sort_env == 0 && hist_ok) ? 0 : (((sort_env == 1 && J == 1) || pb > PART_MAX_BITS) ? 1 : 2);
   if (sort_mode != 2 && J > 1) return fail(ctx, BP_ERR_TOO_LARGE, "MSM batch too long for the partition sort", hipSuccess, __FILE__, __LINE__);
   const uint32_t rbits = kb - pb, n_final = 1u << pb;
   const size_t rhist = ((size_t)1 << rbits) * 4;
@@ -332,7 +320,7 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     // scalars per workgroup: the staging area (slice * W records) within 64 KiB, and >= 512 workgroups where n allows
     uint32_t slice = 64;
     while (slice < 1024 && (uint64_t)2 * slice * W * rec_bytes <= 65536 && (uint64_t)slice * 512 < (uint64_t)n * J) slice <<= 1;
-    slice = env_u32("BP_MSM_PART_SLICE", slice, 64, 4096);
+    slice = knob_u32("BP_MSM_PART_SLICE", slice, 64, 4096);
     if (slice < 64 || slice > 4096 || (uint64_t)slice * W * rec_bytes > 65536) slice = 64;
     const uint32_t cap = slice * W, n_slices = (uint32_t)(((uint64_t)n * J + slice - 1) / slice);
     const unsigned threads = slice >= 1024 ? 1024u : (slice <= 256 ? 256u : slice);
@@ -346,16 +334,16 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     // sizes with a quarter of the global atomics (BP_MSM_COUNT_SLICE forces a size)
     uint32_t slice1 = slice;
     while (slice1 < 8192 && (uint64_t)slice1 * 256 < (uint64_t)n * J) slice1 <<= 1;      // measured at 2^20: 48 / 41 / 34 / 48 us at 1 024 / 2 048 / 4 096 / 8 192
-    slice1 = env_u32("BP_MSM_COUNT_SLICE", slice1, 64, 65536);
+    slice1 = knob_u32("BP_MSM_COUNT_SLICE", slice1, 64, 65536);
     const uint32_t n_slices1 = (uint32_t)(((uint64_t)n * J + slice1 - 1) / slice1);
     hipLaunchKernelGGL(msm_part_count, dim3(n_slices1), dim3(slice1 >= 1024 ? 1024u : threads), 0, st, scalars_all, fmt, plan, slice1, pb, rbits, ctl + 4, roff, cur, long_count + 1);
     // a slice's share of a partition: long -> partition-major write-out, short -> one lane per record (BP_MSM_PART_FLAT = 0 / 1 forces)
-    const uint32_t flat_env = env_u32("BP_MSM_PART_FLAT", 2, 0, 2);
+    const uint32_t flat_env = knob_u32("BP_MSM_PART_FLAT", 2, 0, 2);
     const bool flat = flat_env == 2 ? (cap >> pb) < 8 : flat_env == 1;
     const size_t part_lds = (size_t)3 * n_final * 4 + (size_t)cap * rec_bytes + (flat ? (size_t)cap * 2 : 0);
     const dim3 lgrid(64, n_final < 4 ? n_final : 4);
     // short final runs (2^12 runs of ~3 Ki records at c = 20): 512-lane workgroups (measured 70 / 60 / 72 us at 256 / 512 / 1024 lanes)
-    const unsigned final_threads = env_u32("BP_MSM_FINAL_THREADS", (max_entries >> pb) <= 8192 ? 512 : 1024, 256, 1024) & ~63u;
+    const unsigned final_threads = knob_u32("BP_MSM_FINAL_THREADS", (max_entries >> pb) <= 8192 ? 512 : 1024, 256, 1024) & ~63u;
     if (packed) {
       if (flat) hipLaunchKernelGGL((msm_part_scatter<true, true>), dim3(n_slices), dim3(threads), part_lds, st, scalars_all, fmt, plan, slice, pb, rbits, vb, cap, cur, recs, rvals);
       else hipLaunchKernelGGL((msm_part_scatter<true, false>), dim3(n_slices), dim3(threads), part_lds, st, scalars_all, fmt, plan, slice, pb, rbits, vb, cap, cur, recs, rvals);
@@ -401,9 +389,11 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     BP_HIP(ctx, hipMemcpyAsync(run_off[0], whole, sizeof whole, hipMemcpyHostToDevice, st));
     uint32_t* rlong_list;
     BP_TRY(ws_get(ctx, "msm.run_long", ((size_t)n_final + 2) * 4, (void**)&rlong_list));
+#ifdef BP_EXPERIMENT
     if (plan.naf)
       hipLaunchKernelGGL(msm_naf_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, keys[0], vals[0], long_count + 1);
     else
+#endif
       hipLaunchKernelGGL(msm_digit_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, keys[0], vals[0], long_count + 1);
     uint32_t runs = 1, shift = kb, side = 0;
     for (int level = 0; level < 2 && lv[level]; level++) {
@@ -435,6 +425,11 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
       hipLaunchKernelGGL(msm_radix_long_scatter<false>, lgrid, dim3(1024), rhist, st, rr, run_off[level_count], rbits, rlong_n, rlong_list, cursors, sorted);
     }
   } else {
+#ifdef BP_EXPERIMENT
+    int16_t* digits = nullptr;
+  const size_t hist_bytes = (size_t)B * 4;
+  const unsigned hist_threads = B >= 4096 ? 1024 : 256;   // a big histogram owns the CU's LDS: fill the CU with one workgroup
+  const uint32_t n_tiles = (total + SCAN_TILE - 1) / SCAN_TILE;      // <= 4096 (total <= 2^24)
     BP_TRY(ws_get(ctx, "msm.digits", max_entries * sizeof(int16_t), (void**)&digits));
     BP_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)total * 4, st));
     hipLaunchKernelGGL(msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, digits, long_count + 1);
@@ -443,10 +438,13 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     hipLaunchKernelGGL(scan_block_sums, dim3(1), dim3(256), 0, st, tile_sums, n_tiles, offsets + total);
     hipLaunchKernelGGL(scan_apply, dim3(n_tiles), dim3(256), 0, st, counts, total, tile_sums, offsets, cursors);
     hipLaunchKernelGGL(msm_scatter, dim3(plan.slices, W), dim3(hist_threads), hist_bytes, st, digits, plan, cursors, sorted);
+#else
+    return fail(ctx, BP_ERR_INVALID_ARG, "counting sort is an experiment build", hipSuccess, __FILE__, __LINE__);      // unreachable: sort_mode 0 needs a knob
+#endif
   }
   BP_HIP(ctx, hipEventRecord(ctx->ev[1], st));
   const dim3 acc_grid((unsigned)((n_chunks + 255) / 256));
-  switch (env_u32("BP_MSM_ACC_WAVES", 2, 2, 4)) {
+  switch (knob_u32("BP_MSM_ACC_WAVES", 2, 2, 4)) {
     case 3: hipLaunchKernelGGL(msm_accumulate<3>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial); break;
     case 4: hipLaunchKernelGGL(msm_accumulate<4>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial); break;
     default: hipLaunchKernelGGL(msm_accumulate<2>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial);
@@ -455,7 +453,7 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   // fix-up of the buckets cut by chunk edges.  Long buckets (tables at c <= 17: every one of the 2^15 buckets spans several chunks):
   // two lanes per bucket = one wave per SIMD, half the chain.  Short buckets (wide windows, per-window bucket sets): most buckets
   // sit inside one chunk -- one lane per chunk edge.  BP_MSM_FIXUP=1 / 2 forces the per-bucket / per-edge form.
-  const uint32_t fixup_env = env_u32("BP_MSM_FIXUP", 0, 0, 2);
+  const uint32_t fixup_env = knob_u32("BP_MSM_FIXUP", 0, 0, 2);
   const bool by_edges = fixup_env ? fixup_env == 2 : max_entries / total < 2ull * plan.chunk;
   if (by_edges)
     hipLaunchKernelGGL(msm_fixup_edges, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, offsets, plan, bucket_sum, partial, long_count,
@@ -474,7 +472,7 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     // is latency bound: up to PLANES_STEP_LOG levels per launch inside workgroups, cooperative additions (msm_planes_step).
     // A node of 2^k buckets carries k + 1 values; the two ping-pong buffers hold at most B values (level 1).
     const uint32_t levels = plan.c - 1;               // >= 1 (make_plan keeps c >= 2)
-    const uint64_t wide_min = env_u32("BP_MSM_PLANES_WIDE_MIN", 40000, 256, 1u << 30);
+    const uint64_t wide_min = knob_u32("BP_MSM_PLANES_WIDE_MIN", 40000, 256, 1u << 30);
     uint32_t k = 0, nodes = total, n_wide = 0;            // total = J B leaves: a forest of J trees (J > 1: the vectors of a batch)
     while (n_wide < levels && (uint64_t)(total >> (n_wide + 1)) * (n_wide + 1) >= wide_min) n_wide++;
     proj28_slot* tmp[2] = {nullptr, nullptr};
@@ -495,7 +493,7 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     }
     const proj28_slot* in = bucket_sum;
     int flip = 0;
-    const bool fuse01 = n_wide >= 2 && env_u32("BP_MSM_PLANES_FUSE01", 1, 0, 1) != 0;
+    const bool fuse01 = n_wide >= 2 && knob_u32("BP_MSM_PLANES_FUSE01", 1, 0, 1) != 0;
     while (k < levels) {
       const bool leaf = k == 0;
       if (leaf && fuse01) {                 // levels 0 and 1 in one launch, four buckets per lane

@@ -77,6 +77,7 @@ constexpr uint32_t MSM_MAX_BATCH = 4;
 struct MsmScalars { const fr_t* p[MSM_MAX_BATCH]; };
 
 // ---------------------------------------------------------------- 1. digits
+#ifdef BP_EXPERIMENT      // one-histogram counting sort (BP_MSM_SORT=0): digit array pass
 // fmt 0: 32-byte little-endian canonical (Scalar::to_bytes), 1: Montgomery limbs (Scalar::to_array)
 __global__ void __launch_bounds__(256) msm_digits(const fr_t* __restrict__ scalars, int fmt, MsmPlan plan,
                                                    int16_t* __restrict__ digits, uint32_t* __restrict__ status) {
@@ -108,6 +109,7 @@ __global__ void __launch_bounds__(256) msm_digits(const fr_t* __restrict__ scala
   }
 }
 
+#endif  // BP_EXPERIMENT
 // bucket index inside a window for a non-zero digit: |d| - 1 in [0, 2^(c-1))
 __device__ __forceinline__ uint32_t digit_bucket(int32_t d) { return (uint32_t)(d < 0 ? -d : d) - 1u; }
 
@@ -121,6 +123,7 @@ __device__ __forceinline__ void slice_range(const MsmPlan& plan, uint32_t slice,
   if (lo > plan.n) lo = plan.n;
 }
 
+#ifdef BP_EXPERIMENT      // one-histogram counting sort: count pass
 __global__ void __launch_bounds__(1024) msm_count(const int16_t* __restrict__ digits, MsmPlan plan,
                                                   uint32_t* __restrict__ counts) {
   const uint32_t w = blockIdx.y, B = plan.B;
@@ -140,6 +143,7 @@ __global__ void __launch_bounds__(1024) msm_count(const int16_t* __restrict__ di
   }
 }
 
+#endif  // BP_EXPERIMENT
 // ---------------------------------------------------------------- 3. scan (three small launches)
 // offsets[0..total] = exclusive prefix sums of counts[0..total); cursors = copy of offsets[0..total).
 // Tile = 4096 counts per workgroup (256 lanes x 16).  scan_tile_sums -> scan_block_sums -> scan_apply.
@@ -216,6 +220,7 @@ __global__ void __launch_bounds__(256) scan_apply(const uint32_t* __restrict__ c
   }
 }
 
+#ifdef BP_EXPERIMENT      // one-histogram counting sort: scatter pass
 // ---------------------------------------------------------------- 4. scatter (counting sort)
 __global__ void __launch_bounds__(1024) msm_scatter(const int16_t* __restrict__ digits, MsmPlan plan,
                                                     uint32_t* __restrict__ cursors, uint32_t* __restrict__ sorted) {
@@ -245,6 +250,7 @@ __global__ void __launch_bounds__(1024) msm_scatter(const int16_t* __restrict__ 
   }
 }
 
+#endif  // BP_EXPERIMENT
 // exclusive scan of one value per lane over a 1024-lane workgroup (16 waves); lds16: 16 words
 __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* lds16) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -306,6 +312,7 @@ __global__ void __launch_bounds__(256) msm_digit_records(const fr_t* __restrict_
   }
 }
 
+#ifdef BP_EXPERIMENT      // every-position tables with NAF digits (bp_srs_precompute(h, 256 + w))
 // Width-w NAF records of every scalar (plan.naf = w): slot s of scalar i at [s * n + i].  With E = (k >> pos) + carry:
 // E even -> next position; E odd -> e = E mod 2^w, digit d = e (carry 0) or e - 2^w (carry 1) when e >= 2^(w-1), pos += w.
 // k < 2^255, so every digit sits at a position <= 255 and there are at most 255 / w + 1 of them (= plan.W slots).
@@ -360,6 +367,7 @@ __global__ void __launch_bounds__(256) msm_naf_records(const fr_t* __restrict__ 
   for (; slot < plan.W; slot++) keys[(size_t)slot * plan.n + i] = RADIX_EMPTY;
 }
 
+#endif  // BP_EXPERIMENT
 // run r = records [run_off[r], run_off[r + 1]); the workgroups blockIdx.x, blockIdx.x + gridDim.x, ... take its slices
 __global__ void __launch_bounds__(1024) msm_radix_count(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ run_off, uint32_t shift,
                                                         uint32_t bits, uint32_t* __restrict__ cnt) {

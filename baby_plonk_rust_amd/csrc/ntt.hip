@@ -39,16 +39,8 @@ int ntt_init_tables(bp_ctx* ctx) {
 
 // one radix-4 group (four elements, two stages in registers) per lane: 2^(l-2) * columns lanes, capped at 512 (the kernels'
 // launch bound: a group needs ~140 registers).  BP_NTT_LANES_SHIFT = 1 doubles the lanes (they only help the load/store phases).
-// experiment knobs (A/B runs): taken only inside [lo, hi]; anything else in the environment of the embedding process leaves the default
-static uint32_t env_ntt(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
-  const char* v = getenv(name);
-  if (!v || !*v) return dflt;
-  char* end = nullptr;
-  const unsigned long x = strtoul(v, &end, 10);
-  return (end == v || *end || x < lo || x > hi) ? dflt : (uint32_t)x;
-}
 static unsigned pass_threads(uint32_t l, uint32_t cl) {
-  unsigned t = (((1u << l) << cl) >> 2) << env_ntt("BP_NTT_LANES_SHIFT", 0, 0, 1);
+  unsigned t = (((1u << l) << cl) >> 2) << knob_u32("BP_NTT_LANES_SHIFT", 0, 0, 1);
   return t > 512 ? 512 : (t < 64 ? 64 : t);
 }
 
@@ -58,23 +50,23 @@ static void make_ntt_plan(NttPlan& plan, uint32_t k) {
   plan.P = k <= NTT_SMALL_MAX_LOG ? 1 : (k <= 2 * NTT_MAX_PASS_LOG ? 2 : 3);
   // 2^20 as 7 + 7 + 6: small tiles keep three workgroups per CU busy (0.152 ms against 0.159 for 10 + 10, whose 74-KiB tiles
   // leave one 512-lane workgroup per CU); 2^19 stays 10 + 9 (0.080 against 0.084).  profiles/r02_ntt_radix4_ab.txt
-  if (plan.P == 2 && k >= env_ntt("BP_NTT_THREE_PASS_FROM", 20, 11, 29)) plan.P = 3;
+  if (plan.P == 2 && k >= knob_u32("BP_NTT_THREE_PASS_FROM", 20, 11, 29)) plan.P = 3;
   uint32_t rem = k;
   for (uint32_t i = 0; i < plan.P; i++) {          // balanced widths, larger ones first
     uint32_t left = plan.P - i;
     plan.l[i] = (rem + left - 1) / left;
     rem -= plan.l[i];
     plan.cl[i] = ntt_tile_cols_log(plan.l[i]);
-    if (plan.l[i] <= 7) plan.cl[i] = env_ntt("BP_NTT_COLS_LOG_L7", plan.cl[i], 0, 3);
-    if (plan.l[i] == 8) plan.cl[i] = env_ntt("BP_NTT_COLS_LOG_L8", plan.cl[i], 0, 3);
-    if (plan.l[i] == 9) plan.cl[i] = env_ntt("BP_NTT_COLS_LOG_L9", plan.cl[i], 0, 3);
-    if (plan.l[i] == 10) plan.cl[i] = env_ntt("BP_NTT_COLS_LOG_L10", plan.cl[i], 0, 3);
+    if (plan.l[i] <= 7) plan.cl[i] = knob_u32("BP_NTT_COLS_LOG_L7", plan.cl[i], 0, 3);
+    if (plan.l[i] == 8) plan.cl[i] = knob_u32("BP_NTT_COLS_LOG_L8", plan.cl[i], 0, 3);
+    if (plan.l[i] == 9) plan.cl[i] = knob_u32("BP_NTT_COLS_LOG_L9", plan.cl[i], 0, 3);
+    if (plan.l[i] == 10) plan.cl[i] = knob_u32("BP_NTT_COLS_LOG_L10", plan.cl[i], 0, 3);
     if (plan.cl[i] > 3) plan.cl[i] = 3;
     // an override must still fit the 160 KiB of LDS (tile rows x (columns + pad) + stage twiddles, 36 B each)
     if ((((size_t)1 << plan.l[i]) * ((1u << plan.cl[i]) + 1) + ntt_tw_slots(plan.l[i]) + 2) * N29 * 4 + 16 > 160 * 1024) plan.cl[i] = ntt_tile_cols_log(plan.l[i]);
   }
   // experiment knob: BP_NTT_SPLIT="k:l1,l2,l3" replaces the digit widths of one size (widths must add up to k, each <= 10)
-  if (const char* e = getenv("BP_NTT_SPLIT")) {
+  if (const char* e = knob("BP_NTT_SPLIT")) {
     unsigned kk = 0, a = 0, b = 0, c = 0;
     const int got = sscanf(e, "%u:%u,%u,%u", &kk, &a, &b, &c);
     if (got >= 3 && kk == k && a + b + c == k && a <= (unsigned)NTT_MAX_PASS_LOG && b <= (unsigned)NTT_MAX_PASS_LOG && c <= (unsigned)NTT_MAX_PASS_LOG &&
@@ -170,7 +162,7 @@ int ntt_run_part(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batc
     fr_t* tmp;
     BP_TRY(ws_get(ctx, "ntt.tmp", batch * N * sizeof(fr_t), (void**)&tmp));
     // 2^l x 8 tiles with l <= 7 run unpadded with swizzled rows (39 KiB at l = 7, bank-conflict-free drain); BP_NTT_SWIZZLE=0: padded
-    const bool swz_on = env_ntt("BP_NTT_SWIZZLE", 1, 0, 1) != 0;
+    const bool swz_on = knob_u32("BP_NTT_SWIZZLE", 1, 0, 1) != 0;
     auto swizzled = [&](uint32_t l, uint32_t cl) { return swz_on && cl == 3 && l <= 7 && l >= 2; };
     auto tile_lds = [&](uint32_t l, uint32_t cl) {
       const uint32_t C = 1u << cl, tstride = ((1u << l) * (swizzled(l, cl) || C == 1 ? C : C + 1) + 1) & ~1u;
@@ -192,7 +184,7 @@ int ntt_run_part(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batc
         BP_HIP(ctx, hipFree(tab->full[i]));
         tab->full[i] = nullptr;
       }
-      if (!tab->full[i] && k <= env_ntt("BP_NTT_FULL_TWIDDLES_MAX_LOG", 24, 0, 28)) {      // built once per (N, direction, pass)
+      if (!tab->full[i] && k <= knob_u32("BP_NTT_FULL_TWIDDLES_MAX_LOG", 24, 0, 28)) {      // built once per (N, direction, pass)
         const size_t M = (size_t)1 << (l + s);
         tab->full_ls[i] = (l << 8) | s;
         BP_HIP(ctx, hipMalloc((void**)&tab->full[i], M * sizeof(tw29_t)));

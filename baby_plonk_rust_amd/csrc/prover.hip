@@ -279,13 +279,10 @@ void circuit_release(CircuitEntry& e) {
 }
 
 // ------------------------------------------------------------------------------------------------ round 3 by coset (group contexts)
-static bool force_peer() {
-  const char* v = getenv("BP_FORCE_PEER_COPIES");
-  return v && *v && *v != '0';
-}
 // src (on device src_dev) -> dst (on m's device), n elements, on m's stream
-static hipError_t copy_to_member(bp_ctx* m, fr_t* dst, const fr_t* src, int src_dev, size_t n) {
-  if (src_dev == m->device && !force_peer()) return hipMemcpyAsync(dst, src, n * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream);
+// (owner: the group member the stream's context belongs to, when m is that member's side context)
+static hipError_t copy_to_member(bp_ctx* m, fr_t* dst, const fr_t* src, int src_dev, size_t n, const bp_ctx* owner = nullptr) {
+  if (!peer_path(owner ? owner : m, src_dev)) return hipMemcpyAsync(dst, src, n * sizeof(fr_t), hipMemcpyDeviceToDevice, m->stream);
   return hipMemcpyPeerAsync(dst, m->device, src, src_dev, n * sizeof(fr_t), m->stream);
 }
 
@@ -375,7 +372,7 @@ static int coset_inputs(bp_ctx* ctx, const CircuitEntry& cir, const CosetShare& 
   *ev_out = ev;
   BP_HIP(ctx, hipStreamWaitEvent(w->stream, ctx->ev[4], 0));          // the coefficient vectors are ready behind the leader's event
   for (int p = 0; p < 5; p++)
-    if (which >> p & 1) BP_HIP(ctx, copy_to_member(w, cf + (size_t)p * cap, coefs5[p], ctx->device, lens5[p]));
+    if (which >> p & 1) BP_HIP(ctx, copy_to_member(w, cf + (size_t)p * cap, coefs5[p], ctx->device, lens5[p], sh.member));
   for (uint32_t c = 0; c < sh.count; c++) {
     const uint32_t j = sh.first + c;
     fr_t sn = gn;                                                     // s_j^n = g^n i4^j
@@ -448,7 +445,7 @@ static int round3_by_coset(bp_ctx* ctx, const CircuitEntry& cir, const fr_t* con
         return rc;
       }
       // back to the leader: the copy is issued on the work stream (it follows the kernels that produced tq)
-      hipError_t he = (w->device == ctx->device && !force_peer())
+      hipError_t he = !peer_path(sh.member ? sh.member : w, ctx->device)
                           ? hipMemcpyAsync(v + (size_t)j * n, tq, n * sizeof(fr_t), hipMemcpyDeviceToDevice, w->stream)
                           : hipMemcpyPeerAsync(v + (size_t)j * n, ctx->device, tq, w->device, n * sizeof(fr_t), w->stream);
       if (he != hipSuccess) return fail(ctx, BP_ERR_HIP, "coset quotient back to the leader", he, __FILE__, __LINE__);
@@ -565,18 +562,18 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
   const unsigned blocks_N = (unsigned)((N + 255) / 256);
   bool split_on = !cir.split.empty();                                                // group context: round 3 by coset over the members
   {
-    const char* v = getenv("BP_PROVE_COSET_SPLIT");
+    const char* v = knob("BP_PROVE_COSET_SPLIT");
     if (v && *v == '0') split_on = false;
   }
   bool side_on = !split_on && k < 20;
   {
-    const char* v = getenv("BP_PROVE_SIDE");
+    const char* v = knob("BP_PROVE_SIDE");
     if (v && *v == '0') side_on = false;
     if (v && *v == '1') side_on = !split_on;
   }
   bool early_on = split_on;                // a, b, c, PI to the members' cosets now, beside the commitments (BP_PROVE_COSET_EARLY=0: in round 3)
   {
-    const char* v = getenv("BP_PROVE_COSET_EARLY");
+    const char* v = knob("BP_PROVE_COSET_EARLY");
     if (v && *v == '0') early_on = false;
   }
   const fr_t* coefs5[5] = {poly_abc[0], poly_abc[1], poly_abc[2], zc + (n + 8), coefs + 3 * n};

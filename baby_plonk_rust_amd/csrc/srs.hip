@@ -32,7 +32,7 @@ int srs_from_projective_run(bp_ctx* ctx, const g1_proj* d_in, size_t n, g1_affin
   uint32_t group = 8;
   while (group < 64 && (n / group) > 65536) group <<= 1;
   {
-    const char* v = getenv("BP_SRS_PROJ_GROUP");        // experiment knob
+    const char* v = knob("BP_SRS_PROJ_GROUP");        // experiment knob
     if (v) {
       const long g = strtol(v, nullptr, 10);
       if (g >= 1 && g <= 4096) group = (uint32_t)g;

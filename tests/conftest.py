@@ -11,6 +11,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experiment: needs the experiment build of the library (BABY_PLONK_LIBRARY=exp)")
 
 
 @pytest.fixture(scope="session")

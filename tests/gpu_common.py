@@ -2,11 +2,17 @@
 import os
 
 import numpy as np
+import pytest
 
 from oracle import oracle as O
 from tests import bigint_model as M
 
 Q = M.Q
+# Tests that set BP_* knobs need the experiment build (make -C baby_plonk_rust_amd/csrc exp; run with BABY_PLONK_LIBRARY=exp):
+# the shipped library reads no environment.  Under the default library they are skipped.
+from baby_plonk_rust_amd import _lib as _bp_lib  # noqa: E402
+EXPERIMENT = _bp_lib.EXPERIMENT
+experiment = pytest.mark.skipif(not EXPERIMENT, reason="needs the experiment build: BABY_PLONK_LIBRARY=exp (make -C baby_plonk_rust_amd/csrc exp)")
 NTHREADS = min(32, os.cpu_count() or 1)
 
 

@@ -9,7 +9,7 @@ import pytest
 import baby_plonk_rust_amd as bp
 from oracle import oracle as O
 from tests import bigint_model as M
-from tests.gpu_common import NTHREADS, Q, closed_form, oracle_dot, progression_bytes
+from tests.gpu_common import NTHREADS, Q, closed_form, experiment, oracle_dot, progression_bytes
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(__file__)
@@ -146,6 +146,7 @@ def _bulk_proj(aff):
     return out
 
 
+@experiment
 @pytest.mark.parametrize("c,chunk", [(4, 4), (7, 8), (11, 16), (13, 32), (16, 64), (16, 4), (5, 64)])
 def test_window_and_chunk_independence(ctx, c, chunk, monkeypatch):
     """the group element does not depend on the window width or on how the sorted list is cut"""

@@ -1,4 +1,4 @@
-"""-m gpu: every build of the MSM pipeline stages gives the same bytes.
+"""-m gpu, experiment build only (BABY_PLONK_LIBRARY=exp): every build of the MSM pipeline stages gives the same bytes.
 
 The bucket sort has three builds (partition sort with packed or two-word records, two-level radix sort, one-histogram counting
 sort), the fix-up two (a lane pair per bucket, a lane per chunk edge), the bit-plane tree two kinds of level (one addition per
@@ -12,9 +12,9 @@ import pytest
 import baby_plonk_rust_amd as bp
 from oracle import oracle as O
 from tests import bigint_model as M
-from tests.gpu_common import Q, oracle_dot
+from tests.gpu_common import Q, experiment, oracle_dot
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, experiment]        # every case forces a build through a BP_* knob
 
 BUILDS = [
     {"BP_MSM_SORT": "2"},                                   # partition sort, packed records (the default)

@@ -10,7 +10,7 @@ import baby_plonk_rust_amd as bp
 from baby_plonk_rust_amd._lib import MSM_BLOB_BYTES
 from oracle import oracle as O
 from tests import bigint_model as M
-from tests.gpu_common import NTHREADS, Q, closed_form, oracle_dot, progression_bytes
+from tests.gpu_common import NTHREADS, Q, closed_form, experiment, oracle_dot, progression_bytes
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(__file__)
@@ -234,6 +234,7 @@ def test_windows_wider_than_16_bits(ctx, c, log_n):
     ctx.srs_free(h)
 
 
+@experiment            # every-position tables exist in the experiment build only (measured slower twice)
 @pytest.mark.parametrize("w,log_n", [(6, 9), (8, 12), (11, 13), (14, 15), (16, 16), (18, 17), (19, 17), (22, 17)])
 def test_every_position_tables_naf_digits(ctx, w, log_n):
     """bp_srs_precompute(handle, 256 + w): tables of EVERY bit position (256 rows, T[p][i] = 2^p P_i) carry the scalars' width-w

@@ -32,10 +32,11 @@ def device_lists():
     return lists
 
 
-@pytest.fixture(params=[False, True], ids=["same_device_copies", "forced_peer_copies"])
+@pytest.fixture(params=[False] + ([True] if G.EXPERIMENT else []), ids=["rehearsal_group"] + (["forced_peer_knob"] if G.EXPERIMENT else []))
 def peer(request, monkeypatch):
-    """BP_FORCE_PEER_COPIES=1: scalars that live on the leader reach the other members by hipMemcpyPeerAsync behind the leader's
-    event even when the members share the card -- the branch a multi-GPU node takes (VERDICT r02 next #2a)"""
+    """A group that names a device twice ({0, 0}) is a rehearsal group: its members beyond the leader take the GPU-to-GPU branches
+    (hipMemcpyPeerAsync behind the leader's event) exactly as members on other cards do -- the lines a multi-GPU node executes run
+    here by default (VERDICT r02 next #2a), with no knob.  Experiment build: BP_FORCE_PEER_COPIES=1 also forces the leader's own copies."""
     if request.param:
         monkeypatch.setenv("BP_FORCE_PEER_COPIES", "1")
     return request.param
@@ -187,6 +188,22 @@ def test_group_context_ntt_columns_and_prove(peer):
     assert len(blobs[0]) == 624 and all(b == blobs[0] for b in blobs)
 
 
+@pytest.mark.parametrize("members", [2, 4, 8])
+def test_group_context_one_large_transform_default_threshold(members):
+    """the shipped library splits ONE host transform over the members from 2^22 elements: same output as one GPU, both directions"""
+    one, many = bp.Context(0), bp.Context([0] * members)
+    x = O.splitmix_scalars(1 << 22, 0xA122)
+    want = one.ntt(x)
+    got = many.ntt(x)
+    assert (got == want).all() and many.ntt_stats()["members"] == members and one.ntt_stats()["members"] == 1
+    assert (many.ntt(got, inverse=True) == x).all()
+    small = O.splitmix_scalars(1 << 12, 0xA112)            # below the threshold: the leader alone
+    assert (many.ntt(small) == O.ntt_fast(small)).all() and many.ntt_stats()["members"] == 1
+    many.close()
+    one.close()
+
+
+@G.experiment
 @pytest.mark.parametrize("members", [2, 4, 8])
 def test_group_context_one_large_transform(members, monkeypatch):
     """SURVEY 8e, NTT option ii: ONE transform over the members of a group context -- column slices up, pass 1, block exchange,
