@@ -85,7 +85,7 @@ struct CircuitEntry {
   std::vector<CosetShare> split;       // group contexts only: round 3 by coset over the members (empty otherwise)
 };
 
-struct MemberWorker;     // persistent host thread of one member of a group context (capi.hip)
+struct MemberWorker;     // persistent host thread of one member of a group context (capi_ctx.hip)
 
 struct tw29_t;
 struct NttTables {       // per (log_n, inverse); entries are 48-byte 29-bit-limb twiddle records (fr29.hpp)
@@ -268,7 +268,7 @@ int srs_encode_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, uint8_t* d_byte
 int srs_from_projective_run(bp_ctx* ctx, const g1_proj* d_in, size_t n, g1_affine* d_out);
 int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t first, size_t n, g1_affine* d_out);
 
-int side_ctx_get(bp_ctx* ctx, bp_ctx** out);       // creates ctx->side and its events on first use (capi.hip)
+int side_ctx_get(bp_ctx* ctx, bp_ctx** out);       // creates ctx->side and its events on first use (capi_ctx.hip)
 int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out);
 int circuit_split_build(bp_ctx* ctx, CircuitEntry& e);      // leader of a group: the members' coset shares (prover.hip)
 void circuit_release(CircuitEntry& e);
@@ -287,7 +287,7 @@ int prove_run(bp_ctx* ctx, uint64_t srs, const CircuitEntry& cir, const fr_t* d_
               const ProveStaged* staged = nullptr);
 void transcript_test_vector(uint8_t out32[32]);
 
-// ---- host-side helpers (host.cpp part of capi.hip) ---------------------------------------------------
+// ---- host-side helpers (capi_ctx.hip) ---------------------------------------------------
 void host_horner(g1_proj& out, const g1_proj* window_sums, uint32_t W, uint32_t c);
 void host_plane_horner(g1_proj& out, const g1_proj* planes, uint32_t W, uint32_t c, bool odd_digits = false);
 void host_encode96(uint8_t out96[96], const g1_proj& p);

@@ -113,7 +113,7 @@ static int get_tables(bp_ctx* ctx, uint32_t k, int inverse, NttTables** out) {
   return BP_OK;
 }
 
-// One transform cut in two phases for a group context (NTT option ii; capi.hip ntt_one_over_members): with the
+// One transform cut in two phases for a group context (NTT option ii; capi_ntt.hip ntt_one_over_members): with the
 // digits N = 2^(l_1 + s), phase 0 is pass 1 on the tiles of a COLUMN slice (all d_1, r in the part's range), phase 1 the passes
 // 2 .. P on the slice of e_1 (each e_1 owns 2^s contiguous elements of the intermediate buffer).  Between the phases the members
 // exchange blocks of the intermediate buffer.  Every member keeps buffers in the full N-element layout, so addresses are the
