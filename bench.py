@@ -125,7 +125,7 @@ def profile_lookup(name, key):
 def msm_roofline(n, acc_s, adds, window_bits, tables, traffic_key=None):
     """HBM roofline (the contract's) and the integer-issue roofline (the one that binds) of msm_accumulate for one launch"""
     achieved = MSM_BYTES_PER_UNIT * n / acc_s / 1e9
-    traffic = profile_lookup("r03_hbm_traffic.json", traffic_key) if traffic_key else None
+    traffic = profile_lookup("r04_hbm_traffic.json", traffic_key) if traffic_key else None
     hbm = {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None, "traffic_source": traffic.get("source") if traffic else None,
            "kernel_ms": acc_s * 1e3, "algorithmic_bytes_per_launch": MSM_BYTES_PER_UNIT * n,
@@ -133,7 +133,7 @@ def msm_roofline(n, acc_s, adds, window_bits, tables, traffic_key=None):
            "designed_bytes_note": "what the fixed-base path moves by design: a gathered 128-B slot and a 4-B list entry per bucket addition "
                                   "(13 per scalar at 20-bit windows), not the 128 B per scalar of the algorithmic figure",
            "note": "integer-issue bound by design (11 Fp products + 8 reductions per bucket addition); see roofline_valu_issue"}
-    mix = profile_lookup("r03_msm_accumulate_instr_mix.json", "msm_accumulate<2>")
+    mix = profile_lookup("r04_msm_accumulate_instr_mix.json", "msm_accumulate<2>")
     issue = None
     if mix and adds:
         # lane-cycles of one loop iteration at the measured issue rates, times the additions actually performed
@@ -156,7 +156,7 @@ def msm_roofline(n, acc_s, adds, window_bits, tables, traffic_key=None):
 
 def ntt_roofline(nn, ntt_s, passes, traffic_key=None):
     achieved = NTT_BYTES_PER_UNIT * nn / ntt_s / 1e9
-    traffic = profile_lookup("r03_hbm_traffic.json", traffic_key) if traffic_key else None
+    traffic = profile_lookup("r04_hbm_traffic.json", traffic_key) if traffic_key else None
     butterflies = (nn // 2) * (nn.bit_length() - 1)
     return {"valu": {"bound": "valu", "achieved": butterflies / ntt_s, "peak": BARE_BUTTERFLIES_PER_S, "unit": "butterflies/s",
                      "frac": butterflies / ntt_s / BARE_BUTTERFLIES_PER_S,

@@ -4,7 +4,7 @@
 #   rocprofv3 kernel statistics of the headline legs, of the 2^24 legs and of a 2^20-gate proof; PMC passes (FETCH_SIZE and
 #   WRITE_SIZE separately, counters only) for the MSM and NTT at 2^20 and 2^24.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out

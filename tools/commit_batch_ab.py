@@ -3,6 +3,7 @@
 pipeline (BP_COMMIT_BATCH=1), on one device and through a group context of `--members` shards on this card."""
 import argparse
 import os
+os.environ.setdefault("BABY_PLONK_LIBRARY", "exp")        # this tool sets BP_* knobs: only the experiment build reads them (make -C baby_plonk_rust_amd/csrc exp)
 import sys
 import time
 

@@ -6,6 +6,7 @@ cases are a subset of what this explores); run it on a GPU box with a time budge
 Exits non-zero with the failing case printed."""
 import argparse
 import os
+os.environ.setdefault("BABY_PLONK_LIBRARY", "exp")        # this tool sets BP_* knobs: only the experiment build reads them (make -C baby_plonk_rust_amd/csrc exp)
 import random
 import sys
 import time

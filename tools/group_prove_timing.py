@@ -3,6 +3,7 @@
 members share one GPU here: this checks that the split costs nothing extra, not what it buys on separate GPUs)"""
 import argparse
 import os
+os.environ.setdefault("BABY_PLONK_LIBRARY", "exp")        # this tool sets BP_* knobs: only the experiment build reads them (make -C baby_plonk_rust_amd/csrc exp)
 import random
 import sys
 import time

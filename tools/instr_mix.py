@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction mix of the bucket-accumulation loop (msm_accumulate<2>), from the device assembly of the shipped source.
 
-  python tools/instr_mix.py [--out profiles/r03_msm_accumulate_instr_mix.json]
+  python tools/instr_mix.py [--out profiles/r04_msm_accumulate_instr_mix.json]
 
 Compiles baby_plonk_rust_amd/csrc/msm.hip for gfx950 to assembly (device side only, same flags as the Makefile), finds the
 kernel, takes its hottest loop = the back-edge span with the most v_mad_u64_u32 (one iteration = one mixed bucket addition
@@ -59,7 +59,7 @@ def hottest_loop(body):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_msm_accumulate_instr_mix.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_msm_accumulate_instr_mix.json"))
     ap.add_argument("--asm", default=None, help="reuse an existing device assembly file")
     args = ap.parse_args()
     src = os.path.join(ROOT, "baby_plonk_rust_amd", "csrc", "msm.hip")

@@ -1,4 +1,5 @@
 #!/bin/bash
+export BABY_PLONK_LIBRARY=exp      # BP_* knobs are read by the experiment build only (make -C baby_plonk_rust_amd/csrc exp)
 # A/B of the NTT tile width (columns per LDS tile) and of the pass split; knobs are environment variables read by csrc/ntt.hip
 run() { python tools/run_msm.py --log-n 10 --reps 5 --ntt-log-n $1 2>&1 | grep "^ntt" | tail -2 | tr '\n' ' '; echo; }
 for lg in 16 18 19 20 21 22 24; do echo -n "default            2^$lg: "; run $lg; done

@@ -1,4 +1,5 @@
 #!/bin/bash
+export BABY_PLONK_LIBRARY=exp      # BP_* knobs are read by the experiment build only (make -C baby_plonk_rust_amd/csrc exp)
 # How a pass of 2^7 x 8 tiles scales with tiles per CU: the same kernel on 256, 512, 1024, 2048 and 4096 tiles (transforms of
 # 2^18 .. 2^22 split as 7 + 7 + rest), swizzled (four workgroups per CU) and padded (three); rocprofv3 kernel durations.
 export TMPDIR=/tmp

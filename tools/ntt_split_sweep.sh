@@ -1,4 +1,5 @@
 #!/bin/bash
+export BABY_PLONK_LIBRARY=exp      # BP_* knobs are read by the experiment build only (make -C baby_plonk_rust_amd/csrc exp)
 # A/B of the pass split of one transform size (BP_NTT_SPLIT="k:l1,l2[,l3]", read by csrc/ntt.hip); device ms, two readings each
 run() { python tools/run_msm.py --log-n 10 --reps 5 --ntt-log-n $1 2>&1 | grep "^ntt" | tail -2 | sed 's/.*device //' | tr '\n' ' '; echo; }
 while read lg splits; do

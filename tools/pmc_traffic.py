@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch from rocprofv3 PMC passes -> profiles/r03_hbm_traffic.json (what bench.py's roofline.traffic reads).
+"""HBM bytes per launch from rocprofv3 PMC passes -> profiles/r04_hbm_traffic.json (what bench.py's roofline.traffic reads).
 
-  python tools/pmc_traffic.py FETCH.csv WRITE.csv [--tag 2p20] [--out profiles/r03_hbm_traffic.json] [--merge]
+  python tools/pmc_traffic.py FETCH.csv WRITE.csv [--tag 2p20] [--out profiles/r04_hbm_traffic.json] [--merge]
 
 FETCH.csv / WRITE.csv are the *_counter_collection.csv files of two separate runs of
   rocprofv3 --pmc FETCH_SIZE  -- python3 tools/run_msm.py --log-n L --reps 2 --tables 0 --ntt-log-n L
@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--tag", required=True, help="size tag of the run, e.g. 2p20")
     ap.add_argument("--window-bits", type=int, default=20)
     ap.add_argument("--tables", type=int, default=1)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"))
     ap.add_argument("--merge", action="store_true")
     args = ap.parse_args()
     fetch, write = per_kernel(args.fetch, "FETCH_SIZE"), per_kernel(args.write, "WRITE_SIZE")
