@@ -20,8 +20,11 @@
  *                        of Setup::commit (src/setup.rs:32-37) uses all GPUs without knowing about them.  Batched host NTTs
  *                        (bp_ntt_fr with batch > 1) spread their independent columns over the GPUs.  Every GPU beyond the
  *                        first is driven by a persistent host thread of the library (uploads, waits, epilogues in parallel).
- *                        STATUS: the GPU-to-GPU copy branches have run on one card only (tests force them with
- *                        BP_FORCE_PEER_COPIES=1 over device lists {0,0} / {0,0,0}); no run on distinct GPUs is recorded yet.
+ *                        A list that names a device twice ({0,0}: what a one-GPU box can rehearse) makes a REHEARSAL group: its
+ *                        members beyond the first take the GPU-to-GPU branches (hipMemcpyPeerAsync behind the leader's event)
+ *                        exactly as members on other cards do.  STATUS: that is the only way those branches have run so far;
+ *                        no run on distinct GPUs is recorded yet.
+ *   - the library reads no environment variable (experiment knobs exist in the separate -DBP_EXPERIMENT build only).
  *       one process per GPU (torch.distributed / MPI launchers): every rank owns a point range in a plain bp_init context,
  *                        leaves its partial sums in HBM (bp_msm_g1_blob_device), the caller all-gathers those buffers
  *                        over RCCL/xGMI and every rank combines them (bp_msm_blobs_combine): one collective, one D2H.
