@@ -472,7 +472,7 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     // is latency bound: up to PLANES_STEP_LOG levels per launch inside workgroups, cooperative additions (msm_planes_step).
     // A node of 2^k buckets carries k + 1 values; the two ping-pong buffers hold at most B values (level 1).
     const uint32_t levels = plan.c - 1;               // >= 1 (make_plan keeps c >= 2)
-    const uint64_t wide_min = knob_u32("BP_MSM_PLANES_WIDE_MIN", 40000, 256, 1u << 30);
+    const uint64_t wide_min = knob_u32("BP_MSM_PLANES_WIDE_MIN", 24000, 256, 1u << 30);
     uint32_t k = 0, nodes = total, n_wide = 0;            // total = J B leaves: a forest of J trees (J > 1: the vectors of a batch)
     while (n_wide < levels && (uint64_t)(total >> (n_wide + 1)) * (n_wide + 1) >= wide_min) n_wide++;
     proj28_slot* tmp[2] = {nullptr, nullptr};

@@ -66,7 +66,7 @@ while time.time() < t_end:
         c_plain = rnd.choice([None, 4, 7, 10, 13, 16])
         if mode == "tables":        # widths above 16 take the partitioned sort (only when 8 n >= 2^width, else the plain path answers)
             # 256 + w: tables of every bit position, width-w NAF digits (256 rows: kept to short SRS here)
-            naf_ok = srs_len <= 40000
+            naf_ok = srs_len <= 40000 and bp._lib.EXPERIMENT          # every-position tables exist in the experiment build only
             ctx.srs_precompute(h, rnd.choice([0, 0, 4, 6, 9, 12, 15, 16, 17, 18, 19, 20] + ([256 + 6, 256 + 9, 256 + 13, 256 + 16, 256 + 19] if naf_ok else [])))
         os.environ.pop("BP_MSM_C", None)
         if c_plain:
