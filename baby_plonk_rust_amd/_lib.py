@@ -13,8 +13,10 @@ import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BABY_PLONK_LIBRARY=exp selects the experiment build (csrc/Makefile `make exp`: the only build that reads BP_* knobs); the
 # shipped library reads no environment at all, so the choice is made here, on the Python side of the boundary.
-EXPERIMENT = os.environ.get("BABY_PLONK_LIBRARY", "") == "exp"
-SO_PATH = os.path.join(_HERE, "libbp_msm_ntt_exp.so" if EXPERIMENT else "libbp_msm_ntt.so")
+# (a value ending in .so names a library file directly: A/B runs of two builds of the shipped library on one box)
+_choice = os.environ.get("BABY_PLONK_LIBRARY", "")
+EXPERIMENT = _choice == "exp"
+SO_PATH = _choice if _choice.endswith(".so") else os.path.join(_HERE, "libbp_msm_ntt_exp.so" if EXPERIMENT else "libbp_msm_ntt.so")
 
 BP_OK = 0
 ERRORS = {

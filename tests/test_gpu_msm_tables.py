@@ -166,6 +166,26 @@ def test_full_size_2p20_with_tables(ctx):
     ctx.srs_free(h)
 
 
+def test_north_star_shard_2p21_auto_width(ctx):
+    """what ONE of 8 GPUs holds in the north-star configuration (2^24 points over 8 GPUs): a 2^21-point SRS shard with its own tables at the
+    automatic width (20 bits, 13 windows; entries need 26 bits, so the partition sort runs on two-word records there) -- closed form on the
+    shard's own point range, with the scalars generated in HBM"""
+    import torch
+    n, a, d, seed, first = 1 << 21, 0x0F1E2D3C4B5A6978, 0x1122334455, 0x5EED0015, 5 << 21         # shard 5 of 8
+    h = ctx.srs_generate_progression(n, a + first * d, d)
+    info = ctx.srs_precompute(h)
+    assert info == {"window_bits": 20, "windows": 13, "bytes": 13 * n * 128}
+    t = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+    ctx.synthetic_scalars_device(t.data_ptr(), n, seed)
+    sc = O.splitmix_scalars(n, seed)
+    want = M.enc96(M.ec_mul(O.dot_progression(sc, a + first * d, d)))
+    assert bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n)) == want
+    st = ctx.msm_stats()
+    assert st["tables"] and st["window_bits"] == 20 and 0 < st["mixed_adds"] <= 13 * n
+    assert ctx.msm(h, sc) == want                                   # the same from host scalars
+    ctx.srs_free(h)
+
+
 def test_full_size_2p24_closed_form_both_paths(ctx):
     """BASELINE configs[3] size on one GPU: 2^24 points generated in HBM, scalars generated in HBM by the same SplitMix64 stream
     the oracle reproduces on the CPU; the result must equal the closed form (sum s_i (a + i d)) G with and without tables"""
