@@ -573,6 +573,7 @@ def main():
         mine_j = bpd.my_columns(NTT_COLUMNS, rank, world)
         fresh = {j: synthetic(nn, 0xC0100000 + 977 * j).view(nn, 4) for j in mine_j}
         colbuf = {j: t.clone() for j, t in fresh.items()}
+        torch.cuda.synchronize()                                # the clones run on torch's stream, the transforms on the library's
 
         def cols_step():
             for j in mine_j:
