@@ -552,6 +552,7 @@ def main():
     def ntt_spot_check(v, log_n):
         """output 0 of a forward transform is the plain sum of the inputs; the inverse brings the vector back"""
         c = v.clone()
+        torch.cuda.synchronize()                                # the copy runs on torch's stream, the transform on the library's
         ctx.ntt_device(c.data_ptr(), log_n)
         torch.cuda.synchronize()
         out0 = sum((int(x) & MASK64) << (64 * j) for j, x in enumerate(c[:4].tolist()))
