@@ -67,6 +67,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-seams", action="store_true")
+    ap.add_argument("--skip-group-legs", action="store_true", help="N > 1: do not run the two bp_init_multi legs (group_commit, one proof over all GPUs)")
+    ap.add_argument("--group-legs-timeout", type=int, default=240, help="seconds after which a bp_init_multi leg's child process is killed (its entry then says so)")
     ap.add_argument("--prove-log-n", type=int, default=20, help="gates of the synthetic circuit of the proofs/s leg = 2^prove_log_n (0 = skip)")
     ap.add_argument("--prove-reps", type=int, default=3)
     ap.add_argument("--prove-streams", type=int, default=2, help="concurrent provers per GPU in the proofs/s throughput figure")
@@ -680,14 +682,14 @@ def main():
             dist.barrier(group=ctl) if ctl is not None else dist.barrier()
 
     group_commit = None
-    if world > 1 and strong is not None:
+    if world > 1 and strong is not None and not args.skip_group_legs:
         torch.cuda.synchronize()
         host_barrier()
         if rank == 0:
             group_devs = list(range(world)) if args.backend == "nccl" else [dev_index] * world      # a gloo rehearsal lists its one card once per rank
             group_commit = run_group_legs({"devices": group_devs, "no_tables": bool(args.no_tables),
                                            "commit": {"total": strong["total"], "k": strong["k"], "log_n": args.strong_log_n,
-                                                      "expect": strong["r"]["result"].hex()}}, 420)["group_commit"]
+                                                      "expect": strong["r"]["result"].hex()}}, args.group_legs_timeout)["group_commit"]
         host_barrier()
 
     # ---------------------------------------------------------------- prover leg (BASELINE configs[4])
@@ -747,7 +749,7 @@ def main():
                  "setup_s": t_setup, "circuit_host_s": t_circuit_host, "streams": len(provers), "group": None, "host_witness_s": host_witness_s}
         # one proof on ONE context over all N GPUs (bp_init_multi): the nine commitments of prover.rs are sharded by point range,
         # everything else runs on GPU 0.  Rank 0 drives it; the other ranks have freed their memory and wait on the host.
-        if world > 1:
+        if world > 1 and not args.skip_group_legs:
             del provers, wit
             torch.cuda.empty_cache()
             dist.barrier(group=ctl)
@@ -755,7 +757,7 @@ def main():
                 group_devs = list(range(world)) if args.backend == "nccl" else [dev_index] * world
                 prove["group"] = run_group_legs({"devices": group_devs, "no_tables": bool(args.no_tables),
                                                  "prove": {"log_n": args.prove_log_n, "reps": args.prove_reps, "ntt_log_n": args.strong_log_n,
-                                                           "expect_sha256": hashlib.sha256(blob).hexdigest()}}, 420)["group_proof"]
+                                                           "expect_sha256": hashlib.sha256(blob).hexdigest()}}, args.group_legs_timeout)["group_proof"]
             dist.barrier(group=ctl)
 
     # ---------------------------------------------------------------- reduce over ranks, print the line
