@@ -389,14 +389,40 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     BP_HIP(ctx, hipMemcpyAsync(run_off[0], whole, sizeof whole, hipMemcpyHostToDevice, st));
     uint32_t* rlong_list;
     BP_TRY(ws_get(ctx, "msm.run_long", ((size_t)n_final + 2) * 4, (void**)&rlong_list));
+    // Level 1 of the two-level sort, two builds.  Straight from the scalars, as the partition sort does it (msm_part_count + msm_part_scatter
+    // with two-word records into 2^lv[0] runs: no record pass, one array's traffic less -- the default since round 4: 2^24 points, tail
+    // 5.87 -> 5.32 ms, profiles/r04_sort24_hybrid_ab.txt), or records first (msm_digit_records writes one (bucket, entry) pair per scalar and
+    // window, then msm_radix_count / _scatter partition them: a single level, NAF digits, or BP_MSM_SORT=1 in the experiment build).
+    uint32_t runs = 1, shift = kb, side = 0;
+    int first_level = 0;
+    const bool hybrid = sort_env != 1 && lv[0] && lv[1] && !plan.naf;
+    if (hybrid) {
+      const uint32_t pb1 = lv[0], rb1 = kb - pb1;
+      uint32_t slice = 64;
+      while (slice < 1024 && (uint64_t)2 * slice * W * 8 <= 65536 && (uint64_t)slice * 512 < (uint64_t)n) slice <<= 1;
+      const uint32_t cap = slice * W, n_slices = (uint32_t)(((uint64_t)n + slice - 1) / slice);
+      const unsigned threads = slice >= 1024 ? 1024u : (slice <= 256 ? 256u : slice);
+      uint32_t slice1 = slice;
+      while (slice1 < 8192 && (uint64_t)slice1 * 256 < (uint64_t)n) slice1 <<= 1;
+      const uint32_t n_slices1 = (uint32_t)(((uint64_t)n + slice1 - 1) / slice1);
+      hipLaunchKernelGGL(msm_part_count, dim3(n_slices1), dim3(slice1 >= 1024 ? 1024u : threads), 0, st, scalars_all, fmt, plan, slice1, pb1, rb1, ctl + 4, run_off[1], cur,
+                         long_count + 1);
+      const size_t part_lds = (size_t)3 * (1u << pb1) * 4 + (size_t)cap * 8;
+      hipLaunchKernelGGL((msm_part_scatter<false, false>), dim3(n_slices), dim3(threads), part_lds, st, scalars_all, fmt, plan, slice, pb1, rb1, 0u, cap, cur, keys[1],
+                         vals[1]);
+      runs = 1u << pb1;
+      shift = rb1;
+      side = 1;
+      first_level = 1;
+    } else {
 #ifdef BP_EXPERIMENT
     if (plan.naf)
       hipLaunchKernelGGL(msm_naf_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, keys[0], vals[0], long_count + 1);
     else
 #endif
       hipLaunchKernelGGL(msm_digit_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, keys[0], vals[0], long_count + 1);
-    uint32_t runs = 1, shift = kb, side = 0;
-    for (int level = 0; level < 2 && lv[level]; level++) {
+    }
+    for (int level = first_level; level < 2 && lv[level]; level++) {
       const uint32_t bits = lv[level], nd = 1u << bits, n_sub = runs * nd;
       shift -= bits;
       uint64_t per_run = max_entries / runs;
