@@ -322,6 +322,13 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     while (slice < 1024 && (uint64_t)2 * slice * W * rec_bytes <= 65536 && (uint64_t)slice * 512 < (uint64_t)n * J) slice <<= 1;
     slice = knob_u32("BP_MSM_PART_SLICE", slice, 64, 4096);
     if (slice < 64 || slice > 4096 || (uint64_t)slice * W * rec_bytes > 65536) slice = 64;
+    // Two-word records (2^21 .. 2^23 points at c = 20: bucket-low bits + sign + a 25..27-bit table index exceed one word): the 64-KiB rule leaves
+    // slices of 512 scalars, and a workgroup's fixed cost for its 2^12-entry tables (~12 us) then outweighs its records (~7 us).  A slice of
+    // 1 024 scalars stages 104 KiB; that fits beside the 48 KiB of tables when the per-record partition array of the flat write-out is dropped,
+    // i.e. with the partition-major write-out (BP_MSM_PART_WIDE8=0 keeps the 512-scalar slices).
+    const bool wide8 = !packed && slice == 512 && (uint64_t)1024 * 512 < (uint64_t)n * J && (size_t)3 * n_final * 4 + (size_t)1024 * W * 8 <= 156 * 1024 &&
+                       knob_u32("BP_MSM_PART_WIDE8", 1, 0, 1) != 0;
+    if (wide8) slice = 1024;
     const uint32_t cap = slice * W, n_slices = (uint32_t)(((uint64_t)n * J + slice - 1) / slice);
     const unsigned threads = slice >= 1024 ? 1024u : (slice <= 256 ? 256u : slice);
     uint32_t *recs = nullptr, *rvals = nullptr, *roff, *cur, *rlong_list;
@@ -339,7 +346,7 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     hipLaunchKernelGGL(msm_part_count, dim3(n_slices1), dim3(slice1 >= 1024 ? 1024u : threads), 0, st, scalars_all, fmt, plan, slice1, pb, rbits, ctl + 4, roff, cur, long_count + 1);
     // a slice's share of a partition: long -> partition-major write-out, short -> one lane per record (BP_MSM_PART_FLAT = 0 / 1 forces)
     const uint32_t flat_env = knob_u32("BP_MSM_PART_FLAT", 2, 0, 2);
-    const bool flat = flat_env == 2 ? (cap >> pb) < 8 : flat_env == 1;
+    const bool flat = wide8 ? false : (flat_env == 2 ? (cap >> pb) < 8 : flat_env == 1);
     const size_t part_lds = (size_t)3 * n_final * 4 + (size_t)cap * rec_bytes + (flat ? (size_t)cap * 2 : 0);
     const dim3 lgrid(64, n_final < 4 ? n_final : 4);
     // short final runs (2^12 runs of ~3 Ki records at c = 20): 512-lane workgroups (measured 70 / 60 / 72 us at 256 / 512 / 1024 lanes)
