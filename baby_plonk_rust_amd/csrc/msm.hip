@@ -307,9 +307,9 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   while ((idx_max >> (vb - 1)) != 0) vb++;                              // vb - 1 = bits of the largest entry, + 1 for the sign
   const uint32_t packed_env = knob_u32("BP_MSM_PACKED", 1, 0, 2);
   if (packed_env == 1 && kb + vb > 32 + pb && kb + vb - 32 <= PART_MAX_BITS && knob_u32("BP_MSM_RADIX_BITS", 99, 0, 16) == 99) pb = kb + vb - 32;
-  const uint32_t sort_env = knob_u32("BP_MSM_SORT", 2, 0, 2);
+  const uint32_t sort_env = knob_u32("BP_MSM_SORT", 2, 0, 3);      // 3: the two-level sort (first level from the scalars) at sizes where the partition sort is the default
   const bool hist_ok = plan.parts == 1 && !plan.naf && J == 1;
-  const int sort_mode = (EXPERIMENT_BUILD && sort_env == 0 && hist_ok) ? 0 : (((sort_env == 1 && J == 1) || pb > PART_MAX_BITS) ? 1 : 2);
+  const int sort_mode = (EXPERIMENT_BUILD && sort_env == 0 && hist_ok) ? 0 : ((((sort_env == 1 || sort_env == 3) && J == 1) || pb > PART_MAX_BITS) ? 1 : 2);
   if (sort_mode != 2 && J > 1) return fail(ctx, BP_ERR_TOO_LARGE, "MSM batch too long for the partition sort", hipSuccess, __FILE__, __LINE__);
   const uint32_t rbits = kb - pb, n_final = 1u << pb;
   const size_t rhist = ((size_t)1 << rbits) * 4;
