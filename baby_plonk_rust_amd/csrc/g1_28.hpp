@@ -199,6 +199,42 @@ BP_HD void g1_double28(g1_proj28& r, const g1_proj28& p) {
   r.z = widen28<C28>(norm28(zo));
 }
 
+// ---- canonical form and inversion in the 28-bit Montgomery domain (table builder: srs_window_tables) ---------------------------
+using M28 = F28<MASK28, 2>;                                         // a Montgomery product: limbs <= 2^28 - 1, value < 2p
+// value < 2p with limbs < 2^28 (a mul28 result)  ->  the unique representative in [0, p), limbs < 2^28
+BP_HD F28n canon28(const M28& a) {
+  uint32_t t[N28];
+  int32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < N28; i++) {
+    const int32_t d = (int32_t)a.l[i] - (int32_t)P28::mod(i) + borrow;      // |d| < 2^29
+    t[i] = (uint32_t)d & MASK28;
+    borrow = d >> 28;                                                       // 0 or -1
+  }
+  F28n r;
+#pragma unroll
+  for (int i = 0; i < N28; i++) r.l[i] = borrow < 0 ? a.l[i] : t[i];         // a < p: keep a; else a - p
+  return r;
+}
+// a^(p-2) (fp.rs:346-358): every lane runs the same exponent, so the multiply steps are wave-uniform branches.  0 -> 0.
+BP_HD M28 fp28_invert(const M28& a) {
+  M28 r;
+#pragma unroll
+  for (int i = 0; i < N28; i++) r.l[i] = One28::limb(i);
+  for (int w = 11; w >= 0; w--) {
+    const uint32_t e = FpParams::mod_minus_2(w);
+    for (int b = (w == 11 ? 28 : 31); b >= 0; b--) {
+      r = mul28(r, r);
+      if ((e >> b) & 1) r = mul28(r, a);
+    }
+  }
+  return r;
+}
+
+// inversion of the reference's Montgomery limbs (x 2^384) through the 28-bit domain: one conversion each way, the 381-bit power itself on
+// mul28 (~500 instructions per product against ~700 on saturated limbs).  0 -> 0.
+BP_HD void fp_invert_via28(fp_t& r, const fp_t& a) { r = fp_from_28(fp28_invert(widen28<M28>(fp_to_28(a)))); }
+
 // r = k * p for a small non-negative integer k (< 2^nbits), MSB-first double-and-add
 BP_HD void g1_mul_small28(g1_proj28& r, const g1_proj28& p, uint32_t k, int nbits) {
   g1_proj28 acc = g1_identity28();

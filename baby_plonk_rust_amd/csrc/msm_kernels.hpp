@@ -903,38 +903,50 @@ __global__ void __launch_bounds__(256) srs_to28(const g1_affine* __restrict__ in
 // Fixed-base window tables: table[w * n + i] = 2^(c w) * P_i for w < W, affine, unsaturated limbs.  One lane per point
 // walks its doubling chain; the affine normalisations of a group of TABLE_GROUP rows share one field inversion
 // (Montgomery's trick, as G1Projective::batch_normalize does, g1.rs:806-839).  Built once per SRS.
+// Round 4: the whole chain runs on the 14 x 28-bit limbs of the hot copy (g1_double28, mul28, fp28_invert) instead of the saturated
+// 12 x 32-bit form -- the kernel is nothing but field products, and a product is ~500 instructions there against ~700
+// (profiles/r04_table_build_ab.txt).  Rows are stored canonical (canon28), as srs_to28 stores the points themselves.
 constexpr int TABLE_GROUP = 16;
-__global__ void __launch_bounds__(256) srs_window_tables(const g1_affine* __restrict__ in, size_t n, uint32_t c, uint32_t W,
+__device__ __forceinline__ M28 one_m28() {
+  M28 r;
+#pragma unroll
+  for (int j = 0; j < N28; j++) r.l[j] = One28::limb(j);
+  return r;
+}
+__global__ void __launch_bounds__(256) srs_window_tables(const g1_affine28* __restrict__ in28, size_t n, uint32_t c, uint32_t W,
                                                          g1_affine28* __restrict__ table) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const g1_affine a = load_affine(&in[i]);
-  const bool inf = g1_affine_is_identity(a);           // stays the identity in every row; a point of prime order never doubles to it
-  g1_proj p = g1_from_affine(a);
-  g1_proj row[TABLE_GROUP];
-  fp_t prefix[TABLE_GROUP];                             // prefix[j] = z_0 z_1 ... z_j of the group
+  const g1_affine28 a = load_affine28(&in28[i]);
+  uint32_t nz = 0;
+#pragma unroll
+  for (int j = 0; j < N28; j++) nz |= a.x.l[j] | a.y.l[j];
+  const bool inf = nz == 0;                             // stays the identity in every row; a point of prime order never doubles to it
+  g1_proj28 p = g1_identity28();
+  if (!inf) {
+    p.x = widen28<C28>(a.x);
+    p.y = widen28<C28>(a.y);
+    p.z = widen28<C28>(one_m28());
+  }
+  g1_proj28 row[TABLE_GROUP];
+  M28 prefix[TABLE_GROUP];                              // prefix[j] = z_0 z_1 ... z_j of the group
+  const M28 one = one_m28();
   for (uint32_t w0 = 1; w0 < W; w0 += TABLE_GROUP) {
     const uint32_t cnt = W - w0 < (uint32_t)TABLE_GROUP ? W - w0 : (uint32_t)TABLE_GROUP;
     for (uint32_t j = 0; j < cnt; j++) {
-      for (uint32_t d = 0; d < c; d++) g1_double(p, p);
+      for (uint32_t d = 0; d < c; d++) g1_double28(p, p);
       row[j] = p;
-      if (j == 0) prefix[0] = p.z; else Fp::mul(prefix[j], prefix[j - 1], p.z);
+      prefix[j] = mul28(j == 0 ? one : prefix[j - 1], p.z);       // (the first product only brings z to the product's bounds)
     }
-    fp_t inv;
-    fp_invert(inv, prefix[cnt - 1]);                    // 0 -> 0 for the identity
+    M28 inv = fp28_invert(prefix[cnt - 1]);             // 0 -> 0 for the identity
     for (uint32_t j = cnt; j-- > 0;) {
-      fp_t zinv;
-      if (j) Fp::mul(zinv, inv, prefix[j - 1]); else zinv = inv;
-      Fp::mul(inv, inv, row[j].z);
-      g1_affine r;
-      Fp::mul(r.x, row[j].x, zinv);
-      Fp::mul(r.y, row[j].y, zinv);
-      if (inf) { r.x = Fp::zero(); r.y = Fp::zero(); }
-      const g1_affine28 r28 = g1_affine_to_28(r);
+      const M28 zinv = mul28(inv, j ? prefix[j - 1] : one);
+      inv = mul28(inv, row[j].z);
+      F28n x = canon28(mul28(row[j].x, zinv)), y = canon28(mul28(row[j].y, zinv));
       uint4* q = reinterpret_cast<uint4*>(&table[(size_t)(w0 + j) * n + i]);
       uint32_t wd[28];
 #pragma unroll
-      for (int t = 0; t < N28; t++) { wd[t] = r28.x.l[t]; wd[N28 + t] = r28.y.l[t]; }
+      for (int t = 0; t < N28; t++) { wd[t] = inf ? 0u : x.l[t]; wd[N28 + t] = inf ? 0u : y.l[t]; }
 #pragma unroll
       for (int t = 0; t < 7; t++) q[t] = make_uint4(wd[4 * t], wd[4 * t + 1], wd[4 * t + 2], wd[4 * t + 3]);
     }

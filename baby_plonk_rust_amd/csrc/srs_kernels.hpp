@@ -5,6 +5,7 @@
 //                    s_i = a + i*d (synthetic benchmark points)
 #pragma once
 #include "g1.hpp"
+#include "g1_28.hpp"
 
 namespace bp {
 
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(256) srs_from_projective(const g1_proj* __rest
     out[i].x = run;
   }
   fp_t inv;
-  fp_invert(inv, run);
+  fp_invert_via28(inv, run);
   for (uint32_t j = cnt; j-- > 0;) {
     const size_t i = lane + (size_t)j * lanes;
     const g1_proj p = in[i];
