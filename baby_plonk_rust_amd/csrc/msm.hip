@@ -220,7 +220,9 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     return fail(ctx, BP_ERR_INVALID_ARG, "MSM batch", hipSuccess, __FILE__, __LINE__);
   size_t n = 0;
   for (uint32_t j = 0; j < J; j++) n = n_each[j] > n ? n_each[j] : n;
-  const fr_t* d_scalars = d_scalars_each[0];
+#ifdef BP_EXPERIMENT
+  const fr_t* d_scalars = d_scalars_each[0];           // the records-first passes (experiment builds) take a single vector
+#endif
   out->J = J;
   if (n == 0) {
     if (d_blob) {
@@ -426,8 +428,10 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     if (plan.naf)
       hipLaunchKernelGGL(msm_naf_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, keys[0], vals[0], long_count + 1);
     else
-#endif
       hipLaunchKernelGGL(msm_digit_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, fmt, plan, keys[0], vals[0], long_count + 1);
+#else
+    return fail(ctx, BP_ERR_INVALID_ARG, "records-first sort is an experiment build", hipSuccess, __FILE__, __LINE__);      // unreachable: two levels always take level 1 from the scalars
+#endif
     }
     for (int level = first_level; level < 2 && lv[level]; level++) {
       const uint32_t bits = lv[level], nd = 1u << bits, n_sub = runs * nd;

@@ -281,6 +281,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32
 // One or two partition levels of <= 8 bits each; the record arrays ping-pong.
 constexpr uint32_t RADIX_SLICE = 8192, RADIX_PER_LANE = RADIX_SLICE / 1024, RADIX_MAX_DIGITS = 256, RADIX_EMPTY = 0xffffffffu;
 
+#ifdef BP_EXPERIMENT      // records-first level 1 of the two-level sort (BP_MSM_SORT=1; NAF digits): the shipped build takes level 1 from the scalars
 __global__ void __launch_bounds__(256) msm_digit_records(const fr_t* __restrict__ scalars, int fmt, MsmPlan plan, uint32_t* __restrict__ keys,
                                                           uint32_t* __restrict__ vals, uint32_t* __restrict__ status) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -312,6 +313,7 @@ __global__ void __launch_bounds__(256) msm_digit_records(const fr_t* __restrict_
   }
 }
 
+#endif  // BP_EXPERIMENT
 #ifdef BP_EXPERIMENT      // every-position tables with NAF digits (bp_srs_precompute(h, 256 + w))
 // Width-w NAF records of every scalar (plan.naf = w): slot s of scalar i at [s * n + i].  With E = (k >> pos) + carry:
 // E even -> next position; E odd -> e = E mod 2^w, digit d = e (carry 0) or e - 2^w (carry 1) when e >= 2^(w-1), pos += w.
