@@ -134,28 +134,98 @@ __global__ void __launch_bounds__(256) srs_from_projective(const g1_proj* __rest
   }
 }
 
-// mode 0: s_i = a^i (a = tau, Montgomery);  mode 1: s_i = a + i*d (Montgomery).  P_i = s_i * G, affine.
-// out[j] = P_{first + j}, j < n: a multi-GPU shard generates its own point range.
-__global__ void __launch_bounds__(256, 2) srs_generate(fr_t a, fr_t d, int mode, size_t first, size_t n, g1_affine* __restrict__ out) {
-  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const size_t i = first + j;
-  fr_t s;
-  if (mode == 0) {
-    uint32_t e[2] = {(uint32_t)i, (uint32_t)(i >> 32)};
-    Fr::pow(s, a, e, 2);
-  } else {
-    fr_t idx = Fr::zero(), t;
-    idx.l[0] = (uint32_t)i;
-    idx.l[1] = (uint32_t)(i >> 32);
-    Fr::to_mont(idx, idx);
-    Fr::mul(t, idx, d);
-    Fr::add(s, a, t);
+// ---- fixed-base generation (round 4) --------------------------------------------------------------------------------------------
+// P = s G as 32 mixed additions from a table of the generator's multiples,  gen_table[j * 255 + (d - 1)] = d 2^(8 j) G  (j < 32, d = 1 .. 255;
+// 28-bit affine slots, 1 MiB, built once per context by srs_gen_table), instead of 255 doublings + ~128 additions on saturated limbs per point;
+// a lane makes SRS_GEN_GROUP consecutive points and normalises them with ONE inversion (Montgomery's trick, on the same 28-bit limbs).
+// Same points as srs_generate (the unique affine representatives), 82 -> see profiles/r04_table_build_ab.txt.
+constexpr uint32_t GEN_WINDOWS = 32, GEN_DIGITS = 255, SRS_GEN_GROUP = 8;
+__device__ __forceinline__ void store_affine28_slot(g1_affine28* __restrict__ dst, const F28n& x, const F28n& y) {
+  uint32_t w[28];
+#pragma unroll
+  for (int j = 0; j < N28; j++) { w[j] = x.l[j]; w[N28 + j] = y.l[j]; }
+  uint4* q = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+  for (int j = 0; j < 7; j++) q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+}
+__device__ __forceinline__ g1_affine28 load_affine28_slot(const g1_affine28* __restrict__ p) {
+  g1_affine28 r;
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint32_t w[28];
+#pragma unroll
+  for (int j = 0; j < 7; j++) { const uint4 v = q[j]; w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w; }
+#pragma unroll
+  for (int j = 0; j < N28; j++) { r.x.l[j] = w[j]; r.y.l[j] = w[N28 + j]; }
+  return r;
+}
+__global__ void __launch_bounds__(256) srs_gen_table(g1_affine28* __restrict__ table) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= GEN_WINDOWS * GEN_DIGITS) return;
+  const uint32_t j = t / GEN_DIGITS, d = t % GEN_DIGITS + 1;
+  fr_t s = Fr::zero();
+  s.l[j >> 2] = d << (8 * (j & 3));                            // the integer d 2^(8 j)
+  g1_proj r;
+  g1_mul_scalar(r, g1_from_affine(g1_affine_generator()), s);
+  const g1_affine28 a = g1_affine_to_28(g1_to_affine(r));
+  store_affine28_slot(&table[t], a.x, a.y);
+}
+// mode 0: s_i = a^i (a = tau, Montgomery);  mode 1: s_i = a + i*d (Montgomery).  out[j] = s_{first + j} G, j < n.
+__global__ void __launch_bounds__(256, 2) srs_generate_fb(fr_t a, fr_t d, int mode, size_t first, size_t n, const g1_affine28* __restrict__ gen_table,
+                                                          g1_affine* __restrict__ out) {
+  const size_t base = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * SRS_GEN_GROUP;
+  if (base >= n) return;
+  const uint32_t cnt = n - base < SRS_GEN_GROUP ? (uint32_t)(n - base) : SRS_GEN_GROUP;
+  g1_proj28 pts[SRS_GEN_GROUP];
+  M28 prefix[SRS_GEN_GROUP];
+  M28 one;
+#pragma unroll
+  for (int j = 0; j < N28; j++) one.l[j] = One28::limb(j);
+  for (uint32_t k = 0; k < cnt; k++) {
+    const size_t i = first + base + k;
+    fr_t s;
+    if (mode == 0) {
+      uint32_t e[2] = {(uint32_t)i, (uint32_t)(i >> 32)};
+      Fr::pow(s, a, e, 2);
+    } else {
+      fr_t idx = Fr::zero(), t;
+      idx.l[0] = (uint32_t)i;
+      idx.l[1] = (uint32_t)(i >> 32);
+      Fr::to_mont(idx, idx);
+      Fr::mul(t, idx, d);
+      Fr::add(s, a, t);
+    }
+    Fr::from_mont(s, s);
+    g1_proj28 acc = g1_identity28();
+    for (uint32_t j = 0; j < GEN_WINDOWS; j++) {
+      const uint32_t dg = (s.l[j >> 2] >> (8 * (j & 3))) & 255u;
+      if (dg) {
+        const g1_affine28 q = load_affine28_slot(&gen_table[j * GEN_DIGITS + dg - 1]);
+        g1_add_mixed28(acc, q.x, widen28<PtY28>(q.y));
+      }
+    }
+    pts[k] = acc;
+    uint32_t zz = 0;
+#pragma unroll
+    for (int j = 0; j < N28; j++) zz |= acc.z.l[j];              // s = 0: the accumulator is still (0 : 1 : 0) as written
+    prefix[k] = zz ? mul28(k ? prefix[k - 1] : one, acc.z) : (k ? prefix[k - 1] : one);
   }
-  Fr::from_mont(s, s);
-  g1_proj g = g1_from_affine(g1_affine_generator()), r;
-  g1_mul_scalar(r, g, s);
-  out[j] = g1_to_affine(r);
+  M28 inv = fp28_invert(prefix[cnt - 1]);
+  for (uint32_t k = cnt; k-- > 0;) {
+    uint32_t zz = 0;
+#pragma unroll
+    for (int j = 0; j < N28; j++) zz |= pts[k].z.l[j];
+    g1_affine r;
+    if (zz) {
+      const M28 zinv = mul28(inv, k ? prefix[k - 1] : one);
+      inv = mul28(inv, pts[k].z);
+      r.x = fp_from_28(mul28(pts[k].x, zinv));
+      r.y = fp_from_28(mul28(pts[k].y, zinv));
+    } else {
+      r.x = Fp::zero();
+      r.y = Fp::zero();
+    }
+    out[base + k] = r;
+  }
 }
 
 }  // namespace bp
