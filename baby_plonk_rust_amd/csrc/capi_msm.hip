@@ -256,6 +256,7 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
   for (size_t r = 0; r < sh.size(); r++) BP_TRY(lift(ctx, sh[r], srs_precompute_one(sh[r], hs.empty() ? srs_handle : hs[r], BP_SRS_TABLES_OFF)));
   if (c == BP_SRS_TABLES_OFF) return BP_OK;
   auto fits = [&](uint32_t cc, size_t* need_out, size_t* free_out) -> int {
+    std::map<int, size_t> per_device;                    // shards that share a device (a rehearsal group) share its free memory
     for (size_t r = 0; r < sh.size(); r++) {
       SrsEntry* e;
       BP_TRY(lift(ctx, sh[r], srs_find(sh[r], hs.empty() ? srs_handle : hs[r], &e)));
@@ -263,7 +264,8 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
       size_t free_b = 0, total_b = 0;
       BP_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
       const size_t rows = srs_table_rows(cc);
-      const size_t need = rows * e->n * (sizeof(g1_affine28) + 24) + ((size_t)256 << 20);      // + sort records, lists, partial slots of one MSM
+      size_t& need = per_device[sh[r]->device];
+      need += rows * e->n * (sizeof(g1_affine28) + 24) + ((size_t)256 << 20);      // + sort records, lists, partial slots of one MSM
       if (need > free_b) {
         *need_out = need;
         *free_out = free_b;
