@@ -216,3 +216,18 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.bp_srs_load_projective144(None, None, 0, None) == -1
     assert lib.bp_msm_g1_projective144(None, None, 0, None, 0, 1, None) == -1
     assert lib.bp_srs_export_projective144(None, 1, 0, 0, None) == -1
+
+
+def test_shipped_library_reads_no_environment():
+    """the shipped library imports no getenv at all (every experiment knob is compiled out); the experiment
+    build of the same sources does -- it is the only one that can read BP_* variables"""
+    import subprocess
+    here = os.path.join(ROOT, "baby_plonk_rust_amd")
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(here, "libbp_msm_ntt.so")], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    exp = os.path.join(here, "libbp_msm_ntt_exp.so")
+    if os.path.exists(exp):
+        assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", exp], capture_output=True, text=True, check=True).stdout
+    lib = bp.load()
+    lib.bp_version.restype = __import__("ctypes").c_char_p
+    assert (b"+experiment" in lib.bp_version()) == _lib.EXPERIMENT
