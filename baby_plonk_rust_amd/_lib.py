@@ -15,17 +15,30 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # shipped library reads no environment at all, so the choice is made here, on the Python side of the boundary.
 # (a value ending in .so names a library file directly: A/B runs of two builds of the shipped library on one box)
 _choice = os.environ.get("BABY_PLONK_LIBRARY", "")
-EXPERIMENT = _choice == "exp"
-SO_PATH = _choice if _choice.endswith(".so") else os.path.join(_HERE, "libbp_msm_ntt_exp.so" if EXPERIMENT else "libbp_msm_ntt.so")
+SO_PATH = _choice if _choice.endswith(".so") else os.path.join(_HERE, "libbp_msm_ntt_exp.so" if _choice == "exp" else "libbp_msm_ntt.so")
+
+
+def _is_experiment_build():
+    """what the library itself says (bp_version() ends in "+experiment" for -DBP_EXPERIMENT builds), so that a library named by path
+    is classified by its contents, not by the spelling of the environment value; bp_version needs no GPU"""
+    if not os.path.exists(SO_PATH):
+        return _choice == "exp"
+    fn = C.CDLL(SO_PATH).bp_version
+    fn.restype = C.c_char_p
+    return b"+experiment" in fn()
+
+
+EXPERIMENT = _is_experiment_build()
 
 BP_OK = 0
 ERRORS = {
     -1: "BP_ERR_INVALID_ARG", -2: "BP_ERR_NOT_POW2", -3: "BP_ERR_BAD_POINT", -4: "BP_ERR_BAD_SCALAR",
     -5: "BP_ERR_BASIS", -6: "BP_ERR_LENGTH", -7: "BP_ERR_DIV_ZERO", -8: "BP_ERR_NO_DEVICE", -9: "BP_ERR_HIP",
-    -10: "BP_ERR_TOO_LARGE", -11: "BP_ERR_ASSERT",
+    -10: "BP_ERR_TOO_LARGE", -11: "BP_ERR_ASSERT", -12: "BP_ERR_COMM",
 }
 FR_BYTES_LE, FR_MONT = 0, 1
 MSM_BLOB_BYTES = 22592          # BP_MSM_BLOB_BYTES
+COMM_ID_BYTES = 128             # BP_COMM_ID_BYTES (RCCL's ncclUniqueId)
 BASIS_LAGRANGE, BASIS_MONOMIAL = 0, 1
 
 _vp, _sz, _u64, _u32, _int, _cp = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int, C.c_char_p
@@ -68,6 +81,13 @@ SIGNATURES = {
     "bp_msm_blobs_sum_device_async": (_int, [_vp, _vp, _sz, _vp]),
     "bp_msm_blobs_sum_device": (_int, [_vp, _vp, _sz, _vp]),
     "bp_msm_blobs_combine": (_int, [_vp, _sz, _vp]),
+    "bp_comm_unique_id": (_int, [_vp]),
+    "bp_comm_init_rank": (_int, [_vp, _vp, _int, _int]),
+    "bp_comm_info": (_int, [_vp, _pp(_int), _pp(_int)]),
+    "bp_comm_destroy": (_int, [_vp]),
+    "bp_msm_g1_allgather": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),
+    "bp_comm_last_exchange_ms": (_int, [_vp, _pp(C.c_float)]),
+    "bp_ntt_columns_allgather": (_int, [_vp, _vp, _u32, _sz]),
     "bp_g1_sum_partials": (_int, [_vp, _sz, _vp]),
     "bp_g1_partial_to_bytes96": (_int, [_vp, _vp]),
     "bp_g1_bytes96_to_partial": (_int, [_vp, _vp]),

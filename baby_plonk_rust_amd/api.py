@@ -158,7 +158,8 @@ class Context:
 
     def srs_precompute(self, handle, window_bits=0):
         """fixed-base window tables T[w][i] = 2^(c w) P_i for an SRS that serves many MSMs (0 = auto width,
-        SRS_TABLES_OFF drops them; 256 + w = tables of every bit position for width-w NAF digits)"""
+        SRS_TABLES_OFF drops them; 256 + w = tables of every bit position for width-w NAF digits: experiment build only,
+        the shipped library raises BpError(BP_ERR_INVALID_ARG) for it)"""
         self.check(self._lib.bp_srs_precompute(self._h, handle, window_bits), "bp_srs_precompute")
         return self.srs_table_info(handle)
 
@@ -201,6 +202,49 @@ class Context:
         """gathered records of equal layout -> one record, added slot by slot on the GPU (see bp_msm_blobs_sum_device)"""
         fn = self._lib.bp_msm_blobs_sum_device if wait else self._lib.bp_msm_blobs_sum_device_async
         self.check(fn(self._h, d_blobs_ptr, n_blobs, d_out_ptr), "bp_msm_blobs_sum_device")
+
+    # ---- one process per GPU: the collective under the C ABI (capi_comm.hip) ----
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: the 128-byte id every rank passes to comm_init_rank (ncclGetUniqueId); the host carries it between the ranks"""
+        out = np.zeros(_lib.COMM_ID_BYTES, dtype=np.uint8)
+        rc = _lib.load().bp_comm_unique_id(out.ctypes.data)
+        if rc != 0:
+            raise BpError(rc, "bp_comm_unique_id")
+        return bytes(out)
+
+    def comm_init_rank(self, comm_id, rank, world):
+        buf = np.frombuffer(bytes(comm_id), dtype=np.uint8).copy()
+        assert len(buf) == _lib.COMM_ID_BYTES
+        self.check(self._lib.bp_comm_init_rank(self._h, buf.ctypes.data, rank, world), "bp_comm_init_rank")
+
+    def comm_info(self):
+        r, w = C.c_int(), C.c_int()
+        self.check(self._lib.bp_comm_info(self._h, C.byref(r), C.byref(w)), "bp_comm_info")
+        return r.value, w.value
+
+    def comm_destroy(self):
+        self.check(self._lib.bp_comm_destroy(self._h), "bp_comm_destroy")
+
+    def msm_allgather(self, handle, scalars=None, first=0, fmt=FR_MONT, device_ptr=None, n=None):
+        """sum over ALL ranks' (point, scalar) pairs (bp_msm_g1_allgather): record -> ONE ncclAllGather -> device pre-sum -> one D2H"""
+        out = np.zeros(96, dtype=np.uint8)
+        if device_ptr is not None:
+            rc = self._lib.bp_msm_g1_allgather(self._h, handle, first, device_ptr, n, fmt, 1, out.ctypes.data)
+        else:
+            s = _fr_array(scalars) if fmt == FR_MONT else np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+            rc = self._lib.bp_msm_g1_allgather(self._h, handle, first, s.ctypes.data, len(s), fmt, 0, out.ctypes.data)
+        self.check(rc, "bp_msm_g1_allgather")
+        return bytes(out)
+
+    def comm_last_exchange_ms(self):
+        ms = C.c_float()
+        self.check(self._lib.bp_comm_last_exchange_ms(self._h, C.byref(ms)), "bp_comm_last_exchange_ms")
+        return ms.value
+
+    def ntt_columns_allgather(self, d_columns_ptr, log_n, columns_per_rank):
+        """world x columns_per_rank columns of 2^log_n elements in HBM, this rank's block filled: ONE in-place ncclAllGather"""
+        self.check(self._lib.bp_ntt_columns_allgather(self._h, d_columns_ptr, log_n, columns_per_rank), "bp_ntt_columns_allgather")
 
     def msm_stats(self):
         a, t, adds, c = C.c_float(), C.c_float(), C.c_uint64(), C.c_uint32()

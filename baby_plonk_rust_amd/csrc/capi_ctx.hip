@@ -288,7 +288,18 @@ int ctx_create(bp_ctx** out, int device_id) {
   if (hipGetDevice(&cur) != hipSuccess || cur != device_id) return BP_ERR_NO_DEVICE;
   bp_ctx* ctx = new bp_ctx();
   ctx->device = device_id;
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+  hipError_t se;
+  if (knob_u32("BP_ACC_LOW_PRIORITY", 0, 0, 1)) {         // experiment: tails on high-priority streams, accumulations on low-priority ones
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least urgent (numerically greatest), hi = most urgent
+    se = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi);
+    if (se == hipSuccess) se = hipStreamCreateWithPriority(&ctx->acc_stream, hipStreamNonBlocking, lo);
+    for (auto& e : ctx->acc_ev)
+      if (se == hipSuccess) se = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  } else {
+    se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  }
+  if (se != hipSuccess) {
     delete ctx;
     return BP_ERR_NO_DEVICE;
   }
@@ -415,6 +426,8 @@ void bp_destroy(bp_ctx* ctx) {
     }
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)stream_wait(ctx->stream);
+  comm_release(ctx);
+  if (ctx->comm_host) (void)hipHostFree(ctx->comm_host);
   for (auto& kv : ctx->ws)
     if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->srs) {
@@ -436,6 +449,9 @@ void bp_destroy(bp_ctx* ctx) {
     if (t) (void)hipFree(t);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->acc_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->acc_stream) (void)hipStreamDestroy(ctx->acc_stream);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -249,14 +249,18 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
   const std::vector<uint64_t> hs = lead->member_handle;
   // Memory budget: the tables (rows x points x 128 B: 25.8 GB per GPU at 2^24 points) must fit beside whatever else lives on the
   // device -- a second prover context, the caller's tensors -- together with the workspaces the first MSM against them allocates.
-  // The old tables go first (their memory counts as free).  An automatic width that does not fit falls back to wider windows
-  // (fewer rows: 22 -> 12, 24 -> 11) and then to NO tables (the MSM runs on the raw points, same bytes out: bp_srs_table_info
-  // reports what was built); an explicit width that does not fit is an error that says how much is missing, not an
-  // out-of-memory failure halfway through the build.
-  for (size_t r = 0; r < sh.size(); r++) BP_TRY(lift(ctx, sh[r], srs_precompute_one(sh[r], hs.empty() ? srs_handle : hs[r], BP_SRS_TABLES_OFF)));
-  if (c == BP_SRS_TABLES_OFF) return BP_OK;
+  // The check comes BEFORE anything is released or allocated, and counts the bytes of the tables this SRS holds now as free (they
+  // go once the new width is accepted): a refused explicit width therefore leaves the SRS exactly as it was, old tables included.
+  // An automatic width that does not fit falls back to wider windows (fewer rows: 22 -> 12, 24 -> 11) -- but only to a width MSMs over
+  // this SRS would use (8 n >= 2^c, the rule of msm_shard_launch: a 2^18-point SRS never builds 24-bit tables no MSM would touch) --
+  // and then to NO tables (the MSM runs on the raw points, same bytes out: bp_srs_table_info reports what was built); an explicit
+  // width that does not fit is an error that says how much is missing, not an out-of-memory failure halfway through the build.
+  if (c == BP_SRS_TABLES_OFF) {
+    for (size_t r = 0; r < sh.size(); r++) BP_TRY(lift(ctx, sh[r], srs_precompute_one(sh[r], hs.empty() ? srs_handle : hs[r], BP_SRS_TABLES_OFF)));
+    return BP_OK;
+  }
   auto fits = [&](uint32_t cc, size_t* need_out, size_t* free_out) -> int {
-    std::map<int, size_t> per_device;                    // shards that share a device (a rehearsal group) share its free memory
+    std::map<int, size_t> per_device, held;              // shards that share a device (a rehearsal group) share its free memory
     for (size_t r = 0; r < sh.size(); r++) {
       SrsEntry* e;
       BP_TRY(lift(ctx, sh[r], srs_find(sh[r], hs.empty() ? srs_handle : hs[r], &e)));
@@ -265,10 +269,12 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
       BP_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
       const size_t rows = srs_table_rows(cc);
       size_t& need = per_device[sh[r]->device];
+      size_t& old_bytes = held[sh[r]->device];
+      if (e->d_table) old_bytes += (size_t)e->table_W * std::max<size_t>(e->n, 1) * sizeof(g1_affine28);
       need += rows * e->n * (sizeof(g1_affine28) + 24) + ((size_t)256 << 20);      // + sort records, lists, partial slots of one MSM
-      if (need > free_b) {
+      if (need > free_b + old_bytes) {
         *need_out = need;
-        *free_out = free_b;
+        *free_out = free_b + old_bytes;
         return 1;
       }
     }
@@ -285,14 +291,16 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
     }
     uint32_t pick = BP_SRS_TABLES_OFF;
     for (uint32_t cc : {22u, 24u}) {
-      if (cc <= c) continue;
+      if (cc <= c || 8 * (uint64_t)lead->n < (1ull << cc)) continue;
       rc = fits(cc, &need, &free_b);
       if (rc < 0) return rc;
       if (rc == 0) { pick = cc; break; }
     }
     c = pick;
-    if (c == BP_SRS_TABLES_OFF) return BP_OK;
   }
+  // accepted (or nothing fits: the SRS ends up without tables): only now do the old tables go
+  for (size_t r = 0; r < sh.size(); r++) BP_TRY(lift(ctx, sh[r], srs_precompute_one(sh[r], hs.empty() ? srs_handle : hs[r], BP_SRS_TABLES_OFF)));
+  if (c == BP_SRS_TABLES_OFF) return BP_OK;
   for (size_t r = 0; r < sh.size(); r++) BP_TRY(lift(ctx, sh[r], srs_precompute_one(sh[r], hs.empty() ? srs_handle : hs[r], c)));
   return BP_OK;
 }

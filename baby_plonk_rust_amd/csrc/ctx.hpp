@@ -129,6 +129,11 @@ struct bp_ctx {
   hipEvent_t seam_ev[4] = {nullptr, nullptr, nullptr, nullptr};      // bp_msm_g1_projective144: piece k uploaded and normalised (recorded on the side stream)
   hipStream_t stream = nullptr;
   bool own_stream = true;
+  // experiment (BP_ACC_LOW_PRIORITY=1): msm_accumulate runs on a lowest-priority stream of its own, chained to `stream` by
+  // events, while `stream` is created at the highest priority -- so that sort / fix-up / tree kernels of OTHER pipelines take the
+  // workgroup slots a retiring accumulation generation frees.  Measured: profiles/r05_accumulate_generations_ab.txt.
+  hipStream_t acc_stream = nullptr;
+  hipEvent_t acc_ev[2] = {nullptr, nullptr};
   std::string last_error;
   std::map<std::string, bp::DevBuf> ws;            // grow-only named device workspaces
   std::map<uint64_t, bp::SrsEntry> srs;
@@ -151,6 +156,15 @@ struct bp_ctx {
   bool ntt_async_pending = false;  // bp_ntt_fr_device_async enqueued a transform whose events have not been read yet
   uint32_t ntt_passes = 0;
   uint32_t ntt_members = 1;       // members of a group context that took part in the last host transform
+  // one process per GPU (capi_comm.hip): the RCCL communicator of this context (ncclComm_t), created by bp_comm_init_rank
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 0;
+  hipEvent_t comm_ev[2] = {nullptr, nullptr};      // record complete / gathered, summed and copied
+  void* comm_host = nullptr;                       // pinned landing area of bp_msm_g1_allgather's device-to-host copy
+  size_t comm_host_cap = 0;
+  float comm_exchange_ms = 0;
+  bool gen_table_ready = false;                    // srs_generate_run: the generator's multiples were built into gen_table_ptr
+  const void* gen_table_ptr = nullptr;
   void* pinned = nullptr;                          // small pinned staging buffer (window sums etc.)
   size_t pinned_cap = 0;
 };
@@ -161,20 +175,27 @@ int fail(bp_ctx* ctx, int code, const char* what, hipError_t e, const char* file
 
 // Every entry point that takes a ctx runs under one of these: the calling thread's current device is restored on return
 // (torch shares this HIP runtime; a library call must not leave the thread on another GPU).
-// It also drops the thread's pending HIP error first: hipGetLastError() after a launch reports the LAST error of the calling
-// thread, whoever caused it -- the embedding process (torch, RCCL, the Rust host's own HIP calls) or a previous context's
-// teardown (gpurun_out/r3_t37.log: "invalid device ordinal" surfacing in the next bp_init) -- and an innocent bp_* call must
-// not return it as BP_ERR_HIP.  The post-launch checks keep their meaning: what they see was raised inside this call.
+// The OUTERMOST guard of a thread -- the one an extern "C" entry point (or a member's worker task) opens -- also drops the thread's
+// pending HIP error first: hipGetLastError() after a launch reports the LAST error of the calling thread, whoever caused it -- the
+// embedding process (torch, RCCL, the Rust host's own HIP calls) or a previous context's teardown (gpurun_out/r3_t37.log: "invalid
+// device ordinal" surfacing in the next bp_init) -- and an innocent bp_* call must not return it as BP_ERR_HIP.  Guards nested inside a
+// call (helpers, teardown loops, the memory-budget probe) have no such side effect: a launch error raised earlier in the SAME call is
+// still there for the post-launch hipGetLastError() that follows it.
+inline int& device_guard_depth() {
+  static thread_local int depth = 0;
+  return depth;
+}
 struct DeviceGuard {
   int prev = -1;
   explicit DeviceGuard(int device) {
-    (void)hipGetLastError();
+    if (device_guard_depth()++ == 0) (void)hipGetLastError();
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device) (void)hipSetDevice(device);
   }
   ~DeviceGuard() {
     int cur = -1;
     if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    device_guard_depth()--;
   }
   DeviceGuard(const DeviceGuard&) = delete;
   DeviceGuard& operator=(const DeviceGuard&) = delete;
@@ -201,7 +222,7 @@ inline bool peer_path(const bp_ctx* m, int other_device) {
 
 // Wait for a stream.  A thread blocked in hipStreamSynchronize wakes up tens of microseconds after the GPU has finished; the
 // calls of this library are a few milliseconds long and wait several times each (nine commitments and ~30 small results per
-// proof), so the wait polls hipStreamQuery for the first few milliseconds and only then blocks.  BP_WAIT_BLOCK=1: always block.
+// proof), so the wait polls hipStreamQuery for the first few milliseconds and only then blocks (experiment build: BP_WAIT_BLOCK=1 blocks at once).
 hipError_t stream_wait(hipStream_t st);
 
 // device workspace `name` of at least `bytes` (contents undefined after growth)
@@ -268,6 +289,7 @@ int srs_encode_run(bp_ctx* ctx, const g1_affine* d_in, size_t n, uint8_t* d_byte
 int srs_from_projective_run(bp_ctx* ctx, const g1_proj* d_in, size_t n, g1_affine* d_out);
 int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t first, size_t n, g1_affine* d_out);
 
+void comm_release(bp_ctx* ctx);                   // capi_comm.hip: destroys the context's communicator, if any
 int side_ctx_get(bp_ctx* ctx, bp_ctx** out);       // creates ctx->side and its events on first use (capi_ctx.hip)
 int circuit_build(bp_ctx* ctx, uint32_t log_n, fr_t* d_lag, CircuitEntry* out);
 int circuit_split_build(bp_ctx* ctx, CircuitEntry& e);      // leader of a group: the members' coset shares (prover.hip)

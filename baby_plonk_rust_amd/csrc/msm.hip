@@ -481,10 +481,20 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   }
   BP_HIP(ctx, hipEventRecord(ctx->ev[1], st));
   const dim3 acc_grid((unsigned)((n_chunks + 255) / 256));
+  hipStream_t ast = st;
+  if (ctx->acc_stream) {                  // experiment (BP_ACC_LOW_PRIORITY): the accumulation on its low-priority stream, chained by events
+    ast = ctx->acc_stream;
+    BP_HIP(ctx, hipEventRecord(ctx->acc_ev[0], st));
+    BP_HIP(ctx, hipStreamWaitEvent(ast, ctx->acc_ev[0], 0));
+  }
   switch (knob_u32("BP_MSM_ACC_WAVES", 2, 2, 4)) {
-    case 3: hipLaunchKernelGGL(msm_accumulate<3>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial); break;
-    case 4: hipLaunchKernelGGL(msm_accumulate<4>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial); break;
-    default: hipLaunchKernelGGL(msm_accumulate<2>, acc_grid, dim3(256), 0, st, d_points28, sorted, offsets, plan, bucket_sum, partial);
+    case 3: hipLaunchKernelGGL(msm_accumulate<3>, acc_grid, dim3(256), 0, ast, d_points28, sorted, offsets, plan, bucket_sum, partial); break;
+    case 4: hipLaunchKernelGGL(msm_accumulate<4>, acc_grid, dim3(256), 0, ast, d_points28, sorted, offsets, plan, bucket_sum, partial); break;
+    default: hipLaunchKernelGGL(msm_accumulate<2>, acc_grid, dim3(256), 0, ast, d_points28, sorted, offsets, plan, bucket_sum, partial);
+  }
+  if (ctx->acc_stream) {
+    BP_HIP(ctx, hipEventRecord(ctx->acc_ev[1], ast));
+    BP_HIP(ctx, hipStreamWaitEvent(st, ctx->acc_ev[1], 0));
   }
   BP_HIP(ctx, hipEventRecord(ctx->ev[2], st));
   // fix-up of the buckets cut by chunk edges.  Long buckets (tables at c <= 17: every one of the 2^15 buckets spans several chunks):

@@ -46,12 +46,15 @@ int srs_from_projective_run(bp_ctx* ctx, const g1_proj* d_in, size_t n, g1_affin
 int srs_generate_run(bp_ctx* ctx, const fr_t& a, const fr_t& d, int mode, size_t first, size_t n, g1_affine* d_out) {
   if (n == 0) return BP_OK;
   // the table of the generator's multiples (1 MiB) lives in a workspace of the context: built by the first call, in stream order
-  const bool have_table = ctx->ws.count("srs.gen_table") != 0;
+  // (ctx->gen_table_ready: set only after the table kernel was accepted by the runtime -- the workspace map gains its entry before
+  // the allocation, so the map alone would call a table "there" after a failed first call)
   g1_affine28* table;
   BP_TRY(ws_get(ctx, "srs.gen_table", (size_t)GEN_WINDOWS * GEN_DIGITS * sizeof(g1_affine28), (void**)&table));
-  if (!have_table) {
+  if (!ctx->gen_table_ready || ctx->gen_table_ptr != (const void*)table) {
     hipLaunchKernelGGL(srs_gen_table, dim3((GEN_WINDOWS * GEN_DIGITS + 255) / 256), dim3(256), 0, ctx->stream, table);
     BP_HIP(ctx, hipGetLastError());
+    ctx->gen_table_ready = true;
+    ctx->gen_table_ptr = table;
   }
   const size_t lanes = (n + SRS_GEN_GROUP - 1) / SRS_GEN_GROUP;
   hipLaunchKernelGGL(srs_generate_fb, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, a, d, mode, first, n, table, d_out);

@@ -56,6 +56,8 @@ def combine_partials(partial144, device=None, group=None):
 class ShardedMsm:
     """The MSM path of one rank: the rank's partial sums stay in HBM (bp_msm_g1_blob_device_async), ONE all-gather
     of the records over RCCL/xGMI, the device-side pre-sum, ONE device-to-host copy, host combine (bp_msm_blobs_combine).
+    Under the "nccl" backend all of that is ONE call into the library (bp_msm_g1_allgather, capi_comm.hip: the communicator lives in
+    the bp_ctx); under gloo (CPU rehearsals) the same steps are spelled out here with a host-side gather.
     Stream-ordered end to end: the library context is put on a torch stream owned by this object (bp_set_stream) and the record,
     the collective, the pre-sum and the copy are enqueued on it in that order -- the copy's is the only host wait of a call.
     Buffers are allocated once.  `exchange_s`: GPU time from "record complete" to "gathered, summed and copied" (two events on
@@ -69,6 +71,23 @@ class ShardedMsm:
         ctx.set_stream(self.stream.cuda_stream)          # every later call on ctx is ordered on this stream
         self.collective = dist.is_initialized()          # under a launcher even a single rank goes through the collective
         self.on_gpu = self.collective and dist.get_backend(group) == "nccl"
+        # Under RCCL the exchange is the LIBRARY's (bp_msm_g1_allgather: record -> ncclAllGather -> device pre-sum -> one D2H, all under
+        # the C ABI) -- the Python mirror and a Rust host that binds the C ABI run the same lines.  torch.distributed only carries the
+        # 128-byte communicator id from rank 0 to the others, once.  (gloo rehearsals keep the host-side gather below: RCCL refuses two
+        # ranks on one GPU.)
+        self.c_path = False
+        if self.on_gpu:
+            if ctx.comm_info()[1] == 0:
+                rank = dist.get_rank(group)
+                box = [api.Context.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
+                                           device=self.gpu)
+                ctx.comm_init_rank(box[0], rank, self.world)
+                self.own_comm = True
+            else:
+                self.own_comm = False
+            assert ctx.comm_info() == (dist.get_rank(group), self.world)
+            self.c_path = True
         with torch.cuda.stream(self.stream):
             self.mine = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu)
             self.gathered = torch.empty(self.world * _lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu if self.on_gpu else "cpu")
@@ -87,6 +106,10 @@ class ShardedMsm:
         # the record below must be written in THIS object's stream order, or the all-gather behind it reads a stale record
         self.ctx.set_stream(self.stream.cuda_stream)
         self.stream.wait_stream(torch.cuda.current_stream(self.gpu))        # behind whatever produced the scalars; enqueue only
+        if self.c_path:                                                     # the whole exchange under the C ABI, on this stream
+            out = self.ctx.msm_allgather(srs_handle_local, scalars_local, first=first, device_ptr=device_ptr, n=n)
+            self.exchange_s = 1e-3 * self.ctx.comm_last_exchange_ms()
+            return out
         self.ctx.msm_blob_device(srs_handle_local, self.mine.data_ptr(), scalars_local, first=first, device_ptr=device_ptr, n=n, wait=False)
         with torch.cuda.stream(self.stream):
             self.record_done.record()
@@ -119,6 +142,8 @@ class ShardedMsm:
     def close(self):
         if getattr(self, "ctx", None) is not None and getattr(self.ctx, "_h", None):
             self.ctx.set_stream(None)                    # waits for the stream, then back to the context's own
+            if getattr(self, "c_path", False) and getattr(self, "own_comm", False):
+                self.ctx.comm_destroy()
         self.ctx = None
 
     def __del__(self):

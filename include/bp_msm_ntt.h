@@ -60,7 +60,8 @@ enum {
   BP_ERR_NO_DEVICE = -8,     /* no usable GPU / HIP runtime error at init */
   BP_ERR_HIP = -9,           /* HIP runtime error; bp_last_error() has the text */
   BP_ERR_TOO_LARGE = -10,    /* size beyond the supported range (NTT > 2^28, MSM >= 2^31 points) */
-  BP_ERR_ASSERT = -11        /* a protocol assert_eq! of the reference failed (prover.rs:319  z_n == 1) */
+  BP_ERR_ASSERT = -11,       /* a protocol assert_eq! of the reference failed (prover.rs:319  z_n == 1) */
+  BP_ERR_COMM = -12          /* an RCCL call failed (bp_comm_*, bp_msm_g1_allgather, bp_ntt_columns_allgather); text in bp_last_error */
 };
 enum { BP_FR_BYTES_LE = 0, BP_FR_MONT = 1 };
 enum { BP_BASIS_LAGRANGE = 0, BP_BASIS_MONOMIAL = 1 };   /* polynomial.rs:8-11 */
@@ -122,13 +123,14 @@ int  bp_srs_free(bp_ctx* ctx, uint64_t srs_handle);
  * passes to one; results are the same group element.  window_bits: 0 = chosen from srs_len (16 below 2^20 points, 20 -- thirteen
  * windows -- from 2^20 points, 22 from 2^24), BP_SRS_TABLES_OFF = drop the tables, else 4..24 (above 16 the bucket sort is partitioned).  MSMs shorter than 2^window_bits / 8 scalars keep
  * using the table-free path.  The reference has no counterpart (its MSM recomputes from the raw points).
- * Memory budget (hipMemGetInfo per device, after the previous tables of this SRS are released): window_bits = 0 never fails for lack
- * of memory -- a width that does not fit beside what else lives on the device falls back to wider windows (fewer rows) and then to no
- * tables at all (bp_srs_table_info reports what was built; results are the same bytes either way); an explicit width that does not
- * fit returns BP_ERR_TOO_LARGE with the sizes in bp_last_error(), before anything is allocated.
- * window_bits = 256 + w (w = 6..22): tables of EVERY bit position, T[p][i] = 2^p * P_i for p < 256 (256 x srs_len x 128 bytes:
- * 32 GiB at 2^20 points), used with the scalars' width-w non-adjacent form: ~256 / (w + 1) + 0.5 bucket additions per scalar
- * and 2^(w-2) buckets.  Measured slower than the 16-bit windows at 2^20 as shipped; never chosen by 0. */
+ * Memory budget (hipMemGetInfo per device; the bytes of the tables this SRS holds now count as free): window_bits = 0 never fails
+ * for lack of memory -- a width that does not fit beside what else lives on the device falls back to wider windows (fewer rows; only
+ * widths an MSM over this SRS would use, 8 * srs_len >= 2^width) and then to no tables at all (bp_srs_table_info reports what was
+ * built; results are the same bytes either way); an explicit width that does not fit returns BP_ERR_TOO_LARGE with the sizes in
+ * bp_last_error() before anything is released or allocated: the SRS keeps the tables it had.
+ * window_bits = 256 + w (w = 6..22: tables of EVERY bit position, T[p][i] = 2^p * P_i for p < 256, used with the scalars' width-w
+ * non-adjacent form) exists ONLY in the experiment build libbp_msm_ntt_exp.so (measured slower twice, docs/EXPERIMENTS.md C); the
+ * shipped library rejects it with BP_ERR_INVALID_ARG. */
 #define BP_SRS_TABLES_OFF 1u
 int  bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits);
 /* window_bits / windows / bytes of the tables of an SRS (all 0 without tables). */
@@ -203,6 +205,35 @@ int  bp_msm_last_member_stats(bp_ctx* ctx, int member, float* upload_ms, float* 
                               uint64_t* mixed_adds);
 /* 1 when the last MSM on this ctx went through fixed-base tables, 0 when not, negative on error. */
 int  bp_msm_last_used_tables(bp_ctx* ctx);
+
+/* ---- one process per GPU: the collective under the boundary (SURVEY.md 8b "bp_ctx owns ... the RCCL comm", 8e) ------------------
+ * The reference is one thread on one CPU (prover.rs has no notion of ranks); a Rust host that runs one process per GPU calls these
+ * instead of bringing its own RCCL binding.  The library is linked against librccl; every collective is enqueued on the context's
+ * stream between the library's own kernels.  Communicators belong to plain bp_init contexts (a bp_init_multi context combines its
+ * shards itself).  Exercised on the build pool's one-GPU boxes with worlds of ONE rank only (tests/test_gpu_dist.py); no multi-GPU
+ * run exists yet, and no number for a world > 1 is claimed.
+ * bp_comm_unique_id: rank 0 makes the 128-byte id (ncclGetUniqueId); the host carries it to the other ranks by whatever means it
+ * has (a file, a socket, MPI).  bp_comm_init_rank: every rank, same id (ncclCommInitRank; collective -- returns when all `world`
+ * ranks have called it).  bp_comm_info: rank / world of the context's communicator (world = 0 without one). */
+#define BP_COMM_ID_BYTES 128
+int  bp_comm_unique_id(uint8_t id[128]);
+int  bp_comm_init_rank(bp_ctx* ctx, const uint8_t id[128], int rank, int world);
+int  bp_comm_info(bp_ctx* ctx, int* rank, int* world);
+int  bp_comm_destroy(bp_ctx* ctx);
+/* Setup::commit / BucketMSM::bucket_msm over ALL ranks (src/setup.rs:32-37 -> src/msm.rs:76-118): every rank passes the scalars of
+ * ITS point range (srs_handle = the rank's shard, `first` inside it, zip truncation as bp_msm_g1_partial) and every rank receives
+ * the same 96 bytes: sum over all ranks' (point, scalar) pairs.  Inside: the rank's bit planes stay in HBM as a BP_MSM_BLOB_BYTES
+ * record -> ONE ncclAllGather of the records over xGMI -> slot-wise sum of the gathered records on the device -> ONE 22-KB
+ * device-to-host copy -> host Horner (msm.rs:107-115) + normalisation.  One host wait per call.  Collective: every rank of the
+ * communicator must call it (an empty range is fine: n_scalars = 0). */
+int  bp_msm_g1_allgather(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
+                         int scalars_on_device, uint8_t out96[96]);
+/* GPU time of the last bp_msm_g1_allgather from "this rank's record complete" to "gathered, summed and copied" (HIP events). */
+int  bp_comm_last_exchange_ms(bp_ctx* ctx, float* ms);
+/* NTT by independent columns (Polynomial::ntt / i_ntt on separate polynomials, src/polynomial.rs:47-55): d_columns holds
+ * world x columns_per_rank columns of 2^log_n Montgomery elements in HBM, rank r's finished columns in block r (this rank's block
+ * filled by its own bp_ntt_fr_device calls on this context); ONE in-place ncclAllGather leaves every column on every rank. */
+int  bp_ntt_columns_allgather(bp_ctx* ctx, void* d_columns, uint32_t log_n, size_t columns_per_rank);
 
 /* ---- DFT: ntt_381 / i_ntt_381 (src/utils.rs:63-81, 106-129) --------------------------------------- */
 /* In-place natural-order transform of length 2^log_n on `batch` vectors, vector b at data + b*stride

@@ -118,3 +118,86 @@ def test_bench_under_launcher_with_rccl_single_rank():
     line1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert line1["result_sha"] == line["result_sha"] and line1["strong_scaling"]["result_sha"] == line["strong_scaling"]["result_sha"]
     assert line1["config"]["backend"] is None
+
+
+def _comm_worker(q):
+    try:
+        _comm_body(q)
+    except BaseException:
+        import traceback
+        q.put(traceback.format_exc())
+        raise
+
+
+def _comm_body(q):
+    """RCCL through the C ABI only (no torch.distributed): what a Rust host that runs one process per GPU binds"""
+    import numpy as np
+    import torch
+
+    import baby_plonk_rust_amd as bp
+    from oracle import oracle as O
+    from tests import bigint_model as M
+    ctx = bp.Context(0)
+    assert ctx.comm_info() == (0, 0)
+    n, a, d = (1 << 16) + 77, 31337, 271828
+    h = ctx.srs_generate_progression(n, a, d)
+    ctx.srs_precompute(h)
+    sc = O.splitmix_scalars(n, 0xC0BB)
+    want = M.enc96(M.ec_mul(O.dot_progression(sc, a, d)))
+    try:
+        ctx.msm_allgather(h, sc)
+        q.put("no communicator must be an error")
+        return
+    except bp.BpError as e:
+        assert e.code == -1
+    ctx.comm_init_rank(bp.Context.comm_unique_id(), 0, 1)             # rank 0 of a world of one: ncclGetUniqueId + ncclCommInitRank
+    assert ctx.comm_info() == (0, 1)
+    got = ctx.msm_allgather(h, sc)                                    # record -> ncclAllGather -> device pre-sum -> one D2H -> combine
+    assert got == want == ctx.msm(h, sc), "bp_msm_g1_allgather differs from bp_msm_g1"
+    assert ctx.comm_last_exchange_ms() > 0
+    t = torch.from_numpy(sc.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    assert ctx.msm_allgather(h, None, device_ptr=t.data_ptr(), n=n) == want
+    assert ctx.msm_allgather(h, sc[:1000], first=500) == M.enc96(M.ec_mul(O.dot_progression(sc[:1000], a + 500 * d, d)))
+    assert ctx.msm_allgather(h, sc[:0]) == M.enc96(None)             # an empty range still takes part in the collective
+    bad = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in (1, M.Q, 2)), dtype=np.uint8).reshape(-1, 32)
+    try:
+        ctx.msm_allgather(h, bad, fmt=bp.FR_BYTES_LE)
+        q.put("scalar >= q must be rejected")
+        return
+    except bp.BpError as e:
+        assert e.code == -4
+    # NTT columns: 3 columns of 2^12 in this rank's (only) block; the in-place all-gather of a world of one leaves them as they are
+    cols = O.splitmix_scalars(3 << 12, 0xC01).reshape(3, 1 << 12, 4)
+    tc = torch.from_numpy(cols.view(np.int64).copy()).cuda()
+    torch.cuda.synchronize()
+    for j in range(3):
+        ctx.ntt_device(tc[j].data_ptr(), 12)
+    ctx.ntt_columns_allgather(tc.data_ptr(), 12, 3)
+    out = tc.cpu().numpy().view(np.uint64)
+    assert all((out[j] == O.ntt_fast(cols[j])).all() for j in range(3))
+    try:
+        ctx.comm_init_rank(bp.Context.comm_unique_id(), 0, 1)
+        q.put("a second communicator on one context must be an error")
+        return
+    except bp.BpError as e:
+        assert e.code == -1
+    ctx.comm_destroy()
+    assert ctx.comm_info() == (0, 0)
+    ctx.comm_init_rank(bp.Context.comm_unique_id(), 0, 1)             # and again after a destroy
+    assert ctx.msm_allgather(h, sc) == want
+    ctx.close()                                                       # bp_destroy releases the communicator
+    q.put("ok")
+
+
+def test_rccl_collectives_under_the_c_abi_world_of_one():
+    """the all-gather of the MSM records and of finished NTT columns is reachable through the C ABI alone
+    (bp_comm_unique_id / bp_comm_init_rank / bp_msm_g1_allgather / bp_ntt_columns_allgather; libbp_msm_ntt.so links librccl).
+    A world of one rank is what a one-GPU box can run: same bytes as bp_msm_g1, errors as errors."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_comm_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert res == "ok" and p.exitcode == 0, res

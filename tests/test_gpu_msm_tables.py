@@ -216,6 +216,37 @@ def test_full_size_2p24_closed_form_both_paths(ctx):
     ctx.srs_free(h)
 
 
+def test_full_size_2p24_vs_literal_bucket_msm(ctx):
+    """BASELINE configs[3] size against the LITERAL restatement of src/msm.rs:76-118: one 2^24-point MSM through the
+    22-bit tables, byte for byte equal to the oracle's bucket_msm(256, 4) over the same 2^24 points and scalars (64 windows spread over the
+    box's threads: about a minute), with the closed form beside it.  The oracle gets the points the way the Rust caller would hand them
+    over -- 96-byte encodings read back from the library -- and the closed form pins that they are the progression asked for."""
+    import torch
+    n, a, d, seed = 1 << 24, 0x0123456789ABCDEF01, 0x0F0E0D0C0B0A, 0x5EED2424
+    h = ctx.srs_generate_progression(n, a, d)
+    info = ctx.srs_precompute(h)
+    assert info["window_bits"] == 22
+    t = torch.empty(n * 4, dtype=torch.int64, device="cuda")
+    ctx.synthetic_scalars_device(t.data_ptr(), n, seed)
+    got = bp.sum_partials(ctx.msm_partial(h, None, device_ptr=t.data_ptr(), n=n))
+    assert ctx.msm_stats()["tables"] and ctx.msm_stats()["window_bits"] == 22
+    del t
+    sc = O.splitmix_scalars(n, seed)
+    assert got == M.enc96(M.ec_mul(O.dot_progression(sc, a, d)))
+    proj = np.empty((n, 18), dtype=np.uint64)
+    step = 1 << 21
+    for lo in range(0, n, step):                                     # 96-byte encodings -> the oracle's projective limbs, 2^21 at a time
+        proj[lo:lo + step] = O.proj_from_bytes96(ctx.srs_export(h, lo, step))
+    ctx.srs_free(h)
+    # spot-check the exported points against the oracle's own progression (first points and a far one)
+    head = O.proj_from_bytes96(bytes(O.points_to_bytes96(O.points_progression(64, a, d))))
+    assert (proj[:64] == head).all()
+    far = n - 12345
+    assert bytes(O.g1_bytes96(proj[far])) == M.enc96(M.ec_mul((a + far * d) % Q))
+    want = O.g1_bytes96(O.bucket_msm(proj, sc, threads=NTHREADS))
+    assert got == want
+
+
 @pytest.mark.parametrize("c,log_n", [(17, 14), (18, 15), (19, 16), (20, 17), (21, 18), (22, 19), (24, 21)])
 def test_windows_wider_than_16_bits(ctx, c, log_n):
     """fixed-base tables with c > 16: one window's 2^(c-1) buckets exceed the LDS histogram, so the entries go through the
@@ -252,6 +283,43 @@ def test_windows_wider_than_16_bits(ctx, c, log_n):
     if small is not None:                                       # 16-bit witness-like values: only the low windows are populated
         assert ctx.msm(h, small) == M.enc96(M.ec_mul(oracle_dot(small, a, d)))
     ctx.srs_free(h)
+
+
+@pytest.mark.parametrize("c", list(range(4, 25)))
+def test_table_width_sweep_on_the_shipped_library(ctx, c):
+    """every table width the ABI accepts (bp_srs_precompute(h, c), c = 4 .. 24) x sizes 2^9 .. 2^18 (+ an odd tail) x scalar shapes
+    {uniform, all equal, 0 / 1, one-hot, q - 1} against the closed form, on whichever library is loaded -- the SHIPPED one in the default run
+    (the window / sort / fix-up / tree variants used to be reachable through experiment-build knobs only).  The widths
+    select the code paths by themselves: c <= 16 packed one-word records and up to 15 tree levels, c >= 17 the partitioned sort with final
+    runs, long runs for the narrow top windows (c = 18, 19, 21, 23), cooperative and wide tree levels, per-edge and per-bucket fix-up; sizes
+    with 8 n < 2^c keep to the table-free path (per-window bucket sets, running-sum reduction) and must say so."""
+    rnd = random.Random(0xC0DE00 + c)
+    for log_n in range(9, 19):
+        n = (1 << log_n) + (rnd.randrange(1, 64) if log_n % 2 else 0)
+        a, d = rnd.randrange(1, Q), rnd.randrange(1, Q)
+        h = ctx.srs_generate_progression(n, a, d)
+        info = ctx.srs_precompute(h, c)
+        assert info["window_bits"] == c and info["bytes"] == info["windows"] * n * 128
+        expect_tables = 8 * n >= (1 << c)
+        sum_pts = (n * a + d * (n * (n - 1) // 2)) % Q                 # sum_i (a + i d)
+        uni = O.splitmix_scalars(n, 0x5EEDC000 + 64 * c + log_n)
+        assert ctx.msm(h, uni) == M.enc96(M.ec_mul(oracle_dot(uni, a, d))), (c, log_n, "uniform")
+        st = ctx.msm_stats()
+        assert bool(st["tables"]) == expect_tables and (not expect_tables or st["window_bits"] == c), (c, log_n, st)
+        val = rnd.randrange(1, Q)
+        assert ctx.msm(h, np.tile(bp.scalar_from_int(val), (n, 1))) == M.enc96(M.ec_mul(val * sum_pts % Q)), (c, log_n, "all equal")
+        bits = np.frombuffer(rnd.randbytes(n), dtype=np.uint8) & 1
+        zo = np.zeros((n, 4), dtype=np.uint64)
+        zo[bits == 1] = bp.scalar_from_int(1)
+        idx = np.nonzero(bits)[0]
+        k01 = (int(len(idx)) * a + d * int(idx.sum(dtype=np.int64))) % Q
+        assert ctx.msm(h, zo) == M.enc96(M.ec_mul(k01)), (c, log_n, "0/1")
+        j, v = rnd.randrange(n), rnd.randrange(1, Q)
+        hot = np.zeros((n, 4), dtype=np.uint64)
+        hot[j] = bp.scalar_from_int(v)
+        assert ctx.msm(h, hot) == M.enc96(M.ec_mul(v * (a + j * d) % Q)), (c, log_n, "one-hot")
+        assert ctx.msm(h, np.tile(bp.scalar_from_int(Q - 1), (n, 1))) == M.enc96(M.ec_mul((Q - 1) * sum_pts % Q)), (c, log_n, "q - 1")
+        ctx.srs_free(h)
 
 
 @experiment            # every-position tables exist in the experiment build only (measured slower twice, DESIGN.md 4.4)

@@ -106,6 +106,25 @@ def test_2p24_round_trip_and_spot_checks(ctx):
     assert ctx.ntt_stats()["passes"] == 3
 
 
+def test_2p24_full_array_vs_oracle(ctx):
+    """the 2^24 size element for element: forward and inverse transforms of 2^24 elements in HBM equal the oracle's
+    O(n log n) twin of utils.rs:63-129 on every one of the 2^24 outputs (the twin itself equals the literal O(n^2) restatement up to
+    2^10, tests/test_oracle_msm_ntt_poly.py)"""
+    import torch
+    logn, n = 24, 1 << 24
+    a = O.splitmix_scalars(n, 0xF40024)
+    t = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    torch.cuda.synchronize()
+    ctx.ntt_device(t.data_ptr(), logn)
+    want = O.ntt_fast(a, threads=NTHREADS)
+    assert (t.cpu().numpy().view(np.uint64).reshape(-1, 4) == want).all()
+    del want
+    t.copy_(torch.from_numpy(a.view(np.int64)))
+    torch.cuda.synchronize()
+    ctx.ntt_device(t.data_ptr(), logn, inverse=True)
+    assert (t.cpu().numpy().view(np.uint64).reshape(-1, 4) == O.ntt_fast(a, inverse=True, threads=NTHREADS)).all()
+
+
 def test_async_transforms_back_to_back(ctx):
     """bp_ntt_fr_device_async: transforms enqueued on the context's stream without a host wait in between"""
     import torch
