@@ -277,8 +277,14 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   BP_TRY(ws_get(ctx, "msm.partial", 2 * n_chunks * sizeof(proj28_slot), (void**)&partial));
   const uint32_t n_planes = Wr * per_window;        // tables: A and the c - 1 bit planes; else one sum per window
   if (n_planes > (uint32_t)MSM_MAX_WINDOWS) return fail(ctx, BP_ERR_TOO_LARGE, "MSM windows", hipSuccess, __FILE__, __LINE__);
+  // Bucket reduction without tables (W bucket sets of 2^(c-1) buckets): the same bit-plane tree as with tables, over a forest of W trees
+  // (round 5; rounds 1-4 ran segmented running sums per window, msm_reduce: a dependent chain of ~46 additions per lane, 256 VGPRs + spills,
+  // 0.57 ms at 2^20 points -- kept in the experiment build as BP_MSM_REDUCE=1 for the A/B), then one Horner pass over each tree's c values.
+  const bool reduce_running = EXPERIMENT_BUILD && !table_c && knob_u32("BP_MSM_REDUCE", 0, 0, 1) == 1;
   block_out = nullptr;
-  if (!table_c) BP_TRY(ws_get(ctx, "msm.block_out", (size_t)Wr * blocks_per_window * sizeof(proj28_slot), (void**)&block_out));
+  if (reduce_running) BP_TRY(ws_get(ctx, "msm.block_out", (size_t)Wr * blocks_per_window * sizeof(proj28_slot), (void**)&block_out));
+  proj28_slot* roots = nullptr;                     // table-free: the W roots (A, T_0 .. T_{c-2}) in front of the per-window Horner pass
+  if (!table_c && !reduce_running) BP_TRY(ws_get(ctx, "msm.roots", (size_t)W * plan.c * sizeof(proj28_slot), (void**)&roots));
   BP_TRY(ws_get(ctx, "msm.window_sum", (size_t)n_planes * sizeof(proj28_slot) + 16, (void**)&window_sum));     // + the status word
   // pinned staging: MSM_SLOTS result areas of the largest possible size, so earlier pending results stay where they are
   constexpr size_t slot_bytes = (size_t)MSM_MAX_WINDOWS * sizeof(proj28_slot) + 16;
@@ -488,8 +494,10 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     BP_HIP(ctx, hipStreamWaitEvent(ast, ctx->acc_ev[0], 0));
   }
   switch (knob_u32("BP_MSM_ACC_WAVES", 2, 2, 4)) {
+#ifdef BP_EXPERIMENT          // three / four waves per SIMD: 168 / 128 VGPRs, both spill (tools/kernel_resources.py) and measured slower
     case 3: hipLaunchKernelGGL(msm_accumulate<3>, acc_grid, dim3(256), 0, ast, d_points28, sorted, offsets, plan, bucket_sum, partial); break;
     case 4: hipLaunchKernelGGL(msm_accumulate<4>, acc_grid, dim3(256), 0, ast, d_points28, sorted, offsets, plan, bucket_sum, partial); break;
+#endif
     default: hipLaunchKernelGGL(msm_accumulate<2>, acc_grid, dim3(256), 0, ast, d_points28, sorted, offsets, plan, bucket_sum, partial);
   }
   if (ctx->acc_stream) {
@@ -513,7 +521,7 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
                        long_cap);
   hipLaunchKernelGGL(msm_fixup_long, dim3(512), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
                      long_count, long_list, long_cap, long_scratch, long_ticket);
-  if (table_c) {
+  if (!reduce_running) {
     // The tree over the B = 2^(c-1) buckets, level by level.  A level with at least PLANES_WIDE_MIN additions is throughput
     // bound: one addition per lane through HBM (msm_planes_level; only windows wider than 17 bits have such levels).  The rest
     // is latency bound: up to PLANES_STEP_LOG levels per launch inside workgroups, cooperative additions (msm_planes_step).
@@ -522,6 +530,11 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     const uint64_t wide_min = knob_u32("BP_MSM_PLANES_WIDE_MIN", 24000, 256, 1u << 30);
     uint32_t k = 0, nodes = total, n_wide = 0;            // total = J B leaves: a forest of J trees (J > 1: the vectors of a batch)
     while (n_wide < levels && (uint64_t)(total >> (n_wide + 1)) * (n_wide + 1) >= wide_min) n_wide++;
+    if (n_wide == levels) n_wide = levels - 1;            // the last level is always a step: it writes the result where the epilogue reads it
+    // levels 0 and 1 have the same number of additions, so a wide level 0 comes with a wide level 1 and the two run fused (msm_planes_level01);
+    // a lone wide leaf level (two-level trees, c = 3: knobs only) takes the step path in the shipped library -- its single-level LEAF kernel
+    // is the one tree kernel that spills (tools/kernel_resources.py) and lives in the experiment build only (BP_MSM_PLANES_FUSE01=0)
+    if (!EXPERIMENT_BUILD && n_wide < 2) n_wide = 0;
     proj28_slot* tmp[2] = {nullptr, nullptr};
     {
       size_t need[2] = {0, 0};
@@ -553,16 +566,19 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
         nodes >>= 1;
         const uint64_t items = (uint64_t)nodes * (k + 1);
         const dim3 grid((unsigned)((items + 255) / 256));
+#ifdef BP_EXPERIMENT
         if (leaf) hipLaunchKernelGGL(msm_planes_level<true>, grid, dim3(256), 0, st, offsets, in, k, nodes, tmp[flip]);
-        else hipLaunchKernelGGL(msm_planes_level<false>, grid, dim3(256), 0, st, offsets, in, k, nodes, tmp[flip]);
+        else
+#endif
+        hipLaunchKernelGGL(msm_planes_level<false>, grid, dim3(256), 0, st, offsets, in, k, nodes, tmp[flip]);
         in = tmp[flip];
         k += 1;
       } else {
         const uint32_t m = levels - k < PLANES_STEP_LOG ? levels - k : PLANES_STEP_LOG;
         nodes >>= m;
         const bool last = k + m == levels;
-        proj28_slot* out_nodes = last ? window_sum : tmp[flip];
-        uint32_t* status_out = last ? reinterpret_cast<uint32_t*>(window_sum + n_planes) : (uint32_t*)nullptr;
+        proj28_slot* out_nodes = last ? (table_c ? window_sum : roots) : tmp[flip];
+        uint32_t* status_out = last && table_c ? reinterpret_cast<uint32_t*>(window_sum + n_planes) : (uint32_t*)nullptr;
         const dim3 grid(nodes, k + 1);
         const size_t lds = ((size_t)2 << m) * sizeof(proj28_slot);
         if (leaf) hipLaunchKernelGGL(msm_planes_step<true>, grid, dim3(256), lds, st, offsets, in, k, m, out_nodes, long_count + 1, offsets + total, status_out);
@@ -572,11 +588,16 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
       }
       flip ^= 1;
     }
+    if (!table_c)           // W roots of c values each -> W window sums A + sum_j 2^j T_j (what msm.rs:42-46 computes per window)
+      hipLaunchKernelGGL(msm_planes_window_sums, dim3(W), dim3(64), 0, st, roots, plan.c, window_sum, long_count + 1, offsets + total,
+                         reinterpret_cast<uint32_t*>(window_sum + n_planes));
   } else {
+#ifdef BP_EXPERIMENT
     hipLaunchKernelGGL(msm_reduce, dim3(blocks_per_window, Wr), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum,
                        block_out);
     hipLaunchKernelGGL(msm_window_finish, dim3(Wr), dim3(256), 256 * sizeof(proj28_slot), st, block_out, blocks_per_window, window_sum,
                        long_count + 1, offsets + total, reinterpret_cast<uint32_t*>(window_sum + n_planes));
+#endif
   }
   BP_HIP(ctx, hipGetLastError());
   if (d_blob) {

@@ -1270,6 +1270,7 @@ __device__ __forceinline__ g1_proj28 block_tree_sum28(g1_proj28 v, uint32_t live
   return load_proj28(&tree[0]);
 }
 
+#ifdef BP_EXPERIMENT     // rounds 1-4: the table-free reduction (BP_MSM_REDUCE=1); the shipped library runs the bit-plane tree over every bucket set
 // ---------------------------------------------------------------- 7a. reduce, per-window buckets: T_w = sum_b (b+1) * S_{w,b}
 // Segmented running sums: grid (blocks_per_window, W), 256 lanes; a lane handles `seg` consecutive buckets, then
 // scales its share by its first bucket index and the block tree-sums in LDS.  With W * B buckets there is enough
@@ -1315,6 +1316,7 @@ __global__ void __launch_bounds__(256, 2) msm_window_finish(const proj28_slot* _
   g1_proj28 tot = block_tree_sum28(v, blocks_per_window < blockDim.x ? blocks_per_window : blockDim.x);
   if (threadIdx.x == 0) store_proj28(&window_sum[w], tot);
 }
+#endif
 
 // ---------------------------------------------------------------- 7b. reduce, fixed-base tables (one bucket set):  sum_b (b + 1) S_b  by bit planes
 //   sum_b (b + 1) S_b = A + sum_j 2^j T_j,    A = sum_b S_b,   T_j = sum of the buckets whose index b has bit j set.
@@ -1458,6 +1460,45 @@ msm_planes_step(const uint32_t* __restrict__ offsets, const proj28_slot* __restr
   } else if (threadIdx.x == 0) {
     out[(size_t)w * c + v] = root[0];
   }
+}
+
+// Table-free path (per-window bucket sets): the forest's W roots, c values each (A, T_0 .. T_{c-2}), become the W window sums
+//   sum_b (b + 1) S_{w,b} = A_w + sum_j 2^j T_{w,j}
+// by Horner over the bit planes; all windows side by side, one 64-lane workgroup each; the host's Horner over the windows
+// (msm.rs:107-115) then sees the same W sums as ever.  The c - 1 planes of a window are cut into four runs: four cooperative groups
+// evaluate their run's Horner form side by side (2 (q - 1) dependent cooperative operations for runs of q planes), one group joins the
+// four partial values (q doublings + one addition each) and adds A: 22 dependent operations at c = 16 instead of 29 for the plain chain
+// (~2.8 us each).  The last kernel of the MSM: it also moves the scalar-status word and the entry count behind the sums.
+__global__ void __launch_bounds__(64) msm_planes_window_sums(const proj28_slot* __restrict__ roots, uint32_t c, proj28_slot* __restrict__ window_sum,
+                                                             const uint32_t* __restrict__ status_in, const uint32_t* __restrict__ entries_in,
+                                                             uint32_t* __restrict__ status_out) {
+  __shared__ proj28_slot part[4];
+  const uint32_t w = blockIdx.x, grp = threadIdx.x / COOP;
+  const bool lead = (threadIdx.x & (COOP - 1)) == 0;
+  if (w == 0 && threadIdx.x == 0) { status_out[0] = *status_in; status_out[1] = *entries_in; }
+  const proj28_slot* r = roots + (size_t)w * c;
+  const uint32_t np = c - 1, q = (np + 3) / 4;          // planes T_0 .. T_{np-1} at r[1 ..]; runs of q planes (the last may be shorter or empty)
+  if (grp < 4) {                                        // uniform over a cooperative group
+    const uint32_t lo = grp * q, hi = lo + q < np ? lo + q : np;
+    g1_proj28 t = g1_identity28();
+    if (lo < hi) {
+      t = load_proj28(&r[hi]);                          // T_{hi-1}
+      for (uint32_t j = hi - 1; j-- > lo;) {
+        t = g1_add28_coop(t, t);
+        t = g1_add28_coop(t, load_proj28(&r[1 + j]));
+      }
+    }
+    if (lead) store_proj28(&part[grp], t);
+  }
+  __syncthreads();
+  if (grp != 0) return;
+  g1_proj28 acc = load_proj28(&part[3]);
+  for (uint32_t g = 3; g-- > 0;) {
+    for (uint32_t d = 0; d < q; d++) acc = g1_add28_coop(acc, acc);
+    acc = g1_add28_coop(acc, load_proj28(&part[g]));
+  }
+  acc = g1_add28_coop(acc, load_proj28(&r[0]));         // + A
+  if (lead) store_proj28(&window_sum[w], acc);
 }
 
 }  // namespace bp

@@ -75,19 +75,28 @@ class ShardedMsm:
         # the C ABI) -- the Python mirror and a Rust host that binds the C ABI run the same lines.  torch.distributed only carries the
         # 128-byte communicator id from rank 0 to the others, once.  (gloo rehearsals keep the host-side gather below: RCCL refuses two
         # ranks on one GPU.)
-        self.c_path = False
+        self.c_path, self.own_comm, self.c_path_error = False, False, None
         if self.on_gpu:
-            if ctx.comm_info()[1] == 0:
-                rank = dist.get_rank(group)
-                box = [api.Context.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
-                                           device=self.gpu)
-                ctx.comm_init_rank(box[0], rank, self.world)
-                self.own_comm = True
-            else:
+            rank = dist.get_rank(group)
+            ok = 1
+            try:
+                if ctx.comm_info()[1] == 0:
+                    box = [api.Context.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
+                                               device=self.gpu)
+                    ctx.comm_init_rank(box[0], rank, self.world)
+                    self.own_comm = True
+                if ctx.comm_info() != (rank, self.world):
+                    raise RuntimeError("the context's communicator is rank %d of %d, the process group says %d of %d"
+                                       % (ctx.comm_info() + (rank, self.world)))
+            except Exception as e:                       # no world > 1 has run yet: a failure here must cost the C path, not the job
+                ok, self.c_path_error = 0, repr(e)[:200]
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.gpu)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)          # every rank takes the same path
+            self.c_path = bool(int(flag.item()))
+            if not self.c_path and self.own_comm and ctx.comm_info()[1]:
+                ctx.comm_destroy()
                 self.own_comm = False
-            assert ctx.comm_info() == (dist.get_rank(group), self.world)
-            self.c_path = True
         with torch.cuda.stream(self.stream):
             self.mine = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu)
             self.gathered = torch.empty(self.world * _lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu if self.on_gpu else "cpu")

@@ -110,32 +110,64 @@ def self_launch(args):
     return 0
 
 
-BARE_ADDS_PER_S = 7.343e9     # register-only g1_add_mixed28, whole chip (profiles/r02_ubench_valu_floor.txt)
-BARE_BUTTERFLIES_PER_S = 1024 * 64 / 1311.0 * 2.4e9      # register-only fr29_butterfly: 1 311 clk per wave-butterfly per SIMD, 1 024 SIMDs
+# Numbers that need a separate pass (PMC counters, the static instruction mix, the register-only microbenchmarks) are READ from the
+# committed files of the newest round that has them -- never typed in here -- and every figure derived from them names its file.
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02")
 
 
-def profile_lookup(name, key):
-    """numbers that need a separate profiler pass (PMC counters, static instruction mix) come from committed files under
-    profiles/; None when the running configuration is not the profiled one"""
-    try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            return json.load(f).get(key)
-    except Exception:
-        return None
+def profile_lookup(suffix, key):
+    """(value, file name) of `key` in the newest profiles/rNN_<suffix> that holds it; (None, None) when the running configuration was not
+    profiled (e.g. another size or table width)"""
+    for rnd in PROFILE_ROUNDS:
+        name = "%s_%s" % (rnd, suffix)
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                v = json.load(f).get(key)
+        except Exception:
+            continue
+        if v is not None:
+            return v, name
+    return None, None
+
+
+def ubench_rates():
+    """register-only rates of the two inner operations on the whole chip, from the newest profiles/rNN_ubench_valu_floor.txt
+    (tools/ubench_g1add, tools/ubench_fr29 run on the GPU box): best additions/s of g1_add_mixed28, fewest clocks per wave-butterfly"""
+    import re
+    for rnd in PROFILE_ROUNDS:
+        name = "%s_ubench_valu_floor.txt" % rnd
+        try:
+            text = open(os.path.join(ROOT, "profiles", name)).read()
+        except Exception:
+            continue
+        adds = [float(m) for m in re.findall(r"^g1_add_mixed28 .*?([0-9.]+e[+-]?[0-9]+) additions/s", text, flags=re.M)]
+        clks = [float(m) for m in re.findall(r"butterfl.*?([0-9.]+) clk per butterfly per SIMD", text)]
+        if adds and clks:
+            return {"adds_per_s": max(adds), "butterfly_clk": min(clks), "source": "profiles/" + name}
+    return {"adds_per_s": 7.343e9, "butterfly_clk": 1311.0, "source": "fallback constants (no profiles/rNN_ubench_valu_floor.txt found)"}
+
+
+UBENCH = ubench_rates()
+BARE_ADDS_PER_S = UBENCH["adds_per_s"]                                           # register-only g1_add_mixed28, whole chip
+BARE_BUTTERFLIES_PER_S = 1024 * 64 / UBENCH["butterfly_clk"] * 2.4e9             # register-only fr29_butterfly, 1 024 SIMDs at 2.4 GHz
 
 
 def msm_roofline(n, acc_s, adds, window_bits, tables, traffic_key=None):
     """HBM roofline (the contract's) and the integer-issue roofline (the one that binds) of msm_accumulate for one launch"""
     achieved = MSM_BYTES_PER_UNIT * n / acc_s / 1e9
-    traffic = profile_lookup("r04_hbm_traffic.json", traffic_key) if traffic_key else None
+    traffic, traffic_file = profile_lookup("hbm_traffic.json", traffic_key) if traffic_key else (None, None)
+    designed = (128 * adds + 4 * adds) if adds else None       # one 128-byte point / table slot + one sorted index per bucket addition
     hbm = {"bound": "hbm", "kernel": "msm_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "traffic": traffic["hbm_bytes_per_launch"] if traffic else None, "traffic_source": traffic.get("source") if traffic else None,
+           "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+           "traffic_source": ("profiles/%s: %s" % (traffic_file, traffic.get("source"))) if traffic else None,
            "kernel_ms": acc_s * 1e3, "algorithmic_bytes_per_launch": MSM_BYTES_PER_UNIT * n,
-           "designed_bytes_per_launch": (128 * adds + 4 * adds) if adds else None,       # one 128-byte table slot + one sorted index per bucket addition
-           "designed_bytes_note": "what the fixed-base path moves by design: a gathered 128-B slot and a 4-B list entry per bucket addition "
-                                  "(13 per scalar at 20-bit windows), not the 128 B per scalar of the algorithmic figure",
+           "designed_bytes_per_launch": designed,
+           "designed_frac": (designed / acc_s / 1e9 / HBM_PEAK_GBS) if designed else None,
+           "designed_bytes_note": "what the kernel moves by design: a gathered 128-B slot and a 4-B list entry per bucket addition "
+                                  "(13 per scalar at 20-bit windows with tables, 16 at 16 bits without), not the 128 B per scalar of the "
+                                  "algorithmic figure; designed_frac = designed bytes / kernel time / peak, frac = algorithmic bytes / kernel time / peak",
            "note": "integer-issue bound by design (11 Fp products + 8 reductions per bucket addition); see roofline_valu_issue"}
-    mix = profile_lookup("r04_msm_accumulate_instr_mix.json", "msm_accumulate<2>")
+    mix, mix_file = profile_lookup("msm_accumulate_instr_mix.json", "msm_accumulate<2>")
     issue = None
     if mix and adds:
         # lane-cycles of one loop iteration at the measured issue rates, times the additions actually performed
@@ -148,26 +180,26 @@ def msm_roofline(n, acc_s, adds, window_bits, tables, traffic_key=None):
                             "necessary; not a hardware peak",
                  "valu_per_addition": {"quarter_rate": mix["quarter_rate"], "full_rate": mix["full_rate"], "v_mad_u64_u32": mix.get("v_mad_u64_u32")},
                  "note": "additions counted by the kernel pipeline (non-zero digits) x static instruction classes of the loop body "
-                         "(tools/instr_mix.py on the shipped code object) at the issue rates tools/ubench_int.hip measured "
-                         "(quarter-rate 57, full-rate 90 lanes/clk/CU, 256 CU, 2.4 GHz), over the measured kernel time",
+                         "(tools/instr_mix.py on the shipped code object: profiles/%s) at the issue rates tools/ubench_int.hip measured "
+                         "(quarter-rate 57, full-rate 90 lanes/clk/CU, 256 CU, 2.4 GHz), over the measured kernel time" % mix_file,
                  "bare_kernel_peak": {"value": BARE_ADDS_PER_S, "frac": adds / acc_s / BARE_ADDS_PER_S,
-                                      "source": "tools/ubench_g1add.hip: the same g1_add_mixed28 on registers only, two waves per SIMD "
-                                                "(profiles/r02_ubench_valu_floor.txt)"}}
+                                      "source": "tools/ubench_g1add.hip: the same g1_add_mixed28 on registers only, two waves per SIMD (%s)"
+                                                % UBENCH["source"]}}
     return hbm, issue
 
 
 def ntt_roofline(nn, ntt_s, passes, traffic_key=None):
     achieved = NTT_BYTES_PER_UNIT * nn / ntt_s / 1e9
-    traffic = profile_lookup("r04_hbm_traffic.json", traffic_key) if traffic_key else None
+    traffic, traffic_file = profile_lookup("hbm_traffic.json", traffic_key) if traffic_key else (None, None)
     butterflies = (nn // 2) * (nn.bit_length() - 1)
     return {"valu": {"bound": "valu", "achieved": butterflies / ntt_s, "peak": BARE_BUTTERFLIES_PER_S, "unit": "butterflies/s",
                      "frac": butterflies / ntt_s / BARE_BUTTERFLIES_PER_S,
                      "note": "N/2 log2 N radix-2 butterflies over the kernel time, against fr29_butterfly on registers only (tools/ubench_fr29.hip: "
-                             "1 311 clk per 64 butterflies per SIMD at four waves); the passes also convert limbs, apply inter-pass twiddles and "
-                             "pay ~10 us of ramp each (profiles/r02_ntt_radix4_ab.txt)"},
+                             "%.0f clk per 64 butterflies per SIMD at four waves, %s); the passes also convert limbs, apply inter-pass twiddles and "
+                             "pay ~10 us of ramp each (profiles/r02_ntt_radix4_ab.txt)" % (UBENCH["butterfly_clk"], UBENCH["source"])},
             "bound": "hbm", "kernel": "ntt_pass_* (all %d passes of one transform)" % passes, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
-            "traffic_source": traffic.get("source") if traffic else None, "kernel_ms": ntt_s * 1e3,
+            "traffic_source": ("profiles/%s: %s" % (traffic_file, traffic.get("source"))) if traffic else None, "kernel_ms": ntt_s * 1e3,
             "algorithmic_bytes_per_launch": NTT_BYTES_PER_UNIT * nn}
 
 
@@ -501,6 +533,35 @@ def main():
     weak_ok = expected_msm(weak_pairs, A0, D0) == head["result"]
     assert weak_ok, "weak-scaling MSM differs from the closed form"
 
+    # ---------------------------------------------------------------- pipelined: three commitments in flight (what a prover round issues)
+    # `value` above is SERIAL: one MSM, its result on the host, then the next (what one Setup::commit call costs).  The prover's rounds 1, 3
+    # and 5 issue three / three / two commitments whose results are needed only together (prover.rs:249-251, 483-485, 640-641): bp_commit_many
+    # runs them on the context's lanes, so that one pipeline's sort and tail overlap another's accumulation.  Per step: three 2^log_n-scalar
+    # vectors against the same resident SRS + tables, all three results on the host; every result checked against its closed form.
+    pipelined = None
+    if world == 1 and not args.no_tables:
+        setup = bp.Setup(srs, ctx, tables=False)                       # wraps the resident handle (its tables exist already)
+        vecs = [scal] + [synthetic(n, 0x9199000 + 131 * j) for j in (1, 2)]
+        polys = [bp.DevicePolynomial(v.view(n, 4), bp.BASIS_MONOMIAL, ctx) for v in vecs]
+        torch.cuda.synchronize()
+        for _ in range(max(1, args.warmup)):
+            got3 = bp.commit_many_device(setup, polys)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            got3 = bp.commit_many_device(setup, polys)
+        barrier()
+        dt = time.perf_counter() - t0
+        pipe_ok = all(expected_msm([fr_sums(v, n, 0)], A0, D0) == g for v, g in zip(vecs, got3)) and got3[0] == head["result"]
+        assert pipe_ok, "pipelined commitments differ from the closed form"
+        pipelined = {"metric": "g1_msm_scalar_muls_per_s", "value": 3 * n * args.steps / dt, "unit": "scalar-muls/s", "msms_in_flight": 3,
+                     "ms_per_msm": 1e3 * dt / (3 * args.steps), "ms_per_three": 1e3 * dt / args.steps, "equals_closed_form": pipe_ok,
+                     "how": "bp_commit_many_device: three independent 2^%d-point MSMs against the same SRS + tables on three lanes (own stream and "
+                            "workspaces each), all three results on the host per step; the serial `value` waits for every result before the next "
+                            "MSM starts.  Cutting msm_accumulate into workgroup generations with the tails on high-priority streams was built and "
+                            "measured in round 5 and loses (profiles/r05_accumulate_generations_ab.txt)" % args.log_n}
+        del polys, vecs, setup
+
     # ---------------------------------------------------------------- seams of the reference (N = 1): host scalars, uncached points
     seams = {}
     if world == 1 and not args.skip_seams:
@@ -574,16 +635,30 @@ def main():
     ntt_cols = None
     if use_dist:
         mine_j = bpd.my_columns(NTT_COLUMNS, rank, world)
-        fresh = {j: synthetic(nn, 0xC0100000 + 977 * j).view(nn, 4) for j in mine_j}
-        colbuf = {j: t.clone() for j, t in fresh.items()}
-        torch.cuda.synchronize()                                # the clones run on torch's stream, the transforms on the library's
+        per_rank_cols = (NTT_COLUMNS + world - 1) // world
+        # all columns of all ranks in ONE buffer, rank r's block at rows [r * per_rank, (r + 1) * per_rank): this rank transforms its own
+        # rows in place; under RCCL the gather is the LIBRARY's in-place ncclAllGather (bp_ntt_columns_allgather, the communicator lives
+        # in the bp_ctx), under gloo (CPU rehearsal of the control flow) the Python mirror's host-side gather
+        cols_c_path = args.backend == "nccl" and ctx.comm_info()[1] == world
+        big = torch.zeros((world * per_rank_cols, nn, 4), dtype=torch.int64, device=dev)
+
+        def row_of(j):
+            return (j % world) * per_rank_cols + j // world
+
+        for j in mine_j:
+            big[row_of(j)].copy_(synthetic(nn, 0xC0100000 + 977 * j).view(nn, 4))
+        torch.cuda.synchronize()                                # the copies run on torch's stream, the transforms on the library's
 
         def cols_step():
             for j in mine_j:
-                ctx.ntt_device_async(colbuf[j].data_ptr(), args.ntt_log_n)
+                ctx.ntt_device_async(big[row_of(j)].data_ptr(), args.ntt_log_n)
             ctx.synchronize()
             t_t = time.perf_counter()
-            got = bpd.all_gather_columns(colbuf, NTT_COLUMNS)
+            if cols_c_path:
+                ctx.ntt_columns_allgather(big.data_ptr(), args.ntt_log_n, per_rank_cols)
+                got = [big[row_of(j)] for j in range(NTT_COLUMNS)]
+            else:
+                got = bpd.all_gather_columns({j: big[row_of(j)] for j in mine_j}, NTT_COLUMNS)
             torch.cuda.synchronize()
             return got, time.perf_counter() - t_t
 
@@ -592,12 +667,12 @@ def main():
         ref = synthetic(nn, 0xC0100000 + 977 * probe)
         ctx.ntt_device(ref.data_ptr(), args.ntt_log_n)
         torch.cuda.synchronize()
-        cols_ok = bool(torch.equal(got[probe].to(dev).reshape(-1), ref)) and len(got) == NTT_COLUMNS
+        cols_ok = bool(torch.equal(got[probe].to(dev).reshape(-1), ref.reshape(-1))) and len(got) == NTT_COLUMNS
         digest = hashlib.sha256()
         for c in got:
             digest.update(c[:64].cpu().numpy().tobytes())
         cols_digest = digest.hexdigest()[:16]
-        del got, ref, fresh
+        del got, ref
         for _ in range(max(0, args.warmup - 1)):
             cols_step()
         barrier()
@@ -607,8 +682,9 @@ def main():
             _, g = cols_step()
             gather_s += g
         barrier()
-        ntt_cols = {"elapsed": time.perf_counter() - t0, "gather_s": gather_s, "ok": cols_ok, "digest": cols_digest, "mine": len(mine_j)}
-        del colbuf
+        ntt_cols = {"elapsed": time.perf_counter() - t0, "gather_s": gather_s, "ok": cols_ok, "digest": cols_digest, "mine": len(mine_j),
+                    "c_path": cols_c_path}
+        del big
         torch.cuda.empty_cache()
 
     # ---------------------------------------------------------------- the metric's other sizes, N = 1 (2^16 = configs[1]; 2^24 rides on the strong leg)
@@ -788,8 +864,17 @@ def main():
                                       "raw points only" if args.no_tables else "resident with its fixed-base window tables (Setup)", args.ntt_log_n),
                        "msm_points_per_gpu": n, "window_bits": stats["window_bits"], "ntt_len_per_gpu": nn,
                        "srs_tables": {"used": stats["tables"], "window_bits": table_info["window_bits"], "windows": table_info["windows"],
-                                      "bytes_per_gpu": table_info["bytes"], "build_s": table_build_s},
-                       "parallelism": "point-range x%d" % world, "ranks": world, "backend": args.backend if use_dist else None},
+                                      "bytes": table_info["bytes"], "bytes_per_gpu": table_info["bytes"], "build_ms": 1e3 * table_build_s,
+                                      "build_s": table_build_s,
+                                      "note": "the headline is a FIXED-BASE MSM: T[w][i] = 2^(window_bits w) P_i built once per SRS outside the "
+                                              "timed region; value_without_tables is the same MSM on the raw points"},
+                       "value_without_tables": None if args.no_tables else units / other_elapsed,
+                       "parallelism": "point-range x%d" % world, "ranks": world, "backend": args.backend if use_dist else None,
+                       "msm_exchange": None if not use_dist else
+                       ("bp_msm_g1_allgather: record -> ncclAllGather -> device pre-sum -> one D2H, all under the C ABI (capi_comm.hip)"
+                        if exchange.c_path else ("dist.ShardedMsm: torch.distributed all_gather_into_tensor of the records (C path unavailable: %s)"
+                                                 % exchange.c_path_error if args.backend == "nccl"
+                                                 else "dist.ShardedMsm host-side gather (gloo rehearsal of the control flow)"))},
             # the headline is a FIXED-BASE MSM (the SRS of a Setup with its window tables resident); the reference-shaped figures beside it:
             "value_without_tables": None if args.no_tables else units / other_elapsed,
             "ms_per_step_without_tables": None if args.no_tables else 1e3 * other_elapsed / args.steps,
@@ -805,6 +890,7 @@ def main():
             "msm_accumulate_ms": head["acc_ms"],
             "tail_ms": head["dev_ms"] - head["acc_ms"],
             "tail_note": "device time of one MSM outside msm_accumulate: bucket sort (3 launches), fix-up, bit-plane tree, copies",
+            "register_only_rates_source": UBENCH["source"],
             "equals_closed_form": weak_ok,
             "exchange_ms": head["exchange_ms"],
             ("msm_with_tables" if args.no_tables else "msm_without_tables"): {
@@ -826,12 +912,16 @@ def main():
                 "columns": NTT_COLUMNS, "column_len": nn, "columns_per_rank": [c["columns"] for c in cols_all], "steps": args.steps,
                 "ms_per_step": 1e3 * cols_elapsed / args.steps, "allgather_ms_per_step": 1e3 * cols_gather / args.steps,
                 "allgather_bytes_per_rank_out": 32 * nn * ((NTT_COLUMNS + world - 1) // world) * world,
-                "backend": args.backend, "foreign_column_matches_local_transform": all(c["ok"] for c in cols_all),
+                "backend": args.backend, "collective": "bp_ntt_columns_allgather (in-place ncclAllGather under the C ABI)" if ntt_cols["c_path"]
+                else "dist.all_gather_columns (host-side gather of the gloo rehearsal)",
+                "foreign_column_matches_local_transform": all(c["ok"] for c in cols_all),
                 "same_on_all_ranks": len({c["digest"] for c in cols_all}) == 1,
                 "how": "column j of %d belongs to rank j mod N (dist.my_columns); per step every rank transforms its columns "
-                       "(bp_ntt_fr_device_async, one wait) and ONE all_gather_columns (a [columns per rank, 2^%d, 4] tensor over RCCL) "
+                       "(bp_ntt_fr_device_async, one wait) in its block of one [N x columns per rank, 2^%d, 4] buffer and ONE all-gather over RCCL "
                        "brings every column to every rank; allgather_ms = that collective alone, max over ranks" % (NTT_COLUMNS, args.ntt_log_n)}
         line.update(seams)
+        if pipelined:
+            line["pipelined"] = pipelined
         if sizes:
             line["other_sizes"] = sizes
         if strong:

@@ -54,6 +54,20 @@ def test_rust_bindings_follow_the_header():
         assert "pub const " + const + ";" in text, const
 
 
+def test_library_links_rccl_and_comm_calls_fail_loudly_without_a_context():
+    """the one-process-per-GPU collectives live UNDER the C ABI (capi_comm.hip): the shipped library is linked against librccl
+    (DT_NEEDED), and without a context every comm entry point is an error, not a no-op"""
+    import subprocess
+    dyn = subprocess.check_output(["readelf", "-d", _lib.SO_PATH], text=True)
+    assert re.search(r"NEEDED.*librccl\.so", dyn), dyn
+    lib = bp.load()
+    assert lib.bp_comm_init_rank(None, None, 0, 1) == -1 and lib.bp_comm_destroy(None) == -1
+    assert lib.bp_msm_g1_allgather(None, 0, 0, None, 0, 1, 0, None) == -1 and lib.bp_ntt_columns_allgather(None, None, 10, 1) == -1
+    assert lib.bp_comm_unique_id(None) == -1
+    text = open(os.path.join(ROOT, "include", "bp_msm_ntt.h")).read()
+    assert "#define BP_COMM_ID_BYTES %d" % _lib.COMM_ID_BYTES in text and "BP_ERR_COMM = -12" in text
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     if torch.cuda.is_available():

@@ -395,8 +395,14 @@ def test_table_memory_budget(ctx):
     sc = [rnd.randrange(Q) for _ in range(n)]
     want = closed_form(sc, 9, 4)
     assert ctx.msm(h, frs(sc)) == want                            # workspaces of this size exist before the device is filled
-    free_b, _ = torch.cuda.mem_get_info(ctx.device)
-    hog = torch.empty(free_b - (400 << 20), dtype=torch.uint8, device="cuda:%d" % ctx.device)      # leave 400 MiB: 2^18 x 16 rows x 128 B = 512 MiB does not fit
+    hog = []
+    for _ in range(4):                                            # leave ~400 MiB: 2^18 x 16 rows x 128 B = 512 MiB does not fit
+        free_b, _ = torch.cuda.mem_get_info(ctx.device)           # (asked again after each fill: memory freed by earlier tests of this
+        if free_b <= (450 << 20):                                 # process can reach the driver's free list late, and a single reading
+            break                                                 # taken too early left 900 MiB free behind the hog)
+        hog.append(torch.empty(free_b - (400 << 20), dtype=torch.uint8, device="cuda:%d" % ctx.device))
+        torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(ctx.device)[0] <= (450 << 20)
     try:
         info = ctx.srs_precompute(h, 0)
         assert info["bytes"] == 0 and info["windows"] == 0, info
@@ -410,4 +416,21 @@ def test_table_memory_budget(ctx):
     info = ctx.srs_precompute(h, 0)
     assert info["bytes"] > 0 and info["window_bits"] == 16
     assert ctx.msm(h, frs(sc)) == want
+    # a refused explicit width leaves the SRS as it was -- its 16-bit tables included (they used to be released before the check)
+    hog = []
+    for _ in range(4):
+        free_b, _ = torch.cuda.mem_get_info(ctx.device)
+        if free_b <= (450 << 20):
+            break
+        hog.append(torch.empty(free_b - (400 << 20), dtype=torch.uint8, device="cuda:%d" % ctx.device))
+        torch.cuda.synchronize()
+    try:
+        with pytest.raises(bp.BpError) as ei:
+            ctx.srs_precompute(h, 8)                                  # 32 rows = 1 GiB: does not fit in 400 MiB + the 512 MiB the old tables hold
+        assert ei.value.code == -10
+        assert ctx.srs_table_info(h)["window_bits"] == 16 and ctx.srs_table_info(h)["bytes"] == 16 * n * 128
+        assert ctx.msm(h, frs(sc)) == want and ctx.msm_stats()["tables"]
+    finally:
+        del hog
+        torch.cuda.empty_cache()
     ctx.srs_free(h)
