@@ -300,7 +300,10 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   uint32_t kb = 0;
   while ((1ull << kb) < total) kb++;
   uint32_t pb = 0;
-  while (pb < kb && (max_entries >> (pb + 1)) >= 12288) pb++;             // final runs of ~12-24 Ki entries
+  // final runs of ~12-24 Ki entries; per-window bucket sets (no tables) take runs of half that length: 2^9 buckets of 16 entries per run sort
+  // faster than 2^9 buckets of 32 (tail 0.84 -> 0.80 ms at 2^20, 0.83 -> 0.80 at 2^18, 0.63 -> 0.60 at 2^16: tools/part_bits_probe.sh, round 5)
+  const uint64_t run_min = table_c ? 12288 : 6144;
+  while (pb < kb && (max_entries >> (pb + 1)) >= run_min) pb++;
   pb = knob_u32("BP_MSM_RADIX_BITS", pb, 0, 16);
   if (pb + MSM_HIST_LOG < kb) pb = kb - MSM_HIST_LOG;                   // a final run's buckets must fit one LDS histogram
   if (pb > kb) pb = kb;

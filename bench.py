@@ -645,9 +645,10 @@ def main():
         def row_of(j):
             return (j % world) * per_rank_cols + j // world
 
-        for j in mine_j:
-            big[row_of(j)].copy_(synthetic(nn, 0xC0100000 + 977 * j).view(nn, 4))
-        torch.cuda.synchronize()                                # the copies run on torch's stream, the transforms on the library's
+        torch.cuda.synchronize()                                # the zero fill runs on torch's stream, the library writes on its own
+        for j in mine_j:                                        # generated in place (a temporary per column would be recycled by torch's
+            ctx.synthetic_scalars_device(big[row_of(j)].data_ptr(), nn, 0xC0100000 + 977 * j)      # allocator under a copy still in flight)
+        ctx.synchronize()
 
         def cols_step():
             for j in mine_j:

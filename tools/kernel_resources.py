@@ -14,15 +14,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def code_object(so, tmp):
-    """the gfx950 code object embedded in the host library (.hip_fatbin section -> clang-offload-bundler)"""
+def code_objects(so, tmp):
+    """the gfx950 code objects embedded in the host library: .hip_fatbin holds one clang offload bundle per translation unit"""
     fat = os.path.join(tmp, "fat.bin")
     subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", so, fat])
-    targets = subprocess.check_output([os.path.join(LLVM, "clang-offload-bundler"), "--list", "--type=o", "--input=" + fat], text=True).split()
-    tgt = [t for t in targets if "gfx950" in t][0]
-    co = os.path.join(tmp, "dev.co")
-    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=" + tgt, "--input=" + fat, "--output=" + co])
-    return co
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    out = []
+    for i, a in enumerate(starts):
+        piece = os.path.join(tmp, "bundle%d.bin" % i)
+        open(piece, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        targets = subprocess.check_output([os.path.join(LLVM, "clang-offload-bundler"), "--list", "--type=o", "--input=" + piece], text=True).split()
+        tgt = [t for t in targets if "gfx950" in t]
+        if not tgt:
+            continue
+        co = os.path.join(tmp, "dev%d.co" % i)
+        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=" + tgt[0], "--input=" + piece, "--output=" + co])
+        out.append(co)
+    return out
 
 
 def kernels(co):
@@ -52,7 +62,7 @@ def main():
     ap.add_argument("--out")
     args = ap.parse_args()
     with tempfile.TemporaryDirectory() as tmp:
-        ks = [k for k in kernels(code_object(args.so, tmp)) if args.filter in k["name"]]
+        ks = [k for co in code_objects(args.so, tmp) for k in kernels(co) if args.filter in k["name"]]
     ks.sort(key=lambda k: k["name"])
     lines = ["%-72s %5s %5s %7s %7s %8s %7s" % ("kernel (" + os.path.basename(args.so) + ")", "vgpr", "sgpr", "v.spill", "s.spill", "scratchB", "ldsB")]
     for k in ks:
