@@ -71,7 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--group-legs-timeout", type=int, default=240, help="seconds after which a bp_init_multi leg's child process is killed (its entry then says so)")
     ap.add_argument("--prove-log-n", type=int, default=20, help="gates of the synthetic circuit of the proofs/s leg = 2^prove_log_n (0 = skip)")
     ap.add_argument("--prove-reps", type=int, default=3)
-    ap.add_argument("--prove-streams", type=int, default=2, help="concurrent provers per GPU in the proofs/s throughput figure")
+    ap.add_argument("--prove-streams", type=int, default=3, help="concurrent provers per GPU in the proofs/s throughput figure "
+                    "(measured on one MI355X at 2^20 gates, tools/defaults_sanity.sh: 1 -> 33.5, 2 -> 35.4, 3 -> 36.2, 4 -> 36.3 proofs/s)")
     ap.add_argument("--other-sizes", type=int, nargs="*", default=[16, 24], help="log2 sizes also measured at N = 1 (MSM with tables + NTT)")
     ap.add_argument("--no-tables", action="store_true", help="headline = MSM on the raw SRS, no fixed-base window tables")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
