@@ -65,6 +65,15 @@ static void make_ntt_plan(NttPlan& plan, uint32_t k) {
     // an override must still fit the 160 KiB of LDS (tile rows x (columns + pad) + stage twiddles, 36 B each)
     if ((((size_t)1 << plan.l[i]) * ((1u << plan.cl[i]) + 1) + ntt_tw_slots(plan.l[i]) + 2) * N29 * 4 + 16 > 160 * 1024) plan.cl[i] = ntt_tile_cols_log(plan.l[i]);
   }
+  // three passes of widths (a, a, a - 1) with 8-column tiles everywhere (a <= 7: 2^20 = 7 + 7 + 6): the short digit goes in the MIDDLE --
+  // the last pass pays no inter-pass twiddle product, so it is the cheapest place for a stage: 0.148 against 0.152 ms at 2^20, three alternating
+  // rounds (profiles/r05_ntt_order_ab.txt); 2^22 (8, 7, 7) and 2^23 (8, 8, 7) show no difference between the orders and keep theirs
+  if (plan.P == 3 && plan.l[0] <= 7 && plan.l[0] == plan.l[1] && plan.l[2] + 1 == plan.l[1]) {
+    const uint32_t t = plan.l[1];
+    plan.l[1] = plan.l[2];
+    plan.l[2] = t;
+    for (uint32_t i = 1; i < 3; i++) plan.cl[i] = ntt_tile_cols_log(plan.l[i]);
+  }
   // experiment knob: BP_NTT_SPLIT="k:l1,l2,l3" replaces the digit widths of one size (widths must add up to k, each <= 10)
   if (const char* e = knob("BP_NTT_SPLIT")) {
     unsigned kk = 0, a = 0, b = 0, c = 0;
