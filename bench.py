@@ -67,6 +67,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-seams", action="store_true")
+    ap.add_argument("--skip-pipelined", action="store_true", help="no three-commitments-in-flight leg (its overlapping kernels would inflate the "
+                                                                   "per-kernel averages of a rocprofv3 --kernel-trace run of the serial legs)")
     ap.add_argument("--skip-group-legs", action="store_true", help="N > 1: do not run the two bp_init_multi legs (group_commit, one proof over all GPUs)")
     ap.add_argument("--group-legs-timeout", type=int, default=240, help="seconds after which a bp_init_multi leg's child process is killed (its entry then says so)")
     ap.add_argument("--prove-log-n", type=int, default=20, help="gates of the synthetic circuit of the proofs/s leg = 2^prove_log_n (0 = skip)")
@@ -540,7 +542,7 @@ def main():
     # runs them on the context's lanes, so that one pipeline's sort and tail overlap another's accumulation.  Per step: three 2^log_n-scalar
     # vectors against the same resident SRS + tables, all three results on the host; every result checked against its closed form.
     pipelined = None
-    if world == 1 and not args.no_tables:
+    if world == 1 and not args.no_tables and not args.skip_pipelined:
         setup = bp.Setup(srs, ctx, tables=False)                       # wraps the resident handle (its tables exist already)
         vecs = [scal] + [synthetic(n, 0x9199000 + 131 * j) for j in (1, 2)]
         polys = [bp.DevicePolynomial(v.view(n, 4), bp.BASIS_MONOMIAL, ctx) for v in vecs]

@@ -23,7 +23,7 @@ cd /tmp
 } > $P/${TAG}_ubench_valu_floor.txt 2>&1
 # 1. the weak-scaling legs alone (2^20 MSM with and without tables + 2^20 NTT): msm_accumulate's average here is the bench line's kernel_ms
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt_weak -o b -- python3 $R/bench.py --steps 20 --warmup 5 --skip-cpu --prove-log-n 0 \
-  --other-sizes --skip-seams --strong-log-n 0 > $P/${TAG}_bench_weak_under_rocprof.json 2> $O/${TAG}_kt_weak.err
+  --other-sizes --skip-seams --skip-pipelined --strong-log-n 0 > $P/${TAG}_bench_weak_under_rocprof.json 2> $O/${TAG}_kt_weak.err
 # 2. the 2^24 legs (strong scaling at N = 1: MSM with the auto table width + NTT)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_kt_strong -o b -- python3 $R/tools/run_msm.py --log-n 24 --reps 4 --tables 0 --ntt-log-n 24 \
   > $O/${TAG}_kt_strong.log 2>&1
