@@ -630,6 +630,35 @@ def main():
     ntt_ok = ntt_spot_check(vec, args.ntt_log_n)
     assert ntt_ok, "NTT spot check failed"
     ntt = timed_ntt(vec, args.ntt_log_n, args.steps, args.warmup)
+    # the same transform as a BATCH of independent columns in one call (grid.y = column): what the prover issues (a, b, c, PI in round 1; the
+    # coset evaluations of round 3) and what the north star's "NTT by independent columns" shards -- the per-pass ramp is paid once per batch
+    ntt_batch = None
+    if world == 1 and nn * 8 * 32 <= (8 << 30):
+        NB = 8
+        cols8 = torch.empty((NB, nn, 4), dtype=torch.int64, device=dev)
+        for j in range(NB):
+            ctx.synthetic_scalars_device(cols8[j].data_ptr(), nn, 0xBA7C0000 + 31 * j)
+        first = cols8[3].clone()
+        torch.cuda.synchronize()
+        ctx.ntt_device(first.data_ptr(), args.ntt_log_n)                       # column 3 alone = column 3 of the batch
+        ctx.ntt_device(cols8.data_ptr(), args.ntt_log_n, batch=NB)
+        torch.cuda.synchronize()
+        batch_ok = bool(torch.equal(cols8[3], first))
+        assert batch_ok, "batched NTT differs from the single transform"
+        for _ in range(max(1, args.warmup)):
+            ctx.ntt_device_async(cols8.data_ptr(), args.ntt_log_n, batch=NB)
+        ctx.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.ntt_device_async(cols8.data_ptr(), args.ntt_log_n, batch=NB)
+        ctx.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        ntt_batch = {"columns": NB, "value": NB * nn * args.steps / dt, "unit": "elements/s", "ms_per_column": 1e3 * dt / (NB * args.steps),
+                     "kernel_ms_per_batch": float(ctx.ntt_stats()["device_ms"]), "column_matches_single_transform": batch_ok,
+                     "how": "bp_ntt_fr_device_async(batch = %d): eight independent 2^%d-element columns per launch" % (NB, args.ntt_log_n)}
+        del cols8, first
 
     # ---------------------------------------------------------------- NTT columns over the ranks + ONE all-gather (north_star: "NTT by independent
     # columns across the GPUs with a single RCCL all-gather"; callers: the 23 transforms of prover.rs:386-450, utils.rs:106-129).  Column j
@@ -906,6 +935,7 @@ def main():
                     "kernel_le_step": ntt["kernel_le_step"], "spot_check": ntt_ok,
                     "how": "steps enqueued back to back on the context's stream (bp_ntt_fr_device_async), one wait at the end; "
                            "ms_per_blocking_call = the same transform through bp_ntt_fr_device, which waits for the stream every call",
+                    "batched_columns": ntt_batch,
                     "roofline": ntt_roofline(nn, ntt["dev_ms"] * 1e-3, ntt["passes"], "ntt_2p%d" % args.ntt_log_n)},
             "result_sha": hashlib.sha256(head["result"]).hexdigest()[:16],
             "per_rank": per_rank,
