@@ -289,7 +289,21 @@ int ctx_create(bp_ctx** out, int device_id) {
   bp_ctx* ctx = new bp_ctx();
   ctx->device = device_id;
   hipError_t se;
-  if (knob_u32("BP_ACC_LOW_PRIORITY", 0, 0, 1)) {         // experiment: tails on high-priority streams, accumulations on low-priority ones
+  if (const uint32_t keep = knob_u32("BP_ACC_CU_KEEP", 0, 1, 31)) {
+    // experiment: msm_accumulate on a stream whose CU mask leaves one CU in every (keep + 1) free for the other streams' kernels (a
+    // RESERVATION, where priorities and generations only reorder what waits): hipExtStreamCreateWithCUMask, thinning pattern repeated
+    // over 320 mask bits so that it does not depend on how the runtime numbers the CUs of the 8 XCDs
+    uint32_t mask[10];
+    for (int w = 0; w < 10; w++) {
+      mask[w] = 0;
+      for (int b = 0; b < 32; b++)
+        if ((uint32_t)(w * 32 + b) % (keep + 1) != keep) mask[w] |= 1u << b;
+    }
+    se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipExtStreamCreateWithCUMask(&ctx->acc_stream, 10, mask);
+    for (auto& e : ctx->acc_ev)
+      if (se == hipSuccess) se = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  } else if (knob_u32("BP_ACC_LOW_PRIORITY", 0, 0, 1)) {         // experiment: tails on high-priority streams, accumulations on low-priority ones
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least urgent (numerically greatest), hi = most urgent
     se = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi);
