@@ -354,7 +354,7 @@ int side_ctx_get(bp_ctx* ctx, bp_ctx** out) {
 }  // namespace bp
 
 
-const char* bp_version(void) { return EXPERIMENT_BUILD ? "bp_msm_ntt 0.3 (gfx950) +experiment" : "bp_msm_ntt 0.3 (gfx950)"; }
+const char* bp_version(void) { return EXPERIMENT_BUILD ? "bp_msm_ntt 0.4 (gfx950) +experiment" : "bp_msm_ntt 0.4 (gfx950)"; }
 
 int bp_init(bp_ctx** out, int device_id) {
   if (!out) return BP_ERR_INVALID_ARG;

@@ -57,6 +57,21 @@ class Context {
     return c;
   }
   int shards() const { return bp_ctx_devices(ctx_, nullptr, 0); }
+  // One process per GPU: rank 0 makes the 128-byte id, the host carries it to the other ranks, every rank joins.
+  // The communicator (RCCL) lives inside the library's context; Setup::commit_over_ranks then is one call.
+  static std::array<uint8_t, BP_COMM_ID_BYTES> unique_id() {
+    std::array<uint8_t, BP_COMM_ID_BYTES> id{};
+    int rc = bp_comm_unique_id(id.data());
+    if (rc != BP_OK) throw Panic(rc, "bp_comm_unique_id failed");
+    return id;
+  }
+  void join_ranks(const std::array<uint8_t, BP_COMM_ID_BYTES>& id, int rank, int world) { check(bp_comm_init_rank(ctx_, id.data(), rank, world), "join_ranks"); }
+  void leave_ranks() { check(bp_comm_destroy(ctx_), "leave_ranks"); }
+  int world() const {
+    int w = 0;
+    bp_comm_info(ctx_, nullptr, &w);
+    return w;
+  }
 
  private:
   static std::vector<int> env_devices() {
@@ -253,6 +268,21 @@ class Setup {
   G1 commit(const Polynomial& p) const {                                                 // setup.rs:32-37
     G1 out{};
     ctx_->check(bp_commit(ctx_->raw(), handle_, p.values.data(), p.values.size(), (int)p.basis, BP_FR_MONT, out.data()), "commit");
+    return out;
+  }
+  // this rank's point range of a larger SRS (one process per GPU): the points the rank keeps resident
+  static Setup from_points(const std::vector<G1>& points, Context& c = Context::global(), bool tables = true) {
+    uint64_t h = 0;
+    c.check(bp_srs_load(c.raw(), points.empty() ? nullptr : points[0].data(), points.size(), &h), "from_points");
+    if (tables) (void)bp_srs_precompute(c.raw(), h, 0);
+    return Setup(h, c);
+  }
+  // Setup::commit over ALL ranks of the context's communicator: `slice` holds the coefficients of this rank's point range; every rank
+  // receives the same commitment (bp_msm_g1_allgather: one ncclAllGather of the ranks' partial-sum records under the C ABI)
+  G1 commit_over_ranks(const Polynomial& slice) const {
+    if (slice.basis != Basis::Monomial) throw Panic(BP_ERR_BASIS, "commit: polynomial not in the Monomial basis (setup.rs:34)");
+    G1 out{};
+    ctx_->check(bp_msm_g1_allgather(ctx_->raw(), handle_, 0, slice.values.data(), slice.values.size(), BP_FR_MONT, 0, out.data()), "commit_over_ranks");
     return out;
   }
 

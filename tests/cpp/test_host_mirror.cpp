@@ -142,6 +142,24 @@ int main(int argc, char** argv) {
     CHECK(panics([&] { BucketMSM::bucket_msm({pts[0]}, {S(13)}, 256, 0); }, BP_ERR_INVALID_ARG));
     CHECK(panics([&] { BucketMSM::bucket_msm({pts[0]}, {S(13)}, 300, 4); }, BP_ERR_INVALID_ARG));
   }
+  // ---- one process per GPU through the library's own collective: a world of ONE rank is what a one-GPU box runs.
+  // The rank holds the whole SRS as "its point range"; the commitment over the ranks must be the commitment.
+  {
+    Context rank_ctx(0);                                                                           // a plain context of its own: one communicator per context
+    Setup s2 = Setup::generate_srs(8, le(2));
+    auto pts = s2.powers_of_x();
+    CHECK(rank_ctx.world() == 0);
+    CHECK(panics([&] { Setup::from_points(pts, rank_ctx).commit_over_ranks(mono({S(1)})); }, BP_ERR_INVALID_ARG));   // no communicator yet
+    rank_ctx.join_ranks(Context::unique_id(), 0, 1);
+    CHECK(rank_ctx.world() == 1);
+    Setup shard = Setup::from_points(pts, rank_ctx);
+    Polynomial f = mono({S(3), S(1), S(4), S(1), S(5), S(9), S(2), S(6)});
+    CHECK(shard.commit_over_ranks(f) == s2.commit(f));
+    CHECK(shard.commit_over_ranks(mono({S(0), S(1)})) == pts[1]);
+    CHECK(panics([&] { shard.commit_over_ranks(Polynomial({S(1)}, Basis::Lagrange)); }, BP_ERR_BASIS));
+    rank_ctx.leave_ranks();
+    CHECK(rank_ctx.world() == 0);
+  }
   std::printf("host mirror ok\n");
   return 0;
 }
