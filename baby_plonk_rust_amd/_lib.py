@@ -20,10 +20,17 @@ SO_PATH = _choice if _choice.endswith(".so") else os.path.join(_HERE, "libbp_msm
 
 def _is_experiment_build():
     """what the library itself says (bp_version() ends in "+experiment" for -DBP_EXPERIMENT builds), so that a library named by path
-    is classified by its contents, not by the spelling of the environment value; bp_version needs no GPU"""
+    is classified by its contents, not by the spelling of the environment value; bp_version needs no GPU.
+    torch is imported above, so the loader has already mapped torch's libamdhip64 / librccl and reuses them for this library's
+    DT_NEEDED entries of the same SONAME.  A library that exists but cannot be loaded here (librccl or HIP unresolvable on a box without
+    ROCm) must not break `import baby_plonk_rust_amd` for code that never calls load(): classified by the environment value then, and
+    load() raises the loader's error when it is really needed."""
     if not os.path.exists(SO_PATH):
         return _choice == "exp"
-    fn = C.CDLL(SO_PATH).bp_version
+    try:
+        fn = C.CDLL(SO_PATH).bp_version
+    except OSError:
+        return _choice == "exp"
     fn.restype = C.c_char_p
     return b"+experiment" in fn()
 
@@ -84,6 +91,8 @@ SIGNATURES = {
     "bp_comm_unique_id": (_int, [_vp]),
     "bp_comm_init_rank": (_int, [_vp, _vp, _int, _int]),
     "bp_comm_info": (_int, [_vp, _pp(_int), _pp(_int)]),
+    "bp_comm_set_timeout_ms": (_int, [_vp, _u32]),
+    "bp_comm_stats": (_int, [_vp, _pp(_u64), _pp(_u32)]),
     "bp_comm_destroy": (_int, [_vp]),
     "bp_msm_g1_allgather": (_int, [_vp, _u64, _sz, _vp, _sz, _int, _int, _vp]),
     "bp_comm_last_exchange_ms": (_int, [_vp, _pp(C.c_float)]),

@@ -226,6 +226,16 @@ class Context:
     def comm_destroy(self):
         self.check(self._lib.bp_comm_destroy(self._h), "bp_comm_destroy")
 
+    def comm_set_timeout_ms(self, ms):
+        """bound of every wait behind a collective and of ncclCommInitRank (default 120 000 ms; 0 = none): when it expires the
+        communicator is aborted and the call returns BP_ERR_COMM -- an error, not a stall"""
+        self.check(self._lib.bp_comm_set_timeout_ms(self._h, int(ms)), "bp_comm_set_timeout_ms")
+
+    def comm_stats(self):
+        n, ms = C.c_uint64(), C.c_uint32()
+        self.check(self._lib.bp_comm_stats(self._h, C.byref(n), C.byref(ms)), "bp_comm_stats")
+        return {"collectives": n.value, "timeout_ms": ms.value}
+
     def msm_allgather(self, handle, scalars=None, first=0, fmt=FR_MONT, device_ptr=None, n=None):
         """sum over ALL ranks' (point, scalar) pairs (bp_msm_g1_allgather): record -> ONE ncclAllGather -> device pre-sum -> one D2H"""
         out = np.zeros(96, dtype=np.uint8)

@@ -160,9 +160,16 @@ struct bp_ctx {
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 0;
   hipEvent_t comm_ev[2] = {nullptr, nullptr};      // record complete / gathered, summed and copied
-  void* comm_host = nullptr;                       // pinned landing area of bp_msm_g1_allgather's device-to-host copy
+  // every buffer a collective needs exists from bp_comm_init_rank on (nothing between "called" and "joined the collective" can run
+  // out of memory): comm_dev = mine | summed | gathered[world] records, then the agreement words (mine | all[world]); comm_host = the
+  // pinned mirror (world records + the agreement words)
+  uint8_t* comm_dev = nullptr;
+  void* comm_host = nullptr;
   size_t comm_host_cap = 0;
   float comm_exchange_ms = 0;
+  uint32_t comm_timeout_ms = 120000;               // bound of every wait on a collective and of ncclCommInitRank (bp_comm_set_timeout_ms; 0 = none)
+  uint64_t comm_collectives = 0;                   // collectives this context has enqueued on its communicator(s) (bp_comm_stats)
+  bool comm_init_stuck = false;                    // an ncclCommInitRank of this context ran into the bound: its helper thread is still inside RCCL
   bool gen_table_ready = false;                    // srs_generate_run: the generator's multiples were built into gen_table_ptr
   const void* gen_table_ptr = nullptr;
   void* pinned = nullptr;                          // small pinned staging buffer (window sums etc.)
@@ -249,6 +256,8 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
                     uint32_t table_c, size_t table_stride, int slot, void* d_blob, MsmPending* out);
 int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out);
 int msm_blobs_sum_device_run(bp_ctx* ctx, const void* d_blobs, size_t n_blobs, void* d_out, bool wait = true);
+int msm_blob_poisoned(const uint8_t* blobs, size_t n_blobs, uint32_t* rank);
+int msm_blob_poison_run(bp_ctx* ctx, void* d_blob, int err, uint32_t rank);
 int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out);
 int msm_run(bp_ctx* ctx, const g1_affine28* d_points28, size_t n, const fr_t* d_scalars, int fmt, uint32_t table_c, size_t table_stride,
             g1_proj* host_out);

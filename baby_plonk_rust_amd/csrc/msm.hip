@@ -674,6 +674,7 @@ int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out) {
     MsmBlobHeader h;
     memcpy(&h, blobs + i * BP_MSM_BLOB_BYTES, sizeof h);
     if (h.magic != MSM_BLOB_MAGIC || h.n_planes > (uint32_t)MSM_MAX_WINDOWS) return BP_ERR_INVALID_ARG;
+    if (h.err != 0) return h.err < 0 && h.err >= BP_ERR_COMM ? h.err : BP_ERR_INVALID_ARG;       // a rank's poisoned record: its code for every rank (msm_blob_poisoned names the rank)
     // the Horner passes below index the slots by (Wr, c): a record whose header does not describe its own slot count (another
     // library version on a peer rank, a truncated gather) is rejected here instead of being read past its end
     if (h.n_planes != 0) {
@@ -705,6 +706,31 @@ int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out) {
     g1_add(total, total, part);
   }
   *out = total;
+  return BP_OK;
+}
+
+// first poisoned record among n_blobs host records: its error code (0: none) and the rank that wrote it
+int msm_blob_poisoned(const uint8_t* blobs, size_t n_blobs, uint32_t* rank) {
+  for (size_t i = 0; i < n_blobs; i++) {
+    MsmBlobHeader h;
+    memcpy(&h, blobs + i * BP_MSM_BLOB_BYTES, sizeof h);
+    if (h.magic == MSM_BLOB_MAGIC && h.err != 0) {
+      if (rank) *rank = h.err_rank;
+      return h.err < 0 && h.err >= BP_ERR_COMM ? h.err : BP_ERR_INVALID_ARG;
+    }
+  }
+  return 0;
+}
+
+// this rank's record when its MSM failed before the collective: header only, on the context's stream
+int msm_blob_poison_run(bp_ctx* ctx, void* d_blob, int err, uint32_t rank) {
+  MsmBlobHeader hdr;
+  memset(&hdr, 0, sizeof hdr);
+  hdr.magic = MSM_BLOB_MAGIC;
+  hdr.err = err;
+  hdr.err_rank = rank;
+  hipLaunchKernelGGL(msm_write_blob, dim3(1), dim3(64), 0, ctx->stream, (const proj28_slot*)nullptr, hdr, (uint8_t*)d_blob);
+  BP_HIP(ctx, hipGetLastError());
   return BP_OK;
 }
 

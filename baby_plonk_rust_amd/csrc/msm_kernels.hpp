@@ -1035,9 +1035,14 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
 // ---------------------------------------------------------------- blob (one process per GPU)
 // bp_msm_g1_blob_device: the window sums / bit planes of one rank's MSM as a self-describing record in HBM, so the ranks'
 // records can be all-gathered on the device and combined after a single device-to-host copy (bp_msm_blobs_combine).
+// err / err_rank: a rank whose MSM failed BEFORE the collective (unknown handle, out of memory, a launch error) still takes part in
+// the all-gather with a POISONED record -- magic set, n_planes = 0, err = its negative BP_ERR_* code, err_rank = its rank -- so that no
+// peer is left waiting in ncclAllGather and every rank returns the same error (capi_comm.hip; the reference panics, it never blocks).
 struct MsmBlobHeader {
   uint32_t magic, c, Wr, n_planes, tables, status, entries;
-  uint32_t pad[9];
+  int32_t err;
+  uint32_t err_rank;
+  uint32_t pad[7];
 };
 static_assert(sizeof(MsmBlobHeader) == 64, "blob header");
 constexpr uint32_t MSM_BLOB_MAGIC = 0x424d5042u;      // "BPMB"
@@ -1062,22 +1067,27 @@ __global__ void __launch_bounds__(64) msm_blob_sum(const uint8_t* __restrict__ b
                                                    uint8_t* __restrict__ out) {
   const MsmBlobHeader h0 = *reinterpret_cast<const MsmBlobHeader*>(blobs);
   bool same = h0.magic == MSM_BLOB_MAGIC;
-  uint32_t status = 0, entries = 0;
+  uint32_t status = 0, entries = 0, err_rank = 0;
+  int32_t err = 0;
   for (uint32_t k = 0; k < n_blobs; k++) {
     const MsmBlobHeader h = *reinterpret_cast<const MsmBlobHeader*>(blobs + (size_t)k * blob_bytes);
     same = same && h.magic == h0.magic && h.c == h0.c && h.Wr == h0.Wr && h.n_planes == h0.n_planes && h.tables == h0.tables;
     status |= h.status;
     entries += h.entries;
+    if (err == 0 && h.magic == MSM_BLOB_MAGIC && h.err != 0) { err = h.err; err_rank = h.err_rank; }      // the lowest poisoned rank speaks for all
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     MsmBlobHeader ho = h0;
-    ho.magic = same ? MSM_BLOB_MAGIC : 0u;
+    ho.magic = (same || err != 0) ? MSM_BLOB_MAGIC : 0u;     // a poisoned gather is reported from this one record: nothing else needs to travel
     ho.status = status;
     ho.entries = entries;
+    ho.err = err;
+    ho.err_rank = err_rank;
+    if (err != 0) ho.n_planes = 0;
     *reinterpret_cast<MsmBlobHeader*>(out) = ho;
   }
   const uint32_t slot = blockIdx.x * (64 / COOP) + threadIdx.x / COOP;
-  if (!same || slot >= h0.n_planes) return;                  // uniform over a cooperative group
+  if (!same || err != 0 || slot >= h0.n_planes) return;      // uniform over a cooperative group
   const proj28_slot* first = reinterpret_cast<const proj28_slot*>(blobs + sizeof(MsmBlobHeader)) + slot;
   g1_proj28 acc = load_proj28(first);
   for (uint32_t k = 1; k < n_blobs; k++) {

@@ -53,15 +53,66 @@ def combine_partials(partial144, device=None, group=None):
     return api.sum_partials(allgather_partials(partial144, device, group))
 
 
+def join_library_communicator(ctx, group=None, device=None):
+    """Give `ctx` the library's own RCCL communicator over the ranks of `group` (bp_comm_unique_id on rank 0, the 128 bytes carried by
+    torch.distributed, bp_comm_init_rank everywhere).  Returns True when this call created it, False when every rank's context already
+    had a matching one.  EVERY step is agreed on before the next one, and every rank issues the same collectives in the same order
+    on every path -- a rank that fails at some step says so inside the next collective instead of staying away from it (ADVICE r05:
+    a per-rank try/except around a collective leaves the other ranks waiting).  Any disagreement or failure raises on ALL ranks."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = device if device is not None else _backend_device(ctx.device, group)
+
+    def agree_min(values):
+        t = torch.tensor(values, dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return [int(v) for v in t.cpu()]
+
+    # step 1: which contexts already hold a communicator of this shape?  1 = matching, 0 = none, -1 = another shape
+    have = ctx.comm_info()
+    mine = 1 if have == (rank, world) else (0 if have[1] == 0 else -1)
+    lo, neg_hi = agree_min([mine, -mine])
+    if lo < 0:
+        raise RuntimeError("join_library_communicator: some rank's context holds a communicator of another shape (here: rank %d of %d)" % have)
+    if lo == 1:
+        return False
+    if -neg_hi == 1:
+        raise RuntimeError("join_library_communicator: some ranks' contexts already have a communicator and others have none")
+    # step 2: rank 0 makes the id; its failure travels as None through the SAME broadcast every rank takes part in
+    box, id_error = [None], None
+    if rank == 0:
+        try:
+            box[0] = api.Context.comm_unique_id()
+        except Exception as e:
+            id_error = e
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group, device=dev)
+    if box[0] is None:
+        raise RuntimeError("join_library_communicator: rank 0 could not create the communicator id (%r)" % (id_error,))
+    # step 3: ncclCommInitRank on every rank (bounded inside the library: bp_comm_set_timeout_ms), then agree on the outcome
+    ok, init_error = 1, None
+    try:
+        ctx.comm_init_rank(box[0], rank, world)
+    except Exception as e:
+        ok, init_error = 0, e
+    if agree_min([ok])[0] != 1:
+        if ok:
+            ctx.comm_destroy()
+        raise RuntimeError("join_library_communicator: bp_comm_init_rank failed on some rank (here: %r)" % (init_error,))
+    return True
+
+
 class ShardedMsm:
-    """The MSM path of one rank: the rank's partial sums stay in HBM (bp_msm_g1_blob_device_async), ONE all-gather
-    of the records over RCCL/xGMI, the device-side pre-sum, ONE device-to-host copy, host combine (bp_msm_blobs_combine).
+    """The MSM path of one rank: the rank's partial sums stay in HBM, ONE all-gather of the records over RCCL/xGMI, the
+    device-side pre-sum, ONE device-to-host copy, host combine.
     Under the "nccl" backend all of that is ONE call into the library (bp_msm_g1_allgather, capi_comm.hip: the communicator lives in
-    the bp_ctx); under gloo (CPU rehearsals) the same steps are spelled out here with a host-side gather.
+    the bp_ctx) and there is no other path: the Python mirror and a Rust host that binds the C ABI run the same lines, and a
+    communicator that cannot be created is an error on every rank, not a silent detour (round 6; rounds 4-5 kept a torch all-gather
+    fallback -- with no world > 1 ever run it was not knowable which of the two a first real run would have timed).
+    Under gloo (CPU rehearsals of the control flow: RCCL refuses two ranks on one GPU) the same steps are spelled out here with a
+    host-side gather; without a process group the record goes straight to the host.
     Stream-ordered end to end: the library context is put on a torch stream owned by this object (bp_set_stream) and the record,
     the collective, the pre-sum and the copy are enqueued on it in that order -- the copy's is the only host wait of a call.
-    Buffers are allocated once.  `exchange_s`: GPU time from "record complete" to "gathered, summed and copied" (two events on
-    the stream).  close() (or garbage collection) gives the context its own stream back."""
+    `exchange_s`: GPU time from "record complete" to "gathered, summed and copied" (two events on the stream).
+    close() (or garbage collection) gives the context its own stream back."""
 
     def __init__(self, ctx, group=None):
         self.ctx, self.group = ctx, group
@@ -71,44 +122,20 @@ class ShardedMsm:
         ctx.set_stream(self.stream.cuda_stream)          # every later call on ctx is ordered on this stream
         self.collective = dist.is_initialized()          # under a launcher even a single rank goes through the collective
         self.on_gpu = self.collective and dist.get_backend(group) == "nccl"
-        # Under RCCL the exchange is the LIBRARY's (bp_msm_g1_allgather: record -> ncclAllGather -> device pre-sum -> one D2H, all under
-        # the C ABI) -- the Python mirror and a Rust host that binds the C ABI run the same lines.  torch.distributed only carries the
-        # 128-byte communicator id from rank 0 to the others, once.  (gloo rehearsals keep the host-side gather below: RCCL refuses two
-        # ranks on one GPU.)
-        self.c_path, self.own_comm, self.c_path_error = False, False, None
-        if self.on_gpu:
-            rank = dist.get_rank(group)
-            ok = 1
-            try:
-                if ctx.comm_info()[1] == 0:
-                    box = [api.Context.comm_unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
-                                               device=self.gpu)
-                    ctx.comm_init_rank(box[0], rank, self.world)
-                    self.own_comm = True
-                if ctx.comm_info() != (rank, self.world):
-                    raise RuntimeError("the context's communicator is rank %d of %d, the process group says %d of %d"
-                                       % (ctx.comm_info() + (rank, self.world)))
-            except Exception as e:                       # no world > 1 has run yet: a failure here must cost the C path, not the job
-                ok, self.c_path_error = 0, repr(e)[:200]
-            flag = torch.tensor([ok], dtype=torch.int32, device=self.gpu)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)          # every rank takes the same path
-            self.c_path = bool(int(flag.item()))
-            if not self.c_path and self.own_comm and ctx.comm_info()[1]:
-                ctx.comm_destroy()
-                self.own_comm = False
-        with torch.cuda.stream(self.stream):
-            self.mine = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu)
-            self.gathered = torch.empty(self.world * _lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu if self.on_gpu else "cpu")
-            self.summed = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu)
-        # pinned landing area of the path's single D2H (a fresh pageable tensor per call cost ~30 us of the step)
-        self.host = torch.empty(max(self.world, 1) * _lib.MSM_BLOB_BYTES, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else None
-        self.record_done = torch.cuda.Event(enable_timing=True)
-        self.all_done = torch.cuda.Event(enable_timing=True)
+        # torch.distributed only carries the 128-byte communicator id from rank 0 to the others, once
+        self.c_path = self.on_gpu
+        self.own_comm = join_library_communicator(ctx, group, self.gpu) if self.on_gpu else False
+        if not self.c_path:
+            with torch.cuda.stream(self.stream):
+                self.mine = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device=self.gpu)
+            self.gathered = torch.empty(self.world * _lib.MSM_BLOB_BYTES, dtype=torch.uint8, device="cpu")
+            # pinned landing area of the record's D2H (a fresh pageable tensor per call cost ~30 us of the step)
+            self.host = torch.empty(_lib.MSM_BLOB_BYTES, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else None
+            self.record_done = torch.cuda.Event(enable_timing=True)
+            self.all_done = torch.cuda.Event(enable_timing=True)
         self.exchange_s = 0.0
         # The wait is bp_synchronize (the library polls its stream, which IS this torch stream): torch's Event.synchronize() came back
-        # ~90 us after the GPU had finished (tools/exchange_split.py: 2 786 us per 2^20-point step against 2 650 without the exchange).
-        # (no synchronize: the fills above and the first record are on the same stream)
+        # ~90 us after the GPU had finished (measured in round 4: 2 786 us per 2^20-point step against 2 650 without the exchange).
 
     def __call__(self, srs_handle_local, scalars_local=None, device_ptr=None, n=None, first=0):
         # another ShardedMsm on the same context (or its close()) may have moved the context to a different stream since __init__:
@@ -122,36 +149,22 @@ class ShardedMsm:
         self.ctx.msm_blob_device(srs_handle_local, self.mine.data_ptr(), scalars_local, first=first, device_ptr=device_ptr, n=n, wait=False)
         with torch.cuda.stream(self.stream):
             self.record_done.record()
-            one = self.host[:_lib.MSM_BLOB_BYTES]
-            if not self.collective:
-                one.copy_(self.mine, non_blocking=True)
-                self.all_done.record()
-                self.ctx.synchronize()                                                        # the only host wait (see __init__)
-                host = one
-            elif self.on_gpu:
-                dist.all_gather_into_tensor(self.gathered, self.mine, group=self.group)       # the path's single collective
-                self.ctx.msm_blobs_sum_device(self.gathered.data_ptr(), self.world, self.summed.data_ptr(), wait=False)     # equal layouts: one record
-                one.copy_(self.summed, non_blocking=True)                                     # the path's single D2H (22 KB)
-                self.all_done.record()
-                self.ctx.synchronize()                                                        # the only host wait (see __init__)
-                host = one
-                if int.from_bytes(host[:4].numpy().tobytes(), "little") == 0:                # layouts differ: all records to the host
-                    host = self.gathered.cpu()
-            else:
-                one.copy_(self.mine, non_blocking=True)
-                self.all_done.record()
-                self.ctx.synchronize()
-                dist.all_gather_into_tensor(self.gathered, one.clone(), group=self.group)
+            self.host.copy_(self.mine, non_blocking=True)
+            self.all_done.record()
+            self.ctx.synchronize()                                                            # the only host wait (see __init__)
+            if self.collective:                                                               # gloo: host-side gather of the records
+                dist.all_gather_into_tensor(self.gathered, self.host.clone(), group=self.group)
                 host = self.gathered
+            else:
+                host = self.host
         out = api.combine_blobs(host.numpy().tobytes())
-        self.exchange_s = 1e-3 * self.record_done.elapsed_time(self.all_done)      # GPU-side: record complete -> gathered, summed and copied
+        self.exchange_s = 1e-3 * self.record_done.elapsed_time(self.all_done)      # GPU-side: record complete -> copied
         return out
-
 
     def close(self):
         if getattr(self, "ctx", None) is not None and getattr(self.ctx, "_h", None):
             self.ctx.set_stream(None)                    # waits for the stream, then back to the context's own
-            if getattr(self, "c_path", False) and getattr(self, "own_comm", False):
+            if getattr(self, "own_comm", False) and self.ctx.comm_info()[1]:
                 self.ctx.comm_destroy()
         self.ctx = None
 

@@ -67,6 +67,13 @@ class Context {
   }
   void join_ranks(const std::array<uint8_t, BP_COMM_ID_BYTES>& id, int rank, int world) { check(bp_comm_init_rank(ctx_, id.data(), rank, world), "join_ranks"); }
   void leave_ranks() { check(bp_comm_destroy(ctx_), "leave_ranks"); }
+  // bound of every wait behind a collective and of join_ranks itself (ms; 0 = none): a missing or stuck rank becomes a Panic, not a stall
+  void set_rank_timeout_ms(uint32_t ms) { check(bp_comm_set_timeout_ms(ctx_, ms), "set_rank_timeout_ms"); }
+  uint64_t collectives() const {
+    uint64_t n = 0;
+    bp_comm_stats(ctx_, &n, nullptr);
+    return n;
+  }
   int world() const {
     int w = 0;
     bp_comm_info(ctx_, nullptr, &w);

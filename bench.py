@@ -77,6 +77,10 @@ def parse_args(argv=None):
                     "(measured on one MI355X at 2^20 gates, tools/defaults_sanity.sh: 1 -> 33.5, 2 -> 35.4, 3 -> 36.2, 4 -> 36.3 proofs/s)")
     ap.add_argument("--other-sizes", type=int, nargs="*", default=[16, 24], help="log2 sizes also measured at N = 1 (MSM with tables + NTT)")
     ap.add_argument("--no-tables", action="store_true", help="headline = MSM on the raw SRS, no fixed-base window tables")
+    ap.add_argument("--leg-timeout", type=int, default=900, help="under a launcher: seconds one leg may take before the rank reports which leg it was "
+                                                                  "stuck in and exits non-zero (the lines of the finished legs are out by then); 0 = no watchdog")
+    ap.add_argument("--comm-timeout-ms", type=int, default=120000, help="bound of every wait behind a library collective and of ncclCommInitRank "
+                                                                         "(bp_comm_set_timeout_ms): a missing or stuck rank is BP_ERR_COMM, not a stall")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the N > 1 control flow on a box with fewer GPUs than ranks)")
     return ap.parse_args(argv)
@@ -99,17 +103,23 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=ROOT)
-    line = None
+    # Rank 0 prints a COMPLETE line after the weak leg and again after every later leg (`legs_finished` grows, `provisional` turns false
+    # on the last one).  Each is relayed the moment it arrives: a hang or a kill in a later leg -- no world > 1 has ever run -- leaves the
+    # newest finished line in the caller's tail instead of nothing.
+    lines, final = 0, False
     for out in child.stdout:
         if out.startswith('{"metric"'):
-            line = out.strip()
+            lines += 1
+            final = '"provisional": false' in out
+            sys.stdout.write(out if out.endswith("\n") else out + "\n")
+            sys.stdout.flush()
         else:
             sys.stderr.write(out)
     rc = child.wait()
-    if rc != 0 or line is None:
-        sys.stderr.write("bench.py: the %d-rank run failed (exit code %d%s)\n" % (args.gpus, rc, "" if line else ", no result line"))
+    if rc != 0 or not final:
+        sys.stderr.write("bench.py: the %d-rank run failed (exit code %d; %d result line%s relayed, the last one %s)\n"
+                         % (args.gpus, rc, lines, "" if lines == 1 else "s", "final" if final else "provisional or missing"))
         return rc or 1
-    print(line, flush=True)
     return 0
 
 
@@ -424,8 +434,30 @@ def main():
         dist.all_gather_object(out, obj, group=ctl)
         return out
 
+    # ---------------------------------------------------------------- un-losable line + watchdog (N > 1 has never run on hardware)
+    # Under a launcher rank 0 prints a COMPLETE line after the weak leg and after every later leg; a leg that hangs costs that leg, the
+    # watchdog names it and ends the rank with a non-zero code (a fresh exit, never an exec), the launcher ends the others.
+    progress = {"leg": "start-up", "t": time.monotonic()}
+    if use_dist and args.leg_timeout > 0:
+        import threading
+
+        def watchdog():
+            while True:
+                time.sleep(5)
+                if time.monotonic() - progress["t"] > args.leg_timeout:
+                    sys.stderr.write("bench.py: rank %d spent more than %d s in the leg after '%s' -- giving up (the lines of the finished legs "
+                                     "have been printed)\n" % (rank, args.leg_timeout, progress["leg"]))
+                    sys.stderr.flush()
+                    os._exit(3)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+
     ctx = bp.Context(dev_index)
-    exchange = bpd.ShardedMsm(ctx)
+    ctx.comm_set_timeout_ms(args.comm_timeout_ms)
+    exchange = bpd.ShardedMsm(ctx)                     # under nccl: joins the library's communicator (every step agreed on by all ranks), or raises on all
+    # every leg's result; None / empty until the leg has run (the line is built from whatever is there)
+    pipelined = ntt = ntt_batch = ntt_cols = strong = group_commit = prove = None
+    seams, sizes, red, legs_done, cols_all_box = {}, {}, {}, [], [None]
 
     def timed_msm(srs, d_scal, n, steps, warmup):
         """W + K steps of: per-rank Pippenger on the resident shard, then (N > 1) the single all-gather of the ranks'
@@ -511,6 +543,156 @@ def main():
         ctx.synthetic_scalars_device(t.data_ptr(), count, (seed + GOLDEN * 8 * first) & MASK64)
         return t
 
+    def checkpoint(leg, **times):
+        """a leg has finished on this rank: max over ranks of its wall times (a collective -- every rank passes the same points in the same
+        order), then, under a launcher, rank 0 prints a COMPLETE line from the legs finished so far (`provisional`: true)"""
+        keys = sorted(times)
+        if keys:
+            red.update(zip(keys, max_over_ranks([times[k] for k in keys])))
+        legs_done.append(leg)
+        progress["leg"], progress["t"] = leg, time.monotonic()
+        if use_dist:
+            emit(final=False)
+
+    def emit(final):
+        per_rank = gather_objects({"rank": rank, "device": dev_index, "weak_accumulate_ms": head["acc_ms"], "weak_device_ms": head["dev_ms"],
+                                   "weak_exchange_ms": head["exchange_ms"],
+                                   "strong_points": strong["m"] if strong else 0, "strong_accumulate_ms": strong["r"]["acc_ms"] if strong else 0.0,
+                                   "strong_device_ms": strong["r"]["dev_ms"] if strong else 0.0,
+                                   "strong_exchange_ms": strong["r"]["exchange_ms"] if strong else 0.0})
+        progress["t"] = time.monotonic()
+        if rank == 0:
+            print(json.dumps(build_line(per_rank, final)), flush=True)
+
+    def build_line(per_rank, final):
+        elapsed, other_elapsed = red["elapsed"], red["other_elapsed"]
+        ntt_elapsed, prove_elapsed, prove_single = red.get("ntt_elapsed", 0.0), red.get("prove_elapsed", 0.0), red.get("prove_single", 0.0)
+        strong_elapsed, cols_elapsed, cols_gather = red.get("strong_elapsed", 0.0), red.get("cols_elapsed", 0.0), red.get("cols_gather", 0.0)
+        cols_all = cols_all_box[0]
+        stats = head["stats"]
+        units = world * n * args.steps
+        cfg_key = "2p%d_c%d%s" % (args.log_n, stats["window_bits"], "_tables" if stats["tables"] else "")
+        hbm, issue = msm_roofline(n, head["acc_ms"] * 1e-3, stats["mixed_adds"], stats["window_bits"], stats["tables"], "msm_accumulate_" + cfg_key)
+        line = {
+            "metric": "g1_msm_scalar_muls_per_s",
+            "baseline_metric": "G1 MSM scalar-muls/s + Fr NTT elements/s at 2^20/2^24; proof bit-exact",
+            "value": units / elapsed, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 limbs (381-bit Fp Montgomery, 255-bit Fr)", "data": "synthetic",
+            "config": {"workload": "2^%d-point BLS12-381 G1 MSM per GPU (global 2^%d x %d points, point-range shards, one RCCL all-gather "
+                                   "of the ranks' partial-sum records), SRS %s; + 2^%d Fr NTT per GPU; BASELINE configs[2] at N=1"
+                                   % (args.log_n, args.log_n, world,
+                                      "raw points only" if args.no_tables else "resident with its fixed-base window tables (Setup)", args.ntt_log_n),
+                       "msm_points_per_gpu": n, "window_bits": stats["window_bits"], "ntt_len_per_gpu": 1 << args.ntt_log_n,
+                       "srs_tables": {"used": stats["tables"], "window_bits": table_info["window_bits"], "windows": table_info["windows"],
+                                      "bytes": table_info["bytes"], "bytes_per_gpu": table_info["bytes"], "build_ms": 1e3 * table_build_s,
+                                      "build_s": table_build_s,
+                                      "note": "the headline is a FIXED-BASE MSM: T[w][i] = 2^(window_bits w) P_i built once per SRS outside the "
+                                              "timed region; value_without_tables is the same MSM on the raw points"},
+                       "value_without_tables": None if args.no_tables else units / other_elapsed,
+                       "parallelism": "point-range x%d" % world, "ranks": world, "backend": args.backend if use_dist else None,
+                       "msm_exchange": None if not use_dist else
+                       ("bp_msm_g1_allgather: record -> ncclAllGather -> device pre-sum -> one D2H, all under the C ABI (capi_comm.hip); the only "
+                        "path under nccl -- a communicator that cannot be created is an error on every rank; %d collectives enqueued by rank 0 so far, "
+                        "waits bounded at %d ms" % (ctx.comm_stats()["collectives"], ctx.comm_stats()["timeout_ms"])
+                        if exchange.c_path else "dist.ShardedMsm host-side gather (gloo rehearsal of the control flow)")},
+            # the headline is a FIXED-BASE MSM (the SRS of a Setup with its window tables resident); the reference-shaped figures beside it:
+            "value_without_tables": None if args.no_tables else units / other_elapsed,
+            "ms_per_step_without_tables": None if args.no_tables else 1e3 * other_elapsed / args.steps,
+            "first_commit_ms": None if args.no_tables else 1e3 * (table_build_s + elapsed / args.steps),
+            "uncached_seam_ms_per_call": seams["msm_uncached_seam"]["ms_per_call"] if "msm_uncached_seam" in seams else None,
+            "host_scalars_ms_per_step": seams["msm_host_scalars"]["ms_per_step"] if "msm_host_scalars" in seams else None,
+            "headline_note": "value = scalars resident in HBM against an SRS whose fixed-base tables (config.srs_tables) were built once outside "
+                             "the timed region; first_commit_ms = table build + one MSM; value_without_tables = the same MSM on raw points; "
+                             "uncached_seam_ms_per_call = bucket_msm(&[G1Projective], &[Scalar]) literally, nothing cached, PCIe inclusive",
+            "roofline": hbm,
+            "roofline_valu_issue": issue,
+            "msm_device_ms": head["dev_ms"],
+            "msm_accumulate_ms": head["acc_ms"],
+            "tail_ms": head["dev_ms"] - head["acc_ms"],
+            "tail_note": "device time of one MSM outside msm_accumulate: bucket sort (3 launches), fix-up, bit-plane tree, copies",
+            "register_only_rates_source": UBENCH["source"],
+            "equals_closed_form": weak_ok,
+            "exchange_ms": head["exchange_ms"],
+            ("msm_with_tables" if args.no_tables else "msm_without_tables"): {
+                "value": units / other_elapsed, "unit": "scalar-muls/s", "ms_per_step": 1e3 * other_elapsed / args.steps,
+                "device_ms": other["dev_ms"], "accumulate_ms": other["acc_ms"], "tail_ms": other["dev_ms"] - other["acc_ms"],
+                "window_bits": other["stats"]["window_bits"]},
+            "ntt": None if not ntt else {"metric": "fr_ntt_elements_per_s", "value": world * nn * args.steps / ntt_elapsed, "unit": "elements/s",
+                    "ms_per_step": 1e3 * ntt_elapsed / args.steps, "ms_per_blocking_call": ntt["blocking_ms"], "passes": ntt["passes"],
+                    "kernel_le_step": ntt["kernel_le_step"], "spot_check": ntt_ok,
+                    "how": "steps enqueued back to back on the context's stream (bp_ntt_fr_device_async), one wait at the end; "
+                           "ms_per_blocking_call = the same transform through bp_ntt_fr_device, which waits for the stream every call",
+                    "batched_columns": ntt_batch,
+                    "roofline": ntt_roofline(nn, ntt["dev_ms"] * 1e-3, ntt["passes"], "ntt_2p%d" % args.ntt_log_n)},
+            "result_sha": hashlib.sha256(head["result"]).hexdigest()[:16],
+            "per_rank": per_rank,
+            # under a launcher a complete line goes out after every leg: which legs this one holds, and whether more will follow
+            "legs_finished": list(legs_done), "provisional": not final,
+        }
+        if ntt_cols:
+            line["ntt_columns"] = {
+                "metric": "fr_ntt_elements_per_s", "value": NTT_COLUMNS * nn * args.steps / cols_elapsed, "unit": "elements/s", "n_gpus": world,
+                "columns": NTT_COLUMNS, "column_len": nn, "columns_per_rank": [c["columns"] for c in cols_all], "steps": args.steps,
+                "ms_per_step": 1e3 * cols_elapsed / args.steps, "allgather_ms_per_step": 1e3 * cols_gather / args.steps,
+                "allgather_bytes_per_rank_out": 32 * nn * ((NTT_COLUMNS + world - 1) // world) * world,
+                "backend": args.backend, "collective": "bp_ntt_columns_allgather (in-place ncclAllGather under the C ABI)" if ntt_cols["c_path"]
+                else "dist.all_gather_columns (host-side gather of the gloo rehearsal)",
+                "foreign_column_matches_local_transform": all(c["ok"] for c in cols_all),
+                "same_on_all_ranks": len({c["digest"] for c in cols_all}) == 1,
+                "how": "column j of %d belongs to rank j mod N (dist.my_columns); per step every rank transforms its columns "
+                       "(bp_ntt_fr_device_async, one wait) in its block of one [N x columns per rank, 2^%d, 4] buffer and ONE all-gather over RCCL "
+                       "brings every column to every rank; allgather_ms = that collective alone, max over ranks" % (NTT_COLUMNS, args.ntt_log_n)}
+        line.update(seams)
+        if pipelined:
+            line["pipelined"] = pipelined
+        if sizes:
+            line["other_sizes"] = sizes
+        if strong:
+            r, k = strong["r"], strong["k"]
+            s_hbm, s_issue = msm_roofline(strong["m"], r["acc_ms"] * 1e-3, r["stats"]["mixed_adds"], r["stats"]["window_bits"], r["stats"]["tables"],
+                                          "msm_accumulate_2p%d_c%d%s" % (args.strong_log_n, r["stats"]["window_bits"], "_tables" if r["stats"]["tables"] else "")
+                                          if world == 1 else None)
+            line["strong_scaling"] = {
+                "metric": "g1_msm_scalar_muls_per_s", "value": strong["total"] * k / strong_elapsed, "unit": "scalar-muls/s", "scaling": "strong",
+                "n_gpus": world, "rccl_ranks": world if (use_dist and args.backend == "nccl") else 0, "steps": k, "warmup": 2, "ms_per_step": 1e3 * strong_elapsed / k,
+                "workload": "ONE 2^%d-point G1 MSM (BASELINE configs[3]), %d points per rank, SRS shards resident with tables; per step: "
+                            "per-rank Pippenger, one all-gather of %d-byte records in HBM, one D2H, host combine"
+                            % (args.strong_log_n, strong["m"], bp._lib.MSM_BLOB_BYTES),
+                "points_per_rank": strong["m"], "window_bits": r["stats"]["window_bits"], "tables": r["stats"]["tables"],
+                "accumulate_ms_per_rank": [p["strong_accumulate_ms"] for p in per_rank],
+                "device_ms_per_rank": [p["strong_device_ms"] for p in per_rank],
+                "tail_ms_per_rank": [p["strong_device_ms"] - p["strong_accumulate_ms"] for p in per_rank],
+                "equals_closed_form": strong_ok,
+                "exchange_ms_per_rank": [p["strong_exchange_ms"] for p in per_rank],
+                "srs_generate_s": strong["gen_s"], "table_build_s": strong["table_s"], "table_bytes_per_gpu": strong["table_info"]["bytes"],
+                "result_sha": hashlib.sha256(r["result"]).hexdigest()[:16],
+                "roofline": s_hbm, "roofline_valu_issue": s_issue}
+            if "ntt" in strong:
+                t = strong["ntt"]
+                line["strong_scaling"]["ntt"] = {"value": strong["total"] * k / t["elapsed"], "unit": "elements/s", "ms_per_step": 1e3 * t["elapsed"] / k,
+                                                 "ms_per_blocking_call": t["blocking_ms"], "passes": t["passes"], "kernel_le_step": t["kernel_le_step"],
+                                                 "roofline": ntt_roofline(strong["total"], t["dev_ms"] * 1e-3, t["passes"], "ntt_2p%d" % args.strong_log_n)}
+        if group_commit:
+            line["group_commit"] = group_commit
+        if prove:
+            line["prove"] = {"metric": "plonk_proofs_per_s", "value": world * prove["streams"] * args.prove_reps / prove_elapsed, "unit": "proofs/s",
+                             "gates": 1 << args.prove_log_n, "concurrent_provers_per_gpu": prove["streams"],
+                             "latency_ms_per_proof_single_prover": 1e3 * prove_single / args.prove_reps,
+                             "latency_ms_per_proof_host_witness": None if prove["host_witness_s"] is None else 1e3 * prove["host_witness_s"],
+                             "proofs_per_s_single_prover_per_gpu": args.prove_reps / prove_single,
+                             "round_ms": prove["round_ms"], "proofs_timed_per_gpu": prove["streams"] * args.prove_reps,
+                             "parallelism": "independent proofs x%d" % world,
+                             "one_proof_over_all_gpus": prove["group"],
+                             "workload": "bp_prove: prover.rs rounds 1-5 + host transcript on a synthetic 2^%d-gate circuit (chained "
+                                         "multiplications), witness and circuit resident in HBM, 624-byte proof out; BASELINE configs[4]"
+                                         % args.prove_log_n,
+                             "proof_sha_rank0": prove["sha"], "srs_and_circuit_setup_s": prove["setup_s"],
+                             "synthetic_circuit_host_s": prove["circuit_host_s"]}
+        if final and world == 1 and not args.skip_cpu:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, min(64, os.cpu_count() or 1))
+        return line
+
     # ---------------------------------------------------------------- weak-scaling MSM (the headline `value`)
     n = 1 << args.log_n
     srs = ctx.srs_generate_progression(n, A0 + rank * n * D0, D0)          # this rank's point range [rank n, (rank + 1) n)
@@ -535,13 +717,13 @@ def main():
     weak_pairs = gather_objects(fr_sums(scal, n, rank * n))
     weak_ok = expected_msm(weak_pairs, A0, D0) == head["result"]
     assert weak_ok, "weak-scaling MSM differs from the closed form"
+    checkpoint("weak_msm", elapsed=head["elapsed"], other_elapsed=other["elapsed"])
 
     # ---------------------------------------------------------------- pipelined: three commitments in flight (what a prover round issues)
     # `value` above is SERIAL: one MSM, its result on the host, then the next (what one Setup::commit call costs).  The prover's rounds 1, 3
     # and 5 issue three / three / two commitments whose results are needed only together (prover.rs:249-251, 483-485, 640-641): bp_commit_many
     # runs them on the context's lanes, so that one pipeline's sort and tail overlap another's accumulation.  Per step: three 2^log_n-scalar
     # vectors against the same resident SRS + tables, all three results on the host; every result checked against its closed form.
-    pipelined = None
     if world == 1 and not args.no_tables and not args.skip_pipelined:
         setup = bp.Setup(srs, ctx, tables=False)                       # wraps the resident handle (its tables exist already)
         vecs = [scal] + [synthetic(n, 0x9199000 + 131 * j) for j in (1, 2)]
@@ -566,7 +748,6 @@ def main():
         del polys, vecs, setup
 
     # ---------------------------------------------------------------- seams of the reference (N = 1): host scalars, uncached points
-    seams = {}
     if world == 1 and not args.skip_seams:
         host_scal = scal.cpu().numpy().view(np.uint64).reshape(n, 4)       # pageable memory, as a Rust Vec<Scalar> is
         for _ in range(args.warmup):
@@ -630,9 +811,9 @@ def main():
     ntt_ok = ntt_spot_check(vec, args.ntt_log_n)
     assert ntt_ok, "NTT spot check failed"
     ntt = timed_ntt(vec, args.ntt_log_n, args.steps, args.warmup)
+    checkpoint("ntt", ntt_elapsed=ntt["elapsed"])
     # the same transform as a BATCH of independent columns in one call (grid.y = column): what the prover issues (a, b, c, PI in round 1; the
     # coset evaluations of round 3) and what the north star's "NTT by independent columns" shards -- the per-pass ramp is paid once per batch
-    ntt_batch = None
     if world == 1 and nn * 8 * 32 <= (8 << 30):
         NB = 8
         cols8 = torch.empty((NB, nn, 4), dtype=torch.int64, device=dev)
@@ -664,7 +845,6 @@ def main():
     # columns across the GPUs with a single RCCL all-gather"; callers: the 23 transforms of prover.rs:386-450, utils.rs:106-129).  Column j
     # of NTT_COLUMNS belongs to rank j mod world (dist.my_columns); a step = every rank transforms its columns (enqueued back to back),
     # then one all_gather_columns brings every finished column to every rank.  Runs whenever a process group exists (a world of one included).
-    ntt_cols = None
     if use_dist:
         mine_j = bpd.my_columns(NTT_COLUMNS, rank, world)
         per_rank_cols = (NTT_COLUMNS + world - 1) // world
@@ -719,10 +899,10 @@ def main():
                     "c_path": cols_c_path}
         del big
         torch.cuda.empty_cache()
+        cols_all_box[0] = gather_objects({"ok": ntt_cols["ok"], "digest": ntt_cols["digest"], "columns": ntt_cols["mine"]})
+        checkpoint("ntt_columns", cols_elapsed=ntt_cols["elapsed"], cols_gather=ntt_cols["gather_s"])
 
     # ---------------------------------------------------------------- the metric's other sizes, N = 1 (2^16 = configs[1]; 2^24 rides on the strong leg)
-    sizes = {}
-
     def release():
         nonlocal srs, scal, vec
         if srs is not None:
@@ -758,7 +938,6 @@ def main():
                                           "roofline": ntt_roofline(m, t["dev_ms"] * 1e-3, t["passes"])}}
 
     # ---------------------------------------------------------------- strong scaling = BASELINE configs[3]: ONE 2^24-point MSM over all ranks
-    strong = None
     if args.strong_log_n:
         release()
         total = 1 << args.strong_log_n
@@ -780,6 +959,7 @@ def main():
         if world == 1 and args.strong_log_n <= 26:
             vec = synthetic(total, 0xF40000 + args.strong_log_n)
             strong["ntt"] = timed_ntt(vec, args.strong_log_n, k, 2)
+        checkpoint("strong_msm", strong_elapsed=strong["r"]["elapsed"])
 
     # ---------------------------------------------------------------- the drop-in's multi-GPU seam (N > 1): ONE commit through bp_init_multi
     # BASELINE configs[3] as the reference's single-threaded caller sees it (setup.rs:32-37, msm.rs:76-81): rank 0's process holds
@@ -790,7 +970,6 @@ def main():
         if use_dist:
             dist.barrier(group=ctl) if ctl is not None else dist.barrier()
 
-    group_commit = None
     if world > 1 and strong is not None and not args.skip_group_legs:
         torch.cuda.synchronize()
         host_barrier()
@@ -800,9 +979,9 @@ def main():
                                            "commit": {"total": strong["total"], "k": strong["k"], "log_n": args.strong_log_n,
                                                       "expect": strong["r"]["result"].hex()}}, args.group_legs_timeout)["group_commit"]
         host_barrier()
+        checkpoint("group_commit")
 
     # ---------------------------------------------------------------- prover leg (BASELINE configs[4])
-    prove = None
     if args.prove_log_n:
         import random
         import threading
@@ -854,8 +1033,10 @@ def main():
         for th in threads:
             th.join()
         barrier()
-        prove = {"elapsed": time.perf_counter() - t0, "single_elapsed": single_elapsed, "round_ms": round_ms, "sha": hashlib.sha256(blob).hexdigest()[:16],
+        prove_res = {"elapsed": time.perf_counter() - t0, "single_elapsed": single_elapsed, "round_ms": round_ms, "sha": hashlib.sha256(blob).hexdigest()[:16],
                  "setup_s": t_setup, "circuit_host_s": t_circuit_host, "streams": len(provers), "group": None, "host_witness_s": host_witness_s}
+        prove = prove_res
+        checkpoint("prove", prove_elapsed=prove["elapsed"], prove_single=prove["single_elapsed"])
         # one proof on ONE context over all N GPUs (bp_init_multi): the nine commitments of prover.rs are sharded by point range,
         # everything else runs on GPU 0.  Rank 0 drives it; the other ranks have freed their memory and wait on the host.
         if world > 1 and not args.skip_group_legs:
@@ -868,140 +1049,9 @@ def main():
                                                  "prove": {"log_n": args.prove_log_n, "reps": args.prove_reps, "ntt_log_n": args.strong_log_n,
                                                            "expect_sha256": hashlib.sha256(blob).hexdigest()}}, args.group_legs_timeout)["group_proof"]
             dist.barrier(group=ctl)
+            checkpoint("one_proof_over_all_gpus")
 
-    # ---------------------------------------------------------------- reduce over ranks, print the line
-    times = [head["elapsed"], ntt["elapsed"], other["elapsed"], prove["elapsed"] if prove else 0.0, prove["single_elapsed"] if prove else 0.0,
-             strong["r"]["elapsed"] if strong else 0.0, ntt_cols["elapsed"] if ntt_cols else 0.0, ntt_cols["gather_s"] if ntt_cols else 0.0]
-    elapsed, ntt_elapsed, other_elapsed, prove_elapsed, prove_single, strong_elapsed, cols_elapsed, cols_gather = max_over_ranks(times)
-    cols_all = gather_objects({"ok": ntt_cols["ok"], "digest": ntt_cols["digest"], "columns": ntt_cols["mine"]} if ntt_cols else None)
-    per_rank = gather_objects({"rank": rank, "device": dev_index, "weak_accumulate_ms": head["acc_ms"], "weak_device_ms": head["dev_ms"],
-                               "weak_exchange_ms": head["exchange_ms"],
-                               "strong_points": strong["m"] if strong else 0, "strong_accumulate_ms": strong["r"]["acc_ms"] if strong else 0.0,
-                               "strong_device_ms": strong["r"]["dev_ms"] if strong else 0.0,
-                               "strong_exchange_ms": strong["r"]["exchange_ms"] if strong else 0.0})
-
-    if rank == 0:
-        stats = head["stats"]
-        units = world * n * args.steps
-        cfg_key = "2p%d_c%d%s" % (args.log_n, stats["window_bits"], "_tables" if stats["tables"] else "")
-        hbm, issue = msm_roofline(n, head["acc_ms"] * 1e-3, stats["mixed_adds"], stats["window_bits"], stats["tables"], "msm_accumulate_" + cfg_key)
-        line = {
-            "metric": "g1_msm_scalar_muls_per_s",
-            "baseline_metric": "G1 MSM scalar-muls/s + Fr NTT elements/s at 2^20/2^24; proof bit-exact",
-            "value": units / elapsed, "unit": "scalar-muls/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 limbs (381-bit Fp Montgomery, 255-bit Fr)", "data": "synthetic",
-            "config": {"workload": "2^%d-point BLS12-381 G1 MSM per GPU (global 2^%d x %d points, point-range shards, one RCCL all-gather "
-                                   "of the ranks' partial-sum records), SRS %s; + 2^%d Fr NTT per GPU; BASELINE configs[2] at N=1"
-                                   % (args.log_n, args.log_n, world,
-                                      "raw points only" if args.no_tables else "resident with its fixed-base window tables (Setup)", args.ntt_log_n),
-                       "msm_points_per_gpu": n, "window_bits": stats["window_bits"], "ntt_len_per_gpu": nn,
-                       "srs_tables": {"used": stats["tables"], "window_bits": table_info["window_bits"], "windows": table_info["windows"],
-                                      "bytes": table_info["bytes"], "bytes_per_gpu": table_info["bytes"], "build_ms": 1e3 * table_build_s,
-                                      "build_s": table_build_s,
-                                      "note": "the headline is a FIXED-BASE MSM: T[w][i] = 2^(window_bits w) P_i built once per SRS outside the "
-                                              "timed region; value_without_tables is the same MSM on the raw points"},
-                       "value_without_tables": None if args.no_tables else units / other_elapsed,
-                       "parallelism": "point-range x%d" % world, "ranks": world, "backend": args.backend if use_dist else None,
-                       "msm_exchange": None if not use_dist else
-                       ("bp_msm_g1_allgather: record -> ncclAllGather -> device pre-sum -> one D2H, all under the C ABI (capi_comm.hip)"
-                        if exchange.c_path else ("dist.ShardedMsm: torch.distributed all_gather_into_tensor of the records (C path unavailable: %s)"
-                                                 % exchange.c_path_error if args.backend == "nccl"
-                                                 else "dist.ShardedMsm host-side gather (gloo rehearsal of the control flow)"))},
-            # the headline is a FIXED-BASE MSM (the SRS of a Setup with its window tables resident); the reference-shaped figures beside it:
-            "value_without_tables": None if args.no_tables else units / other_elapsed,
-            "ms_per_step_without_tables": None if args.no_tables else 1e3 * other_elapsed / args.steps,
-            "first_commit_ms": None if args.no_tables else 1e3 * (table_build_s + elapsed / args.steps),
-            "uncached_seam_ms_per_call": seams["msm_uncached_seam"]["ms_per_call"] if "msm_uncached_seam" in seams else None,
-            "host_scalars_ms_per_step": seams["msm_host_scalars"]["ms_per_step"] if "msm_host_scalars" in seams else None,
-            "headline_note": "value = scalars resident in HBM against an SRS whose fixed-base tables (config.srs_tables) were built once outside "
-                             "the timed region; first_commit_ms = table build + one MSM; value_without_tables = the same MSM on raw points; "
-                             "uncached_seam_ms_per_call = bucket_msm(&[G1Projective], &[Scalar]) literally, nothing cached, PCIe inclusive",
-            "roofline": hbm,
-            "roofline_valu_issue": issue,
-            "msm_device_ms": head["dev_ms"],
-            "msm_accumulate_ms": head["acc_ms"],
-            "tail_ms": head["dev_ms"] - head["acc_ms"],
-            "tail_note": "device time of one MSM outside msm_accumulate: bucket sort (3 launches), fix-up, bit-plane tree, copies",
-            "register_only_rates_source": UBENCH["source"],
-            "equals_closed_form": weak_ok,
-            "exchange_ms": head["exchange_ms"],
-            ("msm_with_tables" if args.no_tables else "msm_without_tables"): {
-                "value": units / other_elapsed, "unit": "scalar-muls/s", "ms_per_step": 1e3 * other_elapsed / args.steps,
-                "device_ms": other["dev_ms"], "accumulate_ms": other["acc_ms"], "tail_ms": other["dev_ms"] - other["acc_ms"],
-                "window_bits": other["stats"]["window_bits"]},
-            "ntt": {"metric": "fr_ntt_elements_per_s", "value": world * nn * args.steps / ntt_elapsed, "unit": "elements/s",
-                    "ms_per_step": 1e3 * ntt_elapsed / args.steps, "ms_per_blocking_call": ntt["blocking_ms"], "passes": ntt["passes"],
-                    "kernel_le_step": ntt["kernel_le_step"], "spot_check": ntt_ok,
-                    "how": "steps enqueued back to back on the context's stream (bp_ntt_fr_device_async), one wait at the end; "
-                           "ms_per_blocking_call = the same transform through bp_ntt_fr_device, which waits for the stream every call",
-                    "batched_columns": ntt_batch,
-                    "roofline": ntt_roofline(nn, ntt["dev_ms"] * 1e-3, ntt["passes"], "ntt_2p%d" % args.ntt_log_n)},
-            "result_sha": hashlib.sha256(head["result"]).hexdigest()[:16],
-            "per_rank": per_rank,
-        }
-        if ntt_cols:
-            line["ntt_columns"] = {
-                "metric": "fr_ntt_elements_per_s", "value": NTT_COLUMNS * nn * args.steps / cols_elapsed, "unit": "elements/s", "n_gpus": world,
-                "columns": NTT_COLUMNS, "column_len": nn, "columns_per_rank": [c["columns"] for c in cols_all], "steps": args.steps,
-                "ms_per_step": 1e3 * cols_elapsed / args.steps, "allgather_ms_per_step": 1e3 * cols_gather / args.steps,
-                "allgather_bytes_per_rank_out": 32 * nn * ((NTT_COLUMNS + world - 1) // world) * world,
-                "backend": args.backend, "collective": "bp_ntt_columns_allgather (in-place ncclAllGather under the C ABI)" if ntt_cols["c_path"]
-                else "dist.all_gather_columns (host-side gather of the gloo rehearsal)",
-                "foreign_column_matches_local_transform": all(c["ok"] for c in cols_all),
-                "same_on_all_ranks": len({c["digest"] for c in cols_all}) == 1,
-                "how": "column j of %d belongs to rank j mod N (dist.my_columns); per step every rank transforms its columns "
-                       "(bp_ntt_fr_device_async, one wait) in its block of one [N x columns per rank, 2^%d, 4] buffer and ONE all-gather over RCCL "
-                       "brings every column to every rank; allgather_ms = that collective alone, max over ranks" % (NTT_COLUMNS, args.ntt_log_n)}
-        line.update(seams)
-        if pipelined:
-            line["pipelined"] = pipelined
-        if sizes:
-            line["other_sizes"] = sizes
-        if strong:
-            r, k = strong["r"], strong["k"]
-            s_hbm, s_issue = msm_roofline(strong["m"], r["acc_ms"] * 1e-3, r["stats"]["mixed_adds"], r["stats"]["window_bits"], r["stats"]["tables"],
-                                          "msm_accumulate_2p%d_c%d%s" % (args.strong_log_n, r["stats"]["window_bits"], "_tables" if r["stats"]["tables"] else "")
-                                          if world == 1 else None)
-            line["strong_scaling"] = {
-                "metric": "g1_msm_scalar_muls_per_s", "value": strong["total"] * k / strong_elapsed, "unit": "scalar-muls/s", "scaling": "strong",
-                "n_gpus": world, "rccl_ranks": world if (use_dist and args.backend == "nccl") else 0, "steps": k, "warmup": 2, "ms_per_step": 1e3 * strong_elapsed / k,
-                "workload": "ONE 2^%d-point G1 MSM (BASELINE configs[3]), %d points per rank, SRS shards resident with tables; per step: "
-                            "per-rank Pippenger, one all-gather of %d-byte records in HBM, one D2H, host combine"
-                            % (args.strong_log_n, strong["m"], bp._lib.MSM_BLOB_BYTES),
-                "points_per_rank": strong["m"], "window_bits": r["stats"]["window_bits"], "tables": r["stats"]["tables"],
-                "accumulate_ms_per_rank": [p["strong_accumulate_ms"] for p in per_rank],
-                "device_ms_per_rank": [p["strong_device_ms"] for p in per_rank],
-                "tail_ms_per_rank": [p["strong_device_ms"] - p["strong_accumulate_ms"] for p in per_rank],
-                "equals_closed_form": strong_ok,
-                "exchange_ms_per_rank": [p["strong_exchange_ms"] for p in per_rank],
-                "srs_generate_s": strong["gen_s"], "table_build_s": strong["table_s"], "table_bytes_per_gpu": strong["table_info"]["bytes"],
-                "result_sha": hashlib.sha256(r["result"]).hexdigest()[:16],
-                "roofline": s_hbm, "roofline_valu_issue": s_issue}
-            if "ntt" in strong:
-                t = strong["ntt"]
-                line["strong_scaling"]["ntt"] = {"value": strong["total"] * k / t["elapsed"], "unit": "elements/s", "ms_per_step": 1e3 * t["elapsed"] / k,
-                                                 "ms_per_blocking_call": t["blocking_ms"], "passes": t["passes"], "kernel_le_step": t["kernel_le_step"],
-                                                 "roofline": ntt_roofline(strong["total"], t["dev_ms"] * 1e-3, t["passes"], "ntt_2p%d" % args.strong_log_n)}
-        if group_commit:
-            line["group_commit"] = group_commit
-        if prove:
-            line["prove"] = {"metric": "plonk_proofs_per_s", "value": world * prove["streams"] * args.prove_reps / prove_elapsed, "unit": "proofs/s",
-                             "gates": 1 << args.prove_log_n, "concurrent_provers_per_gpu": prove["streams"],
-                             "latency_ms_per_proof_single_prover": 1e3 * prove_single / args.prove_reps,
-                             "latency_ms_per_proof_host_witness": None if prove["host_witness_s"] is None else 1e3 * prove["host_witness_s"],
-                             "proofs_per_s_single_prover_per_gpu": args.prove_reps / prove_single,
-                             "round_ms": prove["round_ms"], "proofs_timed_per_gpu": prove["streams"] * args.prove_reps,
-                             "parallelism": "independent proofs x%d" % world,
-                             "one_proof_over_all_gpus": prove["group"],
-                             "workload": "bp_prove: prover.rs rounds 1-5 + host transcript on a synthetic 2^%d-gate circuit (chained "
-                                         "multiplications), witness and circuit resident in HBM, 624-byte proof out; BASELINE configs[4]"
-                                         % args.prove_log_n,
-                             "proof_sha_rank0": prove["sha"], "srs_and_circuit_setup_s": prove["setup_s"],
-                             "synthetic_circuit_host_s": prove["circuit_host_s"]}
-        if world == 1 and not args.skip_cpu:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, min(64, os.cpu_count() or 1))
-        print(json.dumps(line), flush=True)
+    emit(final=True)
     if use_dist:
         dist.barrier(group=ctl) if ctl is not None else dist.barrier()
         dist.destroy_process_group()

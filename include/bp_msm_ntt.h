@@ -25,9 +25,15 @@
  *                        exactly as members on other cards do.  STATUS: that is the only way those branches have run so far;
  *                        no run on distinct GPUs is recorded yet.
  *   - the library reads no environment variable (experiment knobs exist in the separate -DBP_EXPERIMENT build only).
- *       one process per GPU (torch.distributed / MPI launchers): every rank owns a point range in a plain bp_init context,
- *                        leaves its partial sums in HBM (bp_msm_g1_blob_device), the caller all-gathers those buffers
- *                        over RCCL/xGMI and every rank combines them (bp_msm_blobs_combine): one collective, one D2H.
+ *       one process per GPU (torch.distributed / MPI launchers): every rank owns a point range in a plain bp_init context and
+ *                        joins the library's own communicator (bp_comm_unique_id on rank 0, the host carries 128 bytes to the
+ *                        others, bp_comm_init_rank everywhere).  bp_msm_g1_allgather then is the whole exchange under this ABI:
+ *                        the rank's partial sums stay in HBM as a record, ONE ncclAllGather of the records over xGMI on the
+ *                        context's stream, the slot-wise sum of the gathered records on the device, ONE 22-KB device-to-host
+ *                        copy, host Horner; bp_ntt_columns_allgather gathers finished NTT columns in place.  A rank never skips
+ *                        a collective (a local failure travels as a poisoned record / agreement word and every rank returns it),
+ *                        and every wait behind a collective is bounded (bp_comm_set_timeout_ms): errors, not stalls.
+ *                        (bp_msm_g1_blob_device + bp_msm_blobs_combine remain for hosts that bring their own collective.)
  *   - wire formats are the reference's own:
  *       scalar  fmt BP_FR_BYTES_LE : 32-byte little-endian canonical  (Scalar::to_bytes,  scalar.rs:292-304)
  *               fmt BP_FR_MONT     : 4 x u64 Montgomery limbs          (Scalar::to_array,  scalar.rs:35-40)
@@ -61,7 +67,8 @@ enum {
   BP_ERR_HIP = -9,           /* HIP runtime error; bp_last_error() has the text */
   BP_ERR_TOO_LARGE = -10,    /* size beyond the supported range (NTT > 2^28, MSM >= 2^31 points) */
   BP_ERR_ASSERT = -11,       /* a protocol assert_eq! of the reference failed (prover.rs:319  z_n == 1) */
-  BP_ERR_COMM = -12          /* an RCCL call failed (bp_comm_*, bp_msm_g1_allgather, bp_ntt_columns_allgather); text in bp_last_error */
+  BP_ERR_COMM = -12          /* an RCCL call failed, the communicator reported an asynchronous error, or a collective / ncclCommInitRank
+                                did not finish within the bound of bp_comm_set_timeout_ms (the communicator is then aborted); text in bp_last_error */
 };
 enum { BP_FR_BYTES_LE = 0, BP_FR_MONT = 1 };
 enum { BP_BASIS_LAGRANGE = 0, BP_BASIS_MONOMIAL = 1 };   /* polynomial.rs:8-11 */
@@ -214,25 +221,40 @@ int  bp_msm_last_used_tables(bp_ctx* ctx);
  * run exists yet, and no number for a world > 1 is claimed.
  * bp_comm_unique_id: rank 0 makes the 128-byte id (ncclGetUniqueId); the host carries it to the other ranks by whatever means it
  * has (a file, a socket, MPI).  bp_comm_init_rank: every rank, same id (ncclCommInitRank; collective -- returns when all `world`
- * ranks have called it).  bp_comm_info: rank / world of the context's communicator (world = 0 without one). */
+ * ranks have called it; it allocates every buffer the later collectives need and ends with a 32-byte agreement all-gather in
+ * which the ranks compare world and record size).  bp_comm_info: rank / world of the context's communicator (world = 0 without one).
+ * Failure semantics -- the reference panics, it never blocks (src/setup.rs:34, src/utils.rs:65,108), and neither does a collective here:
+ *   - a rank that fails locally in front of a collective still JOINS it and says so inside it (a poisoned MSM record; the agreement
+ *     word of bp_ntt_columns_allgather); every rank of the communicator then returns that rank's error code;
+ *   - every host wait behind a collective polls the stream and ncclCommGetAsyncError and gives up after the bound of
+ *     bp_comm_set_timeout_ms (milliseconds; default 120 000; 0 = wait for ever): the communicator is aborted (ncclCommAbort),
+ *     bp_comm_info reports world 0, the call returns BP_ERR_COMM; a new communicator may be created afterwards;
+ *   - ncclCommInitRank runs on a helper thread under the same bound; when it expires (a rank never arrived) the call returns
+ *     BP_ERR_COMM, the helper stays parked inside RCCL until the process ends and this context refuses further communicators.
+ * bp_comm_stats: collectives this context has enqueued so far (agreement all-gathers included) and the bound in force. */
 #define BP_COMM_ID_BYTES 128
 int  bp_comm_unique_id(uint8_t id[128]);
 int  bp_comm_init_rank(bp_ctx* ctx, const uint8_t id[128], int rank, int world);
 int  bp_comm_info(bp_ctx* ctx, int* rank, int* world);
+int  bp_comm_set_timeout_ms(bp_ctx* ctx, uint32_t ms);
+int  bp_comm_stats(bp_ctx* ctx, uint64_t* collectives, uint32_t* timeout_ms);
 int  bp_comm_destroy(bp_ctx* ctx);
 /* Setup::commit / BucketMSM::bucket_msm over ALL ranks (src/setup.rs:32-37 -> src/msm.rs:76-118): every rank passes the scalars of
  * ITS point range (srs_handle = the rank's shard, `first` inside it, zip truncation as bp_msm_g1_partial) and every rank receives
  * the same 96 bytes: sum over all ranks' (point, scalar) pairs.  Inside: the rank's bit planes stay in HBM as a BP_MSM_BLOB_BYTES
  * record -> ONE ncclAllGather of the records over xGMI -> slot-wise sum of the gathered records on the device -> ONE 22-KB
  * device-to-host copy -> host Horner (msm.rs:107-115) + normalisation.  One host wait per call.  Collective: every rank of the
- * communicator must call it (an empty range is fine: n_scalars = 0). */
+ * communicator must call it (an empty range is fine: n_scalars = 0).  A rank whose own part fails (unknown handle, `first` beyond
+ * its shard, out of memory, a scalar >= q) still takes part: its record carries the error and EVERY rank returns that code. */
 int  bp_msm_g1_allgather(bp_ctx* ctx, uint64_t srs_handle, size_t first, const void* scalars, size_t n_scalars, int scalar_fmt,
                          int scalars_on_device, uint8_t out96[96]);
 /* GPU time of the last bp_msm_g1_allgather from "this rank's record complete" to "gathered, summed and copied" (HIP events). */
 int  bp_comm_last_exchange_ms(bp_ctx* ctx, float* ms);
 /* NTT by independent columns (Polynomial::ntt / i_ntt on separate polynomials, src/polynomial.rs:47-55): d_columns holds
  * world x columns_per_rank columns of 2^log_n Montgomery elements in HBM, rank r's finished columns in block r (this rank's block
- * filled by its own bp_ntt_fr_device calls on this context); ONE in-place ncclAllGather leaves every column on every rank. */
+ * filled by its own bp_ntt_fr_device calls on this context); ONE in-place ncclAllGather leaves every column on every rank.  A 32-byte
+ * agreement all-gather goes first (status, log_n, columns_per_rank of every rank): a rank with bad arguments, or ranks that disagree
+ * on the shape, make every rank return the same error before any column moves.  log_n <= 28. */
 int  bp_ntt_columns_allgather(bp_ctx* ctx, void* d_columns, uint32_t log_n, size_t columns_per_rank);
 
 /* ---- DFT: ntt_381 / i_ntt_381 (src/utils.rs:63-81, 106-129) --------------------------------------- */

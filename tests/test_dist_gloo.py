@@ -83,3 +83,88 @@ def test_bench_refuses_to_fake_ranks_without_gpus():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                          timeout=300, cwd=root, env=env)
     assert out.returncode == 2 and "--gpus 2" in out.stderr and not out.stdout.strip()
+
+
+class _FakeCtx:
+    """stands in for a Context on the CPU: the collectives of join_library_communicator are torch.distributed's, only the three
+    comm calls are the library's (they need a GPU)"""
+    device = 0
+
+    def __init__(self, have=(0, 0), init_fails=False):
+        self.have, self.init_fails, self.destroyed = have, init_fails, 0
+
+    def comm_info(self):
+        return self.have
+
+    def comm_init_rank(self, comm_id, rank, world):
+        assert len(comm_id) == 128
+        if self.init_fails:
+            raise RuntimeError("injected: bp_comm_init_rank failed on this rank")
+        self.have = (rank, world)
+
+    def comm_destroy(self):
+        self.destroyed += 1
+        self.have = (0, 0)
+
+
+def _join_worker(rank, world, port, case, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from baby_plonk_rust_amd import api
+        api.Context.comm_unique_id = staticmethod(lambda: bytes(range(128)))
+        if case == "ok":
+            ctx = _FakeCtx()
+        elif case == "init_fails_on_rank_1":
+            ctx = _FakeCtx(init_fails=(rank == 1))
+        elif case == "id_fails_on_rank_0":
+            ctx = _FakeCtx()
+
+            def boom():
+                raise RuntimeError("injected: no id")
+            api.Context.comm_unique_id = staticmethod(boom)
+        elif case == "all_have":
+            ctx = _FakeCtx(have=(rank, world))
+        elif case == "mixed":
+            ctx = _FakeCtx(have=(rank, world) if rank == 0 else (0, 0))
+        elif case == "other_shape":
+            ctx = _FakeCtx(have=(0, 5) if rank == 1 else (0, 0))
+        try:
+            made = bpd.join_library_communicator(ctx, device="cpu")
+            out = ("joined", made, ctx.have, ctx.destroyed)
+        except RuntimeError as e:
+            out = ("raised", str(e)[:60], ctx.have, ctx.destroyed)
+        # the ranks' collectives still line up afterwards, on every path: one more all-reduce must complete
+        import torch
+        t = torch.tensor([rank + 1])
+        dist.all_reduce(t)
+        q.put((rank, out, int(t)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["ok", "init_fails_on_rank_1", "id_fails_on_rank_0", "all_have", "mixed", "other_shape"])
+def test_join_library_communicator_every_step_is_agreed_on(case):
+    """a failure on ONE rank at any step of the communicator's creation raises on EVERY rank and leaves the ranks' collectives
+    lined up (no rank sits in a broadcast or an init the other never enters)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_join_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r, (out, tot)) for r, out, tot in [q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(tot == 3 for _, tot in res.values())                      # the follow-up all-reduce completed on both ranks
+    kinds = {r: out[0] for r, (out, _) in res.items()}
+    if case == "ok":
+        assert res[0][0] == ("joined", True, (0, 2), 0) and res[1][0] == ("joined", True, (1, 2), 0)
+    elif case == "all_have":
+        assert res[0][0] == ("joined", False, (0, 2), 0) and res[1][0] == ("joined", False, (1, 2), 0)
+    else:
+        assert kinds == {0: "raised", 1: "raised"}, res
+        if case == "init_fails_on_rank_1":
+            assert res[0][0][2:] == ((0, 0), 1) and res[1][0][2:] == ((0, 0), 0)      # the rank whose init succeeded gave its communicator back

@@ -65,9 +65,16 @@ def test_bench_self_launches_two_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                  # exactly one result line reaches the caller
-    line = json.loads(lines[0])
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    # under a launcher rank 0 prints a COMPLETE line after the weak leg and after every later leg, each relayed as it arrives: a kill
+    # in a later leg leaves the newest finished line in the caller's tail (VERDICT r05 #1c)
+    assert len(lines) >= 2 and all(l["provisional"] for l in lines[:-1]) and lines[-1]["provisional"] is False
+    assert lines[0]["legs_finished"] == ["weak_msm"] and lines[0]["value"] > 0 and lines[0]["n_gpus"] == 2 and "roofline" in lines[0]
+    assert all(a["legs_finished"] == b["legs_finished"][:len(a["legs_finished"])] and len(b["legs_finished"]) == len(a["legs_finished"]) + 1
+               for a, b in zip(lines, lines[1:-1]))
+    assert lines[-1]["legs_finished"] == ["weak_msm", "ntt", "ntt_columns", "strong_msm", "group_commit", "prove", "one_proof_over_all_gpus"]
+    assert all(l["value"] == lines[0]["value"] and l["ms_per_step"] == lines[0]["ms_per_step"] for l in lines)      # the headline does not move between lines
+    line = lines[-1]
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["ntt"]["value"] > 0
     assert line["config"]["msm_points_per_gpu"] == 1 << 14 and len(line["per_rank"]) == 2
     st = line["strong_scaling"]
@@ -182,6 +189,45 @@ def _comm_body(q):
         return
     except bp.BpError as e:
         assert e.code == -1
+    # VERDICT r05 #1a: a rank NEVER skips a collective.  A local failure in front of the all-gather (here: `first` beyond the shard, an
+    # unknown handle) still enqueues it -- the collective counter advances -- and comes back as that error; the communicator stays usable
+    assert ctx.comm_stats()["timeout_ms"] == 120000
+    for kwargs, code, text in (({"first": n + 1}, -1, "out of bounds"), ({"handle": h + 12345}, -1, "")):
+        before = ctx.comm_stats()["collectives"]
+        try:
+            ctx.msm_allgather(kwargs.get("handle", h), sc[:100], first=kwargs.get("first", 0))
+            q.put("a local failure in front of the collective must still be an error: %r" % (kwargs,))
+            return
+        except bp.BpError as e:
+            assert e.code == code and text in str(e), str(e)
+        assert ctx.comm_stats()["collectives"] == before + 1, "the failing rank stayed away from the all-gather"
+        assert ctx.comm_info() == (0, 1) and ctx.msm_allgather(h, sc) == want
+    before = ctx.comm_stats()["collectives"]
+    try:
+        ctx.ntt_columns_allgather(tc.data_ptr(), 29, 3)               # bad shape: said INSIDE the agreement all-gather, no column moves
+        q.put("columns longer than 2^28 must be an error")
+        return
+    except bp.BpError as e:
+        assert e.code == -10
+    assert ctx.comm_stats()["collectives"] == before + 1
+    ctx.ntt_columns_allgather(tc.data_ptr(), 12, 3)
+    assert ctx.comm_stats()["collectives"] == before + 3              # agreement + the columns
+    # VERDICT r05 #1b: every wait behind a collective is bounded.  A 1-ms bound under a 2^21-point table-free MSM (~7 ms of kernels in front
+    # of the all-gather): BP_ERR_COMM, the communicator aborted -- not a stall; a new communicator works afterwards
+    big = ctx.srs_generate_progression(1 << 21, a, d)
+    sc_big = O.splitmix_scalars(1 << 21, 0xB16)
+    ctx.comm_set_timeout_ms(1)
+    try:
+        ctx.msm_allgather(big, sc_big)
+        q.put("a 1-ms bound must expire under a 7-ms pipeline")
+        return
+    except bp.BpError as e:
+        assert e.code == -12 and "did not finish within 1 ms" in str(e), str(e)
+    assert ctx.comm_info() == (0, 0)
+    ctx.synchronize()
+    ctx.comm_set_timeout_ms(120000)
+    ctx.comm_init_rank(bp.Context.comm_unique_id(), 0, 1)
+    assert ctx.msm_allgather(big, sc_big) == M.enc96(M.ec_mul(O.dot_progression(sc_big, a, d)))
     ctx.comm_destroy()
     assert ctx.comm_info() == (0, 0)
     ctx.comm_init_rank(bp.Context.comm_unique_id(), 0, 1)             # and again after a destroy
@@ -201,3 +247,50 @@ def test_rccl_collectives_under_the_c_abi_world_of_one():
     res = q.get(timeout=600)
     p.join(timeout=120)
     assert res == "ok" and p.exitcode == 0, res
+
+
+def _missing_rank_worker(q):
+    import time
+    import baby_plonk_rust_amd as bp
+    try:
+        ctx = bp.Context(0)
+        ctx.comm_set_timeout_ms(500)
+        t0 = time.perf_counter()
+        try:
+            ctx.comm_init_rank(bp.Context.comm_unique_id(), 0, 2)      # a world of two whose rank 1 never calls: ncclCommInitRank would block for ever
+            q.put("an init without its second rank must not succeed")
+        except bp.BpError as e:
+            waited = time.perf_counter() - t0
+            assert e.code == -12 and "did not return within 500 ms" in str(e), str(e)
+            assert 0.4 < waited < 30, waited
+            assert ctx.comm_info() == (0, 0)
+            try:
+                ctx.comm_init_rank(bp.Context.comm_unique_id(), 0, 1)  # the helper thread is still inside RCCL: this context takes no further communicator
+                q.put("a context whose init is stuck must refuse another")
+            except bp.BpError as e2:
+                assert e2.code == -12 and "still inside RCCL" in str(e2)
+                other = bp.Context(0)                                  # a fresh context of the same process is fine
+                other.comm_init_rank(bp.Context.comm_unique_id(), 0, 1)
+                assert other.comm_info() == (0, 1)
+                q.put("ok")
+    except BaseException:
+        import traceback
+        q.put(traceback.format_exc())
+    finally:
+        os._exit(0)            # the parked helper thread sits in RCCL's bootstrap: leave without running RCCL's static destructors
+
+
+def test_comm_init_is_bounded_when_a_rank_never_arrives():
+    """VERDICT r05 #1b: ncclCommInitRank blocks until every rank of the world has called it; with a bound it is BP_ERR_COMM instead of a
+    stall (the reference panics, it never blocks: src/setup.rs:34)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_missing_rank_worker, args=(q,))
+    p.start()
+    try:
+        res = q.get(timeout=300)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert res == "ok", res
