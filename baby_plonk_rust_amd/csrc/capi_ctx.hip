@@ -90,6 +90,28 @@ void host_horner(g1_proj& out, const g1_proj* window_sums, uint32_t W, uint32_t 
   out = acc;
 }
 
+// quads[w * nq + j] = the part of window w's sum that carries the factor 2^(4j) (msm_planes_window_quads):
+//   out = sum_w 2^(c w) sum_j 2^(4 j) quads[w][j], one Horner pass from the top position down -- c (W - 1) + 4 (nq - 1) doublings, the same
+//   dependent chain the W window sums needed (nq = 1 is host_horner: one value per window)
+void host_quad_horner(g1_proj& out, const g1_proj* quads, uint32_t W, uint32_t c, uint32_t nq) {
+  g1_proj acc = g1_identity();
+  uint32_t prev = 0;
+  bool first = true;
+  for (uint32_t w = W; w-- > 0;)
+    for (uint32_t j = nq; j-- > 0;) {
+      const uint32_t pos = c * w + 4 * j;
+      if (first) {
+        acc = quads[(size_t)w * nq + j];
+        first = false;
+      } else {
+        for (uint32_t d = pos; d < prev; d++) g1_double(acc, acc);
+        g1_add(acc, acc, quads[(size_t)w * nq + j]);
+      }
+      prev = pos;
+    }
+  out = acc;
+}
+
 // planes[w * c + 0] = A_w, planes[w * c + 1 + j] = T_{w,j} (j < c - 1):
 //   out = sum_w 2^(c w) (A_w + sum_j 2^j T_{w,j}),  one pass from the top bit position down (bucket b holds digit b + 1);
 //   odd_digits (NAF tables, one window): bucket b holds digit 2b + 1, out = A + 2 sum_j 2^j T_j

@@ -267,6 +267,7 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
       DeviceGuard guard(sh[r]->device);
       size_t free_b = 0, total_b = 0;
       BP_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+      if (ctx->free_bytes_probe) free_b = (size_t)ctx->free_bytes_probe;        // tests: the reading to decide on (bpx_set_free_bytes_probe below)
       const size_t rows = srs_table_rows(cc);
       size_t& need = per_device[sh[r]->device];
       size_t& old_bytes = held[sh[r]->device];
@@ -302,6 +303,16 @@ int bp_srs_precompute(bp_ctx* ctx, uint64_t srs_handle, uint32_t window_bits) {
   for (size_t r = 0; r < sh.size(); r++) BP_TRY(lift(ctx, sh[r], srs_precompute_one(sh[r], hs.empty() ? srs_handle : hs[r], BP_SRS_TABLES_OFF)));
   if (c == BP_SRS_TABLES_OFF) return BP_OK;
   for (size_t r = 0; r < sh.size(); r++) BP_TRY(lift(ctx, sh[r], srs_precompute_one(sh[r], hs.empty() ? srs_handle : hs[r], c)));
+  return BP_OK;
+}
+
+// INTERNAL, not part of include/bp_msm_ntt.h: the memory-budget decision of bp_srs_precompute made testable without filling a
+// 288-GB device (a test that hogs memory until ~400 MiB are left depends on when other processes' frees reach the
+// driver).  bytes != 0: bp_srs_precompute on this context decides as if hipMemGetInfo had reported that many free bytes on every
+// device (the bytes of the tables the SRS holds now still count as free on top); 0: the real reading again.  Nothing else reads it.
+extern "C" int bpx_set_free_bytes_probe(bp_ctx* ctx, uint64_t bytes) {
+  if (!ctx) return BP_ERR_INVALID_ARG;
+  ctx->free_bytes_probe = bytes;
   return BP_OK;
 }
 

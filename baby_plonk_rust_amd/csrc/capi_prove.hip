@@ -42,7 +42,7 @@ int bp_circuit_load(bp_ctx* ctx, uint32_t log_n, const void* const columns[8], i
     (void)hipFree(lag);
     return rc;
   }
-  if (is_group(ctx)) {                       // round 3 by coset over the members: their shares of the coset tables
+  if (is_group(ctx) || knob_u32("BP_PROVE_COSET_ONE", 0, 0, 1) == 1) {       // round 3 by coset over the members: their shares of the coset tables (experiment: one device, all four)
     rc = circuit_split_build(ctx, e);
     if (rc != BP_OK) {
       circuit_release(e);

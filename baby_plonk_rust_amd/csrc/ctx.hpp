@@ -170,6 +170,7 @@ struct bp_ctx {
   uint32_t comm_timeout_ms = 120000;               // bound of every wait on a collective and of ncclCommInitRank (bp_comm_set_timeout_ms; 0 = none)
   uint64_t comm_collectives = 0;                   // collectives this context has enqueued on its communicator(s) (bp_comm_stats)
   bool comm_init_stuck = false;                    // an ncclCommInitRank of this context ran into the bound: its helper thread is still inside RCCL
+  uint64_t free_bytes_probe = 0;                   // tests only (bpx_set_free_bytes_probe): the free-memory reading bp_srs_precompute decides on; 0 = hipMemGetInfo
   bool gen_table_ready = false;                    // srs_generate_run: the generator's multiples were built into gen_table_ptr
   const void* gen_table_ptr = nullptr;
   void* pinned = nullptr;                          // small pinned staging buffer (window sums etc.)
@@ -245,6 +246,7 @@ struct MsmPending {
   bool empty = true, blob = false;
   uint32_t tables = 0;                  // 0: per-window buckets; 1: fixed-base window tables; 2: every-position tables (odd NAF digits)
   uint32_t c = 0, Wr = 0, n_planes = 0;
+  uint32_t quads = 1;                   // table-free: values per window the device hands over (msm_planes_window_quads); 1: whole window sums
   uint32_t J = 1;                       // scalar vectors in the pipeline (msm_launch_many): msm_finish writes J results
   uint64_t adds = 0;
   const void* h_windows = nullptr;      // pinned: n_planes accumulator slots + the status word
@@ -320,6 +322,7 @@ void transcript_test_vector(uint8_t out32[32]);
 
 // ---- host-side helpers (capi_ctx.hip) ---------------------------------------------------
 void host_horner(g1_proj& out, const g1_proj* window_sums, uint32_t W, uint32_t c);
+void host_quad_horner(g1_proj& out, const g1_proj* quads, uint32_t W, uint32_t c, uint32_t nq);
 void host_plane_horner(g1_proj& out, const g1_proj* planes, uint32_t W, uint32_t c, bool odd_digits = false);
 void host_encode96(uint8_t out96[96], const g1_proj& p);
 bool host_decode96(g1_proj& out, const uint8_t in96[96]);

@@ -1,7 +1,9 @@
 // msm.hip -- host driver of the G1 MSM pipeline (kernels in msm_kernels.hpp).
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "ctx.hpp"
@@ -14,6 +16,26 @@ static uint32_t ilog2_floor(size_t n) {
   while ((n >> (l + 1)) != 0) l++;
   return l;
 }
+// radix for table width c with W windows (R = 0: power-of-two windows); cached per width
+static const MsmRadix& msm_radix_for(uint32_t c, uint32_t W) {
+  static MsmRadix cache[MSM_MAX_TABLE_C + 1];
+  static bool done[MSM_MAX_TABLE_C + 1];
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!done[c]) {
+    done[c] = true;
+    // Widths from 21 bits only (2^20 allocated buckets and more).  Fewer live buckets save tree time only where a tree level runs for
+    // several wave rounds: at c = 22 (2^21 buckets, 2^24 points) the radix takes 0.3 ms off the 5.3-ms tail and 0.65 ms off the MSM; at
+    // c = 20 every wide level of the 2^19-bucket tree is ONE round of two waves per SIMD, a fifth of the workgroups leaving early frees
+    // no SIMD earlier, and the division costs msm_part_count 9 us: 2.60-2.64 against 2.63 ms, no gain (profiles/r06_tail_ab.txt).
+    // Experiment build: BP_MSM_RADIX=0 keeps power-of-two windows everywhere, BP_MSM_RADIX_FROM moves the threshold.
+    if (knob_u32("BP_MSM_RADIX", 1, 0, 1) != 0 && c >= knob_u32("BP_MSM_RADIX_FROM", 21, 8, 30)) cache[c] = msm_radix_compute(c, W);
+  }
+  return cache[c];
+}
+// live buckets of table width c (the prefix of the 2^(c-1) allocated ones that digits can reach)
+uint32_t msm_table_radix(uint32_t c, uint32_t W) { return msm_radix_for(c, W).R; }
+
 // Window width: minimise W * (n + 2 * 2^(c-1)) (bucket adds + reduction adds).  Per-window bucket sets (any point set) are
 // bounded by the 128 KiB LDS histogram of one window (c <= 16); with fixed-base tables wider windows go through the
 // partitioned sort (plan.parts > 1), up to MSM_MAX_TABLE_C.
@@ -88,6 +110,14 @@ static void make_plan(MsmPlan& plan, size_t n, uint32_t table_c, size_t table_st
     }
     W++;
   }
+  if (table_c) {                                     // fixed-base tables: the radix need not be a power of two
+    const MsmRadix& rx = msm_radix_for(c, W);
+    if (rx.R) {
+      plan.radix = rx.R;
+      memcpy(plan.radix_m, rx.m, sizeof plan.radix_m);
+      memcpy(plan.bias, rx.bias, sizeof plan.bias);
+    }
+  }
   plan.c = c;
   plan.W = W;
   plan.B = 1u << (c - 1);
@@ -154,13 +184,14 @@ uint32_t srs_table_rows(uint32_t c) { return msm_table_windows(c); }
 int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_points28, size_t n, uint32_t c, g1_affine28** d_table,
                    uint32_t* windows) {
   const uint32_t W = msm_table_windows(c);
+  const uint32_t radix = (c & MSM_NAF_FLAG) ? 0u : msm_table_radix(c, W);       // rows R^w P_i where the MSM cuts radix-R digits (MsmPlan::radix)
   if ((uint64_t)W * n >= (1ull << 31))
     return fail(ctx, BP_ERR_TOO_LARGE, "fixed-base tables: windows * points >= 2^31", hipSuccess, __FILE__, __LINE__);
   g1_affine28* t = nullptr;
   BP_HIP(ctx, hipMalloc((void**)&t, (size_t)W * (n ? n : 1) * sizeof(g1_affine28)));
   if (n) {
     BP_HIP(ctx, hipMemcpyAsync(t, d_points28, n * sizeof(g1_affine28), hipMemcpyDeviceToDevice, ctx->stream));
-    hipLaunchKernelGGL(srs_window_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_points28, n, (c & MSM_NAF_FLAG) ? 1u : c, W, t);
+    hipLaunchKernelGGL(srs_window_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_points28, n, (c & MSM_NAF_FLAG) ? 1u : c, W, radix, t);
   }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = stream_wait(ctx->stream);
@@ -250,7 +281,13 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   const uint64_t n_chunks = (max_entries + plan.chunk - 1) / plan.chunk;
   // bucket reduction: running sums per window (msm_reduce), or (tables: one bucket set) the bit-plane tree
   const uint32_t blocks_per_window = table_c ? 0 : ((B + plan.seg - 1) / plan.seg + 255) / 256;
-  const uint32_t per_window = table_c ? plan.c : 1;     // slots per window that go to the host
+  // Bucket reduction without tables (W bucket sets of 2^(c-1) buckets): the same bit-plane tree as with tables, over a forest of W trees
+  // (round 5; rounds 1-4 ran segmented running sums per window, msm_reduce: a dependent chain of ~46 additions per lane, 256 VGPRs + spills,
+  // 0.57 ms at 2^20 points -- kept in the experiment build as BP_MSM_REDUCE=1 for the A/B), then two levels of the Horner form over each
+  // tree's c values (msm_planes_window_quads): `quads` values per window go to the host.
+  const bool reduce_running = EXPERIMENT_BUILD && !table_c && knob_u32("BP_MSM_REDUCE", 0, 0, 1) == 1;
+  const uint32_t quads = (table_c || reduce_running) ? 1u : (plan.c + 2) / 4;          // ceil((c - 1) / 4); c = 2: one quad (A + T_0)
+  const uint32_t per_window = table_c ? plan.c : quads;     // slots per window that go to the host
 
   uint32_t *counts, *offsets, *cursors, *sorted;
   proj28_slot *bucket_sum, *partial, *block_out, *window_sum;
@@ -258,9 +295,11 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   const uint32_t long_cap = (uint32_t)(n_chunks / FIXUP_LONG + 1);
   // control words, zeroed by ONE memset per MSM: [0] long-bucket counter, [1] scalar status, [2] long-run counter of the sort,
   // [4] ticket + [5 ..] partition sizes of msm_part_count, then one ticket per queued long bucket (msm_fixup_long)
+  // ... then one ticket per long RUN of the sort (msm_radix_long_count; at most 2^16 final runs).  The memset covers the words in use.
   uint32_t* ctl;
-  const size_t ctl_words = 8 + PART_MAX + long_cap;
-  BP_TRY(ws_get(ctx, "msm.ctl", ctl_words * 4, (void**)&ctl));
+  const size_t ctl_fixed = 8 + PART_MAX + long_cap;
+  BP_TRY(ws_get(ctx, "msm.ctl", (ctl_fixed + 65536) * 4, (void**)&ctl));
+  uint32_t* run_ticket = ctl + ctl_fixed;
   BP_TRY(ws_get(ctx, "msm.counts", (size_t)total * 4, (void**)&counts));        // bucket sizes (histogram sort; long runs of the other two)
   BP_TRY(ws_get(ctx, "msm.offsets", ((size_t)total + 1) * 4, (void**)&offsets));
   BP_TRY(ws_get(ctx, "msm.cursors", (size_t)total * 4, (void**)&cursors));
@@ -277,10 +316,6 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   BP_TRY(ws_get(ctx, "msm.partial", 2 * n_chunks * sizeof(proj28_slot), (void**)&partial));
   const uint32_t n_planes = Wr * per_window;        // tables: A and the c - 1 bit planes; else one sum per window
   if (n_planes > (uint32_t)MSM_MAX_WINDOWS) return fail(ctx, BP_ERR_TOO_LARGE, "MSM windows", hipSuccess, __FILE__, __LINE__);
-  // Bucket reduction without tables (W bucket sets of 2^(c-1) buckets): the same bit-plane tree as with tables, over a forest of W trees
-  // (round 5; rounds 1-4 ran segmented running sums per window, msm_reduce: a dependent chain of ~46 additions per lane, 256 VGPRs + spills,
-  // 0.57 ms at 2^20 points -- kept in the experiment build as BP_MSM_REDUCE=1 for the A/B), then one Horner pass over each tree's c values.
-  const bool reduce_running = EXPERIMENT_BUILD && !table_c && knob_u32("BP_MSM_REDUCE", 0, 0, 1) == 1;
   block_out = nullptr;
   if (reduce_running) BP_TRY(ws_get(ctx, "msm.block_out", (size_t)Wr * blocks_per_window * sizeof(proj28_slot), (void**)&block_out));
   proj28_slot* roots = nullptr;                     // table-free: the W roots (A, T_0 .. T_{c-2}) in front of the per-window Horner pass
@@ -296,7 +331,6 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   // Bucket sort, three builds: the partition sort (default wherever its 2^pb <= 2^11 partitions leave final runs
   // that one workgroup sorts: up to ~5 * 10^7 entries), the two-level radix sort (beyond), the one-histogram counting sort of
   // round 1 (c <= 16 only; kept selectable for A/B: BP_MSM_SORT=0 histogram, 1 two-level, 2 partition).
-  BP_HIP(ctx, hipMemsetAsync(ctl, 0, ctl_words * 4, st));
   uint32_t kb = 0;
   while ((1ull << kb) < total) kb++;
   uint32_t pb = 0;
@@ -324,6 +358,7 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   if (sort_mode != 2 && J > 1) return fail(ctx, BP_ERR_TOO_LARGE, "MSM batch too long for the partition sort", hipSuccess, __FILE__, __LINE__);
   const uint32_t rbits = kb - pb, n_final = 1u << pb;
   const size_t rhist = ((size_t)1 << rbits) * 4;
+  BP_HIP(ctx, hipMemsetAsync(ctl, 0, (ctl_fixed + n_final) * 4, st));
   uint32_t* rlong_n = ctl + 2;
   if (sort_mode == 2) {
     const bool packed = rbits + vb <= 32 && packed_env != 0;
@@ -369,9 +404,8 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
       hipLaunchKernelGGL(msm_radix_final<true>, dim3(n_final < 4096 ? n_final : 4096), dim3(final_threads), rhist, st, rr, roff, n_final, rbits, total, offsets,
                          sorted, rlong_n, rlong_list, counts);
       if (n_final > 1) {
-        hipLaunchKernelGGL(msm_radix_long_count<true>, lgrid, dim3(1024), rhist, st, rr, roff, rbits, rlong_n, rlong_list, counts);
-        hipLaunchKernelGGL(msm_radix_long_prefix, dim3(n_final < 16 ? n_final : 16), dim3(1024), 0, st, roff, n_final, rbits, total, rlong_n, rlong_list,
-                           counts, offsets, cursors);
+        hipLaunchKernelGGL(msm_radix_long_count<true>, lgrid, dim3(1024), rhist, st, rr, roff, n_final, rbits, total, rlong_n, rlong_list, counts, offsets,
+                           cursors, run_ticket);
         hipLaunchKernelGGL(msm_radix_long_scatter<true>, lgrid, dim3(1024), rhist, st, rr, roff, rbits, rlong_n, rlong_list, cursors, sorted);
       }
     } else {
@@ -381,9 +415,8 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
       hipLaunchKernelGGL(msm_radix_final<false>, dim3(n_final < 4096 ? n_final : 4096), dim3(final_threads), rhist, st, rr, roff, n_final, rbits, total, offsets,
                          sorted, rlong_n, rlong_list, counts);
       if (n_final > 1) {
-        hipLaunchKernelGGL(msm_radix_long_count<false>, lgrid, dim3(1024), rhist, st, rr, roff, rbits, rlong_n, rlong_list, counts);
-        hipLaunchKernelGGL(msm_radix_long_prefix, dim3(n_final < 16 ? n_final : 16), dim3(1024), 0, st, roff, n_final, rbits, total, rlong_n, rlong_list,
-                           counts, offsets, cursors);
+        hipLaunchKernelGGL(msm_radix_long_count<false>, lgrid, dim3(1024), rhist, st, rr, roff, n_final, rbits, total, rlong_n, rlong_list, counts, offsets,
+                           cursors, run_ticket);
         hipLaunchKernelGGL(msm_radix_long_scatter<false>, lgrid, dim3(1024), rhist, st, rr, roff, rbits, rlong_n, rlong_list, cursors, sorted);
       }
     }
@@ -465,9 +498,8 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
                        sorted, rlong_n, rlong_list, counts);
     if (runs > 1) {                 // long runs (none for uniformly random scalars beyond the top window's): slice-parallel
       const dim3 lgrid(256, runs < 16 ? runs : 16);
-      hipLaunchKernelGGL(msm_radix_long_count<false>, lgrid, dim3(1024), rhist, st, rr, run_off[level_count], rbits, rlong_n, rlong_list, counts);
-      hipLaunchKernelGGL(msm_radix_long_prefix, dim3(runs < 64 ? runs : 64), dim3(1024), 0, st, run_off[level_count], runs, rbits, total, rlong_n,
-                         rlong_list, counts, offsets, cursors);
+      hipLaunchKernelGGL(msm_radix_long_count<false>, lgrid, dim3(1024), rhist, st, rr, run_off[level_count], runs, rbits, total, rlong_n, rlong_list, counts,
+                         offsets, cursors, run_ticket);
       hipLaunchKernelGGL(msm_radix_long_scatter<false>, lgrid, dim3(1024), rhist, st, rr, run_off[level_count], rbits, rlong_n, rlong_list, cursors, sorted);
     }
   } else {
@@ -591,8 +623,8 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
       }
       flip ^= 1;
     }
-    if (!table_c)           // W roots of c values each -> W window sums A + sum_j 2^j T_j (what msm.rs:42-46 computes per window)
-      hipLaunchKernelGGL(msm_planes_window_sums, dim3(W), dim3(64), 0, st, roots, plan.c, window_sum, long_count + 1, offsets + total,
+    if (!table_c)           // W roots of c values each -> W x quads partial Horner values (the host finishes what msm.rs:42-46, 107-115 compute)
+      hipLaunchKernelGGL(msm_planes_window_quads, dim3(W), dim3(64), 0, st, roots, plan.c, quads, window_sum, long_count + 1, offsets + total,
                          reinterpret_cast<uint32_t*>(window_sum + n_planes));
   } else {
 #ifdef BP_EXPERIMENT
@@ -611,6 +643,7 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
     hdr.Wr = table_c ? 1 : Wr;
     hdr.n_planes = n_planes;
     hdr.tables = plan.naf ? 2u : (table_c != 0 ? 1u : 0u);
+    hdr.quads = table_c ? 0u : quads;
     hipLaunchKernelGGL(msm_write_blob, dim3(1), dim3(256), 0, st, window_sum, hdr, (uint8_t*)d_blob);
     BP_HIP(ctx, hipGetLastError());
   } else {
@@ -622,6 +655,7 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   out->c = plan.c;
   out->Wr = table_c ? 1 : Wr;
   out->n_planes = n_planes;
+  out->quads = quads;
   out->adds = max_entries;      // upper bound (blob mode keeps it); msm_finish replaces it by the exact count of non-zero digits
   out->h_windows = h_windows;
   return BP_OK;
@@ -659,7 +693,7 @@ int msm_finish(bp_ctx* ctx, const MsmPending& pend, g1_proj* host_out) {
     for (uint32_t j = 0; j < pend.J; j++)              // a batch: c values per vector, one Horner pass each
       host_plane_horner(host_out[j], windows.data() + (size_t)j * pend.c, pend.Wr, pend.c, pend.tables == 2);
   } else {
-    host_horner(*host_out, windows.data(), pend.Wr, pend.c);
+    host_quad_horner(*host_out, windows.data(), pend.Wr, pend.c, pend.quads);
   }
   return BP_OK;
 }
@@ -679,7 +713,8 @@ int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out) {
     // library version on a peer rank, a truncated gather) is rejected here instead of being read past its end
     if (h.n_planes != 0) {
       const bool width_ok = h.tables == 2 ? (h.c >= 5 && h.c <= 21) : (h.tables <= 1 && h.c >= 2 && h.c <= (uint32_t)MSM_MAX_TABLE_C);
-      if (!width_ok || h.Wr < 1 || h.n_planes != (h.tables ? h.Wr * h.c : h.Wr)) return BP_ERR_INVALID_ARG;
+      const uint32_t per = h.tables ? h.c : (h.quads ? h.quads : 1u);
+      if (!width_ok || h.Wr < 1 || per > 8 * 4 || h.n_planes != h.Wr * per) return BP_ERR_INVALID_ARG;
     }
     if (h.status) return BP_ERR_BAD_SCALAR;
   }
@@ -695,14 +730,14 @@ int msm_blobs_combine(const uint8_t* blobs, size_t n_blobs, g1_proj* out) {
     for (size_t k = i + 1; k < n_blobs; k++) {
       MsmBlobHeader g;
       memcpy(&g, blobs + k * BP_MSM_BLOB_BYTES, sizeof g);
-      if (done[k] || g.c != h.c || g.Wr != h.Wr || g.n_planes != h.n_planes || g.tables != h.tables) continue;
+      if (done[k] || g.c != h.c || g.Wr != h.Wr || g.n_planes != h.n_planes || g.tables != h.tables || g.quads != h.quads) continue;
       done[k] = true;
       const proj28_slot* sk = reinterpret_cast<const proj28_slot*>(blobs + k * BP_MSM_BLOB_BYTES + sizeof(MsmBlobHeader));
       for (uint32_t w = 0; w < h.n_planes; w++) g1_add(sum[w], sum[w], slot_to_proj(&sk[w]));
     }
     g1_proj part;
     if (h.tables) host_plane_horner(part, sum.data(), h.Wr, h.c, h.tables == 2);
-    else host_horner(part, sum.data(), h.Wr, h.c);
+    else host_quad_horner(part, sum.data(), h.Wr, h.c, h.quads ? h.quads : 1u);
     g1_add(total, total, part);
   }
   *out = total;

@@ -31,6 +31,7 @@
 #pragma once
 #include "g1.hpp"
 #include "g1_28.hpp"
+#include "msm_digits.hpp"
 
 namespace bp {
 
@@ -72,6 +73,17 @@ struct MsmPlan {
   // pipeline's index space, elements with i >= nj[j] do not exist.  Partition sort only (msm_part_*); J = 1 everywhere else.
   uint32_t J;          // 1 .. MSM_MAX_BATCH
   uint32_t nj[4];      // length of vector j
+  // Fixed-base tables free the digit radix from being a power of two (round 6): T[w][i] = R^w P_i for ANY R.  W windows of c bits cover
+  // c W >= 256 bits, but a scalar has 255: at c = 20 (13 windows) five bits of every bucket index are bought and never used.  With
+  // R = the smallest (low Hamming weight) even number whose W-th power exceeds 2^256 the signed digits |d| <= R / 2 fill R / 2 buckets
+  // instead of 2^(c-1): 425 984 instead of 524 288 at 13 windows, 1 327 104 instead of 2 097 152 at 12 -- a fifth to a third of the
+  // bucket tree's leaves (and of its additions) gone; the live buckets are a PREFIX of the 2^(c-1) the tree is sized for, the rest
+  // stay empty and whole waves of the tree skip them.  radix = 0: power-of-two windows (every table-free MSM; widths that waste < 10 %).
+  // Digits: k' = k + bias (bias = sum_{w < W-1} (R / 2) R^w), f = k' / R^W as a 288-bit fraction = the top limbs of k' * radix_m
+  // (radix_m = ceil(2^512 / R^W)) + 2 ulp, then W times "multiply by R, take the integer part" from the top digit down; signed digit
+  // = that - R / 2 below the top window.  Exact: the fraction's error is in [0, 2^-257 + 2^-287) and 1 / R^W > 2^-256.93 (make_plan).
+  uint32_t radix;
+  uint32_t radix_m[8];
 };
 constexpr uint32_t MSM_MAX_BATCH = 4;
 struct MsmScalars { const fr_t* p[MSM_MAX_BATCH]; };
@@ -513,12 +525,20 @@ __global__ void __launch_bounds__(1024) msm_radix_final(RunRecords<PACKED> recs,
   }
 }
 
-// long runs, slice-parallel: count -> prefix (offsets and cursors of the run's buckets) -> scatter.  grid (slices, lanes of the
-// list); workgroup (x, y) takes slices x, x + gridDim.x, ... of the long runs y, y + gridDim.y, ...
+// long runs, slice-parallel: count (+ prefix = offsets and cursors of the run's buckets, by the run's last workgroup) -> scatter.
+// grid (slices, lanes of the list); workgroup (x, y) takes slices x, x + gridDim.x, ... of the long runs y, y + gridDim.y, ...
+// Round 6: two launches instead of three.  Every long run k is visited by exactly gridDim.x workgroups (those with blockIdx.y = k mod
+// gridDim.y, with or without slices of their own); each takes a ticket of the run when its slices are counted, and the one that takes
+// the last ticket scans the run's bucket sizes (what msm_radix_long_prefix did in a launch of its own).  ticket[k]: zero before the
+// launch, zero again after it.  The sizes are only ever touched by device-scope atomics (as in msm_part_count), so the last workgroup
+// reads them with an addition of zero and needs no cache maintenance.
 template <bool PACKED>
-__global__ void __launch_bounds__(1024) msm_radix_long_count(RunRecords<PACKED> recs, const uint32_t* __restrict__ run_off, uint32_t rbits,
-                                                             const uint32_t* __restrict__ long_n, const uint32_t* __restrict__ long_list,
-                                                             uint32_t* __restrict__ counts) {
+__global__ void __launch_bounds__(1024) msm_radix_long_count(RunRecords<PACKED> recs, const uint32_t* __restrict__ run_off, uint32_t n_runs, uint32_t rbits,
+                                                             uint32_t total, const uint32_t* __restrict__ long_n, const uint32_t* __restrict__ long_list,
+                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors,
+                                                             uint32_t* __restrict__ ticket) {
+  __shared__ uint32_t scan16[16];
+  __shared__ uint32_t carry, last_s;
   const uint32_t nb = 1u << rbits, n_long = *long_n;
   for (uint32_t k = blockIdx.y; k < n_long; k += gridDim.y) {
     const uint32_t run = long_list[k], lo = run_off[run], hi = run_off[run + 1];
@@ -534,24 +554,19 @@ __global__ void __launch_bounds__(1024) msm_radix_long_count(RunRecords<PACKED> 
       }
       __syncthreads();
     }
-  }
-}
-// one workgroup per long run
-__global__ void __launch_bounds__(1024) msm_radix_long_prefix(const uint32_t* __restrict__ run_off, uint32_t n_runs, uint32_t rbits, uint32_t total,
-                                                              const uint32_t* __restrict__ long_n, const uint32_t* __restrict__ long_list,
-                                                              const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                              uint32_t* __restrict__ cursors) {
-  __shared__ uint32_t scan16[16];
-  __shared__ uint32_t carry;
-  const uint32_t nb = 1u << rbits, n_long = *long_n;
-  for (uint32_t k = blockIdx.x; k < n_long; k += gridDim.x) {
-    const uint32_t run = long_list[k], lo = run_off[run];
-    if (threadIdx.x == 0) carry = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this workgroup's additions have been performed before it takes its ticket
     __syncthreads();
+    if (threadIdx.x == 0) {
+      last_s = atomicAdd(&ticket[k], 1u) == gridDim.x - 1 ? 1u : 0u;
+      carry = 0;
+    }
+    __syncthreads();
+    if (!last_s) continue;                                 // uniform over the workgroup
+    if (threadIdx.x == 0) ticket[k] = 0;                   // as found, for the next launch
     for (uint32_t b0 = 0; b0 < nb; b0 += blockDim.x) {
       const uint32_t b = b0 + threadIdx.x;
       const uint64_t bucket = ((uint64_t)run << rbits) + b;
-      const uint32_t v = (b < nb && bucket < total) ? counts[bucket] : 0u;
+      const uint32_t v = (b < nb && bucket < total) ? atomicAdd(&counts[bucket], 0u) : 0u;
       const uint32_t ex = block_exclusive_scan_1024(v, scan16) + carry;
       if (b < nb && bucket < total) {
         offsets[bucket] = lo + ex;
@@ -607,15 +622,17 @@ constexpr uint32_t PART_MAX_BITS = 12, PART_MAX = 1u << PART_MAX_BITS;
 
 // every (bucket id, entry | sign << 31) of scalar i, in window (or NAF slot) order.  status != null: canonical-bytes inputs are
 // range-checked (Scalar::from_bytes rejects values >= q, scalar.rs:264-288)
-template <class F>
-__device__ __forceinline__ void msm_scalar_entries(fr_t k, uint32_t i, uint32_t bucket_base, int fmt, const MsmPlan& plan,
-                                                   uint32_t* __restrict__ status, F&& emit) {
+// the scalar as the canonical integer the digits are cut from
+__device__ __forceinline__ void msm_scalar_canon(fr_t& k, int fmt, uint32_t* __restrict__ status) {
   if (fmt == 1) {
     Fr::from_mont(k, k);                           // msm.rs:126: scalar.to_bytes() = canonical integer
   } else if (status) {
     fr_t t;
     if (!big_sub(t, k, Fr::modulus())) atomicOr(status, 1u);
   }
+}
+template <class F>
+__device__ __forceinline__ void msm_canon_entries(const fr_t& k, uint32_t i, uint32_t bucket_base, const MsmPlan& plan, F&& emit) {
   if (plan.naf) {                                  // as msm_naf_records
     uint32_t kw[10];
 #pragma unroll
@@ -653,6 +670,12 @@ __device__ __forceinline__ void msm_scalar_entries(fr_t k, uint32_t i, uint32_t 
     }
     return;
   }
+  if (plan.radix) {                                // digits in radix R (MsmPlan::radix, msm_digits.hpp), top window first
+    msm_radix_digits(k.l, plan.radix, plan.radix_m, plan.bias, plan.W, [&](uint32_t w, int32_t d) {
+      if (d != 0) emit(bucket_base + digit_bucket(d), (i + w * plan.wpoints) | (d < 0 ? 0x80000000u : 0u));
+    });
+    return;
+  }
   uint32_t kp[10];
   uint64_t carry = 0;
 #pragma unroll
@@ -670,23 +693,39 @@ __device__ __forceinline__ void msm_scalar_entries(fr_t k, uint32_t i, uint32_t 
     if (d != 0) emit(bucket_base + w * plan.wbuckets + digit_bucket(d), (i + w * plan.wpoints) | (d < 0 ? 0x80000000u : 0u));
   }
 }
+template <class F>
+__device__ __forceinline__ void msm_scalar_entries(fr_t k, uint32_t i, uint32_t bucket_base, int fmt, const MsmPlan& plan,
+                                                   uint32_t* __restrict__ status, F&& emit) {
+  msm_scalar_canon(k, fmt, status);
+  msm_canon_entries(k, i, bucket_base, plan, emit);
+}
 
-// the entries of the scalars [lo, hi) of the pipeline's index space (element x = vector x / n, position x % n)
+// element x of the pipeline's index space (vector x / n, position x % n): its scalar, position and bucket base; false: no such element
+__device__ __forceinline__ bool msm_slice_scalar(const MsmScalars& sc, uint64_t x, const MsmPlan& plan, fr_t& k, uint32_t& i, uint32_t& base) {
+  uint32_t j = 0;
+  i = (uint32_t)x;
+  if (plan.J > 1) {
+    j = (uint32_t)(x / plan.n);
+    i = (uint32_t)(x - (uint64_t)j * plan.n);
+  }
+  if (i >= plan.nj[j]) return false;
+  const fr_t* __restrict__ src = sc.p[0];
+  if (j == 1) src = sc.p[1];
+  if (j == 2) src = sc.p[2];
+  if (j == 3) src = sc.p[3];
+  k = src[i];
+  base = j * plan.B;
+  return true;
+}
+// the entries of the scalars [lo, hi) of the pipeline's index space
 template <class F>
 __device__ __forceinline__ void msm_slice_entries(const MsmScalars& sc, uint64_t lo, uint64_t hi, int fmt, const MsmPlan& plan,
                                                   uint32_t* __restrict__ status, F&& emit) {
   for (uint64_t x = lo + threadIdx.x; x < hi; x += blockDim.x) {
-    uint32_t j = 0, i = (uint32_t)x;
-    if (plan.J > 1) {
-      j = (uint32_t)(x / plan.n);
-      i = (uint32_t)(x - (uint64_t)j * plan.n);
-    }
-    if (i >= plan.nj[j]) continue;
-    const fr_t* __restrict__ src = sc.p[0];
-    if (j == 1) src = sc.p[1];
-    if (j == 2) src = sc.p[2];
-    if (j == 3) src = sc.p[3];
-    msm_scalar_entries(src[i], i, j * plan.B, fmt, plan, status, emit);
+    fr_t k;
+    uint32_t i, base;
+    if (!msm_slice_scalar(sc, x, plan, k, i, base)) continue;
+    msm_scalar_entries(k, i, base, fmt, plan, status, emit);
   }
 }
 
@@ -753,7 +792,21 @@ __global__ void __launch_bounds__(1024) msm_part_scatter(MsmScalars scalars, int
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   const uint64_t all = (uint64_t)plan.J * plan.n, lo = (uint64_t)blockIdx.x * slice, hi = lo + slice < all ? lo + slice : all;
-  msm_slice_entries(scalars, lo, hi, fmt, plan, nullptr, [&](uint32_t bucket, uint32_t) { atomicAdd(&h[bucket >> rbits], 1u); });
+  // One scalar per lane (the usual shape: slices of <= 1 024 scalars under 1 024 lanes): the canonical integer stays in registers between
+  // the counting pass and the staging pass -- the second Montgomery conversion of round 5's scatter is gone (uniform over the workgroup)
+  const bool one = slice <= blockDim.x;
+  fr_t kc;
+  uint32_t ic = 0, bc = 0;
+  bool live = false;
+  if (one && lo + threadIdx.x < hi) {
+    live = msm_slice_scalar(scalars, lo + threadIdx.x, plan, kc, ic, bc);
+    if (live) msm_scalar_canon(kc, fmt, nullptr);
+  }
+  if (one) {
+    if (live) msm_canon_entries(kc, ic, bc, plan, [&](uint32_t bucket, uint32_t) { atomicAdd(&h[bucket >> rbits], 1u); });
+  } else {
+    msm_slice_entries(scalars, lo, hi, fmt, plan, nullptr, [&](uint32_t bucket, uint32_t) { atomicAdd(&h[bucket >> rbits], 1u); });
+  }
   __syncthreads();
   // this slice's share of every partition: place in the staging area (lbase) and in the partition's final run (gbase).  The
   // reservations (one returning global atomic per partition the slice touches) are all issued before the scan's barriers, so
@@ -774,7 +827,7 @@ __global__ void __launch_bounds__(1024) msm_part_scatter(MsmScalars scalars, int
     if (threadIdx.x == blockDim.x - 1) carry_s = ex + v;
     __syncthreads();
   }
-  msm_slice_entries(scalars, lo, hi, fmt, plan, nullptr, [&](uint32_t bucket, uint32_t val) {
+  auto stage = [&](uint32_t bucket, uint32_t val) {
     const uint32_t part = bucket >> rbits, pos = lbase[part] + atomicAdd(&h[part], 1u);
     if (PACKED) {
       st_key[pos] = ((bucket & rmask) << vb) | ((val >> 31) << (vb - 1)) | (val & 0x7fffffffu);
@@ -783,7 +836,12 @@ __global__ void __launch_bounds__(1024) msm_part_scatter(MsmScalars scalars, int
       st_val[pos] = val;
     }
     if (FLAT) st_part[pos] = (uint16_t)part;
-  });
+  };
+  if (one) {
+    if (live) msm_canon_entries(kc, ic, bc, plan, stage);
+  } else {
+    msm_slice_entries(scalars, lo, hi, fmt, plan, nullptr, stage);
+  }
   __syncthreads();
   if (FLAT) {
     const uint32_t live = carry_s;
@@ -915,7 +973,9 @@ __device__ __forceinline__ M28 one_m28() {
   for (int j = 0; j < N28; j++) r.l[j] = One28::limb(j);
   return r;
 }
-__global__ void __launch_bounds__(256) srs_window_tables(const g1_affine28* __restrict__ in28, size_t n, uint32_t c, uint32_t W,
+// radix != 0: row w = radix^w P (MsmPlan::radix) -- one small scalar multiplication per row (20 doublings + 3 additions for R = 0xD0000)
+// instead of c doublings.
+__global__ void __launch_bounds__(256) srs_window_tables(const g1_affine28* __restrict__ in28, size_t n, uint32_t c, uint32_t W, uint32_t radix,
                                                          g1_affine28* __restrict__ table) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -936,7 +996,9 @@ __global__ void __launch_bounds__(256) srs_window_tables(const g1_affine28* __re
   for (uint32_t w0 = 1; w0 < W; w0 += TABLE_GROUP) {
     const uint32_t cnt = W - w0 < (uint32_t)TABLE_GROUP ? W - w0 : (uint32_t)TABLE_GROUP;
     for (uint32_t j = 0; j < cnt; j++) {
-      for (uint32_t d = 0; d < c; d++) g1_double28(p, p);
+      if (radix) g1_mul_small28(p, p, radix, 32 - __clz(radix));
+      else
+        for (uint32_t d = 0; d < c; d++) g1_double28(p, p);
       row[j] = p;
       prefix[j] = mul28(j == 0 ? one : prefix[j - 1], p.z);       // (the first product only brings z to the product's bounds)
     }
@@ -992,6 +1054,9 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
   // dependent load (the wave used to stall on offsets[g + 1] at every boundary -- four per lane at c = 20, where some lane of a
   // wave leaves a bucket in most iterations -- and to re-read offsets[g] for the "whole bucket" test)
   uint32_t g = bucket_of(offsets, total, p0);
+  // (Round 6 tried to hand this bucket to msm_fixup_edges, which bisects for the same position again: ONE 4-byte store per lane here,
+  // before the loop, cost the kernel 5 % -- 1.93 -> 2.03 ms at 2^20, 0.194 -> 0.207 at 2^16, three alternating rounds on one box -- against
+  // 3 us saved there: profiles/r06_tail_ab.txt.  The store shares the loop's vmcnt counter with the gathers.)
   uint32_t g_start = offsets[g], g_end = offsets[g + 1];
   uint32_t g_end2 = g + 2 <= total ? offsets[g + 2] : M;
   uint32_t run_start = p0;
@@ -1042,7 +1107,8 @@ struct MsmBlobHeader {
   uint32_t magic, c, Wr, n_planes, tables, status, entries;
   int32_t err;
   uint32_t err_rank;
-  uint32_t pad[7];
+  uint32_t quads;      // table-free records: values per window (msm_planes_window_quads); 0 or 1: one window sum each
+  uint32_t pad[6];
 };
 static_assert(sizeof(MsmBlobHeader) == 64, "blob header");
 constexpr uint32_t MSM_BLOB_MAGIC = 0x424d5042u;      // "BPMB"
@@ -1071,7 +1137,7 @@ __global__ void __launch_bounds__(64) msm_blob_sum(const uint8_t* __restrict__ b
   int32_t err = 0;
   for (uint32_t k = 0; k < n_blobs; k++) {
     const MsmBlobHeader h = *reinterpret_cast<const MsmBlobHeader*>(blobs + (size_t)k * blob_bytes);
-    same = same && h.magic == h0.magic && h.c == h0.c && h.Wr == h0.Wr && h.n_planes == h0.n_planes && h.tables == h0.tables;
+    same = same && h.magic == h0.magic && h.c == h0.c && h.Wr == h0.Wr && h.n_planes == h0.n_planes && h.tables == h0.tables && h.quads == h0.quads;
     status |= h.status;
     entries += h.entries;
     if (err == 0 && h.magic == MSM_BLOB_MAGIC && h.err != 0) { err = h.err; err_rank = h.err_rank; }      // the lowest poisoned rank speaks for all
@@ -1472,43 +1538,50 @@ msm_planes_step(const uint32_t* __restrict__ offsets, const proj28_slot* __restr
   }
 }
 
-// Table-free path (per-window bucket sets): the forest's W roots, c values each (A, T_0 .. T_{c-2}), become the W window sums
-//   sum_b (b + 1) S_{w,b} = A_w + sum_j 2^j T_{w,j}
-// by Horner over the bit planes; all windows side by side, one 64-lane workgroup each; the host's Horner over the windows
-// (msm.rs:107-115) then sees the same W sums as ever.  The c - 1 planes of a window are cut into four runs: four cooperative groups
-// evaluate their run's Horner form side by side (2 (q - 1) dependent cooperative operations for runs of q planes), one group joins the
-// four partial values (q doublings + one addition each) and adds A: 22 dependent operations at c = 16 instead of 29 for the plain chain
-// (~2.8 us each).  The last kernel of the MSM: it also moves the scalar-status word and the entry count behind the sums.
-__global__ void __launch_bounds__(64) msm_planes_window_sums(const proj28_slot* __restrict__ roots, uint32_t c, proj28_slot* __restrict__ window_sum,
-                                                             const uint32_t* __restrict__ status_in, const uint32_t* __restrict__ entries_in,
-                                                             uint32_t* __restrict__ status_out) {
+// Table-free path (per-window bucket sets): the forest's W roots, c values each (A, T_0 .. T_{c-2}), on their way to
+//   sum_b (b + 1) S_{w,b} = A_w + sum_j 2^j T_{w,j}      (what msm.rs:42-46 computes per window).
+// Every factor 2^j is j DEPENDENT doublings, whoever performs them, and the host performs one in ~0.5 us where a lone wave needs ~7 us
+// per cooperative operation: round 5 evaluated the whole form here (22 dependent operations at c = 16: 148 us on 16 waves) and the host
+// then doubled its way through the 16 window sums anyway.  Round 6 stops after two levels: a window's planes are folded in QUADS
+//   Q_j = (T_4j + 2 T_4j+1) + 4 (T_4j+2 + 2 T_4j+3)     (+ A in quad 0),   j < ceil((c - 1) / 4)
+// -- five dependent operations, every quad of every window side by side -- and the host's one Horner pass runs over the quads (the same
+// c (W - 1) + ... doublings as before, 48 more additions at c = 16).  One 64-lane workgroup per window: eight cooperative groups =
+// four quads x two halves; every group issues the same five operations (a half that has nothing to add adds the identity: the complete
+// formulas make that a no-op), so the wave never diverges.  out[w * nq + j].
+// The last kernel of the MSM: it also moves the scalar-status word and the entry count behind the values.
+__global__ void __launch_bounds__(64) msm_planes_window_quads(const proj28_slot* __restrict__ roots, uint32_t c, uint32_t nq, proj28_slot* __restrict__ window_sum,
+                                                              const uint32_t* __restrict__ status_in, const uint32_t* __restrict__ entries_in,
+                                                              uint32_t* __restrict__ status_out) {
   __shared__ proj28_slot part[4];
-  const uint32_t w = blockIdx.x, grp = threadIdx.x / COOP;
+  const uint32_t w = blockIdx.x, grp = threadIdx.x / COOP, j = grp >> 1, h = grp & 1;
   const bool lead = (threadIdx.x & (COOP - 1)) == 0;
   if (w == 0 && threadIdx.x == 0) { status_out[0] = *status_in; status_out[1] = *entries_in; }
   const proj28_slot* r = roots + (size_t)w * c;
-  const uint32_t np = c - 1, q = (np + 3) / 4;          // planes T_0 .. T_{np-1} at r[1 ..]; runs of q planes (the last may be shorter or empty)
-  if (grp < 4) {                                        // uniform over a cooperative group
-    const uint32_t lo = grp * q, hi = lo + q < np ? lo + q : np;
-    g1_proj28 t = g1_identity28();
-    if (lo < hi) {
-      t = load_proj28(&r[hi]);                          // T_{hi-1}
-      for (uint32_t j = hi - 1; j-- > lo;) {
-        t = g1_add28_coop(t, t);
-        t = g1_add28_coop(t, load_proj28(&r[1 + j]));
-      }
+  const uint32_t np = c - 1, p0 = 4 * j + 2 * h, p1 = p0 + 1;       // this half: T_p0 + 2 T_p1 (planes that do not exist are the identity)
+  // (operands are picked limb by limb: a ?: between whole points goes through a stack frame)
+  auto pick = [](bool c, const g1_proj28& a, const g1_proj28& b) {
+    g1_proj28 o;
+#pragma unroll
+    for (int i = 0; i < N28; i++) {
+      o.x.l[i] = c ? a.x.l[i] : b.x.l[i];
+      o.y.l[i] = c ? a.y.l[i] : b.y.l[i];
+      o.z.l[i] = c ? a.z.l[i] : b.z.l[i];
     }
-    if (lead) store_proj28(&part[grp], t);
-  }
+    return o;
+  };
+  const g1_proj28 blank = g1_identity28();
+  const bool have1 = j < nq && p1 < np, have0 = j < nq && p0 < np;
+  g1_proj28 t = pick(have1, load_proj28(&r[have1 ? 1 + p1 : 0]), blank);
+  t = g1_add28_coop(t, t);
+  t = g1_add28_coop(t, pick(have0, load_proj28(&r[have0 ? 1 + p0 : 0]), blank));
+  // upper half: x 4; lower half: + A (quad 0 only), then nothing
+  t = g1_add28_coop(t, pick(h != 0, t, pick(j == 0, load_proj28(&r[0]), blank)));
+  t = g1_add28_coop(t, pick(h != 0, t, blank));
+  if (h && lead && j < 4) store_proj28(&part[j], t);
   __syncthreads();
-  if (grp != 0) return;
-  g1_proj28 acc = load_proj28(&part[3]);
-  for (uint32_t g = 3; g-- > 0;) {
-    for (uint32_t d = 0; d < q; d++) acc = g1_add28_coop(acc, acc);
-    acc = g1_add28_coop(acc, load_proj28(&part[g]));
-  }
-  acc = g1_add28_coop(acc, load_proj28(&r[0]));         // + A
-  if (lead) store_proj28(&window_sum[w], acc);
+  if (h) return;
+  t = g1_add28_coop(t, load_proj28(&part[j]));
+  if (lead && j < nq) store_proj28(&window_sum[(size_t)w * nq + j], t);
 }
 
 }  // namespace bp

@@ -203,17 +203,32 @@ int ntt_run_part(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batc
       }
       unsigned first, count;
       tile_range((unsigned)(N >> (l + cl)), &first, &count);
-      hipLaunchKernelGGL(swizzled(l, cl) ? ntt_pass_strided_swz : ntt_pass_strided, dim3(count, (unsigned)batch),
-                         dim3(pass_threads(l, cl)), lds, st, i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp, tmp, i == 0 ? stride : N, N, k, l, s,
-                         cl, small, tab->lo, hi, tab->h, tab->full[i], first);
+      NttStridedArgs sa;
+      sa.src = i == 0 ? (const fr_t*)d_data : (const fr_t*)tmp;
+      sa.src_stride = i == 0 ? stride : N;
+      sa.k = k; sa.l = l; sa.s = s; sa.cl = cl;
+      sa.small_tw = small;
+      sa.tile0 = first;
+      sa.h = tab->h;
+      sa.dst = tmp;
+      sa.dst_stride = N;
+      sa.tw_lo = tab->lo; sa.tw_hi = hi; sa.tw_full = tab->full[i];
+      hipLaunchKernelGGL(swizzled(l, cl) ? ntt_pass_strided_swz : ntt_pass_strided, dim3(count, (unsigned)batch), dim3(pass_threads(l, cl)), lds, st, sa);
     }
     if (phase != 0) {
       const uint32_t l = plan.l[plan.P - 1], cl = plan.cl[plan.P - 1];
       const size_t lds = tile_lds(l, cl);
       unsigned first, count;
       tile_range((unsigned)(N >> (l + cl)), &first, &count);
-      hipLaunchKernelGGL(swizzled(l, cl) ? ntt_pass_last_swz : ntt_pass_last, dim3(count, (unsigned)batch),
-                         dim3(pass_threads(l, cl)), lds, st, (const fr_t*)tmp, d_data, N, stride, plan, small, first);
+      NttLastArgs la;
+      la.src = tmp;
+      la.src_stride = N;
+      la.small_tw = small;
+      la.tile0 = first;
+      la.plan = plan;
+      la.dst = d_data;
+      la.dst_stride = stride;
+      hipLaunchKernelGGL(swizzled(l, cl) ? ntt_pass_last_swz : ntt_pass_last, dim3(count, (unsigned)batch), dim3(pass_threads(l, cl)), lds, st, la);
     }
   }
   BP_HIP(ctx, hipGetLastError());

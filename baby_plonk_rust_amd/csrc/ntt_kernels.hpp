@@ -274,30 +274,61 @@ __global__ void __launch_bounds__(256) ntt_make_pass_table(const tw29_t* __restr
   store_tw29(&out[x], twiddle_lookup(lo, hi, h, (e * r) << tshift));
 }
 
+// Kernel arguments of a pass travel as ONE struct (= the kernarg segment).  The fields of the FILL phase are read the usual way; the
+// fields only the DRAIN phase needs (destination, inter-pass twiddle tables) are read back from the kernarg segment AFTER the
+// butterflies, behind an opaque barrier the compiler cannot hoist them over: rounds 2-5 kept all fourteen arguments in scalar
+// registers through the whole pass, which put every ntt_pass_* at the 106-SGPR ceiling with 4-6 spilled and a (never used) 36-byte
+// scratch frame per lane.
+struct NttStridedArgs {
+  const fr_t* src;
+  size_t src_stride;
+  uint32_t k, l, s, cl;          // l digit width, s = bits below the digit, k = log2 N, cl = log2 of the tile's columns
+  const tw29_t* small_tw;
+  uint32_t tile0, h;             // tile0: first tile of this launch (a member of a group context runs a slice of the tiles)
+  // drain phase
+  fr_t* dst;
+  size_t dst_stride;
+  const tw29_t *tw_lo, *tw_hi, *tw_full;
+};
+template <class A>
+__device__ __forceinline__ const A* ntt_late_args() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const A* p = (const A*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));    // the loads through p stay behind this point
+  return p;
+#else
+  return nullptr;                // (host pass of the compiler: never executed)
+#endif
+}
+
 // Strided pass (every pass but the last).  grid.x = tiles, grid.y = batch.
-//   l      digit width, s = bits below the digit, mlog = l + s, k = log2 N
-//   element (hi, d, r): address hi * 2^mlog + d * 2^s + r; tile = all d x C consecutive r.
+//   element (hi, d, r): address hi * 2^mlog + d * 2^s + r (mlog = l + s); tile = all d x C consecutive r.
 template <bool SWZ>
-__device__ __forceinline__ void ntt_pass_strided_body(const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride,
-                                                      uint32_t k, uint32_t l, uint32_t s, uint32_t cl,
-                                                      const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo,
-                                                      const tw29_t* __restrict__ tw_hi, uint32_t h, const tw29_t* __restrict__ tw_full, uint32_t tile0) {
+__device__ __forceinline__ void ntt_pass_strided_body(const NttStridedArgs& a) {
+  const fr_t* src = a.src;
+  const tw29_t* __restrict__ small_tw = a.small_tw;
+  const uint32_t k = a.k, l = a.l, s = a.s, cl = a.cl;
   const uint32_t C = 1u << cl, CP = SWZ || C == 1 ? C : C + 1;        // a single column needs no row pad
-  const uint32_t bx = blockIdx.x + tile0;           // tile0: first tile of this launch (a member of a group context runs a slice of the tiles)
+  const uint32_t bx = blockIdx.x + a.tile0;
   const uint32_t L = 1u << l, mlog = l + s, tstride = (L * CP + 1) & ~1u;      // even: the limb-pair arrays stay 8-byte aligned
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
-  const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
   const uint32_t tiles_per_hi = 1u << (s - cl);
   const uint32_t hi = bx / tiles_per_hi, r0 = (bx % tiles_per_hi) << cl;
-  const size_t base = ((size_t)hi << mlog) + r0;
-  for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
-    const uint32_t c = x & (C - 1), d = x >> cl;
-    lds_st29(tile, tstride, tile_at<SWZ>(d, c, CP), fr29_from_sat(load_fr(&src[soff + base + ((size_t)d << s) + c])));
+  {
+    const size_t soff = (size_t)blockIdx.y * a.src_stride, base = ((size_t)hi << mlog) + r0;
+    for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
+      const uint32_t c = x & (C - 1), d = x >> cl;
+      lds_st29(tile, tstride, tile_at<SWZ>(d, c, CP), fr29_from_sat(load_fr(&src[soff + base + ((size_t)d << s) + c])));
+    }
   }
   lds_fill_stage_twiddles(tw, l, small_tw);
   __syncthreads();
   lds_ntt_dif<SWZ>(tile, tstride, tw, small_tw, l, cl, CP);
+  const NttStridedArgs* late = ntt_late_args<NttStridedArgs>();
+  fr_t* dst = late->dst;
+  const tw29_t* __restrict__ tw_full = late->tw_full;
+  const size_t base = ((size_t)hi << mlog) + r0, doff = (size_t)blockIdx.y * late->dst_stride;
   const uint32_t tshift = k - mlog;                 // w_M^x = w_N^(x << tshift)
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t c = x & (C - 1), e = x >> cl;
@@ -306,54 +337,64 @@ __device__ __forceinline__ void ntt_pass_strided_body(const fr_t* src, fr_t* dst
       v = fr29_mul(v, load_tw29(&tw_full[((size_t)e << s) + r0 + c]));
     } else {
       const uint64_t E = ((uint64_t)e * (r0 + c)) << tshift;
-      v = fr29_mul(v, twiddle_lookup(tw_lo, tw_hi, h, E));   // tw_hi may carry the folded N^-1 (first pass of an inverse)
+      v = fr29_mul(v, twiddle_lookup(late->tw_lo, late->tw_hi, late->h, E));   // tw_hi may carry the folded N^-1 (first pass of an inverse)
     }
     // dst is the transform's own intermediate buffer: the value (< 2q < 2^256 after the product) is only packed, not brought
     // below q -- the next pass accepts anything below 2q; the last pass writes canonical residues
     store_fr(&dst[doff + base + ((size_t)e << s) + c], fr29_pack(v));
   }
 }
-#define BP_NTT_STRIDED_ARGS const fr_t* src, fr_t* dst, size_t src_stride, size_t dst_stride, uint32_t k, uint32_t l, uint32_t s, uint32_t cl, \
-    const tw29_t* __restrict__ small_tw, const tw29_t* __restrict__ tw_lo, const tw29_t* __restrict__ tw_hi, uint32_t h, const tw29_t* __restrict__ tw_full, \
-    uint32_t tile0
-__global__ void __launch_bounds__(512) ntt_pass_strided(BP_NTT_STRIDED_ARGS) {
-  ntt_pass_strided_body<false>(src, dst, src_stride, dst_stride, k, l, s, cl, small_tw, tw_lo, tw_hi, h, tw_full, tile0);
-}
+__global__ void __launch_bounds__(512) ntt_pass_strided(NttStridedArgs a) { ntt_pass_strided_body<false>(a); }
 // 2^l x 8 tiles, l <= 7, unpadded with swizzled rows: 256 lanes, three workgroups per CU
-__global__ void __launch_bounds__(256, 3) ntt_pass_strided_swz(BP_NTT_STRIDED_ARGS) {
-  ntt_pass_strided_body<true>(src, dst, src_stride, dst_stride, k, l, s, cl, small_tw, tw_lo, tw_hi, h, tw_full, tile0);
-}
+__global__ void __launch_bounds__(256, 3) ntt_pass_strided_swz(NttStridedArgs a) { ntt_pass_strided_body<true>(a); }
 
 // Last pass: contiguous rows of length L = 2^l (l = l_P); tile = C rows with consecutive e_1.
 // Row (e_1, mid): src address (e_1 * 2^(s1 - l) + mid) * L + d, s1 = k - l_1.
 // Output index = e_1 + 2^(l_1) * rev_digits(mid) + 2^(k - l) * e_P, where mid = (e_2..e_{P-1}) is re-ordered
 // digit by digit (least significant output digit first).
+struct NttLastArgs {
+  const fr_t* src;
+  size_t src_stride;
+  const tw29_t* small_tw;
+  uint32_t tile0;
+  NttPlan plan;
+  // drain phase
+  fr_t* dst;
+  size_t dst_stride;
+};
 template <bool SWZ>
-__device__ __forceinline__ void ntt_pass_last_body(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
-                                                   size_t dst_stride, const NttPlan& plan, const tw29_t* __restrict__ small_tw, uint32_t tile0) {
-  const uint32_t k = plan.k, P = plan.P, l = plan.l[P - 1], l1 = plan.l[0], L = 1u << l, bx = blockIdx.x + tile0;
-  const uint32_t cl = plan.cl[P - 1], C = 1u << cl, CP = SWZ || C == 1 ? C : C + 1, tstride = (L * CP + 1) & ~1u;
+__device__ __forceinline__ void ntt_pass_last_body(const NttLastArgs& a) {
+  const fr_t* __restrict__ src = a.src;
+  const tw29_t* __restrict__ small_tw = a.small_tw;
+  const uint32_t k = a.plan.k, P = a.plan.P, l = a.plan.l[P - 1], l1 = a.plan.l[0], L = 1u << l, bx = blockIdx.x + a.tile0;
+  const uint32_t cl = a.plan.cl[P - 1], C = 1u << cl, CP = SWZ || C == 1 ? C : C + 1, tstride = (L * CP + 1) & ~1u;
   uint32_t* tile = ntt_lds_raw;
   uint32_t* tw = tile + N29 * tstride;
-  const size_t soff = (size_t)blockIdx.y * src_stride, doff = (size_t)blockIdx.y * dst_stride;
   const uint32_t midbits = k - l1 - l;              // bits of (e_2 .. e_{P-1})
   // blockIdx.x enumerates (e1_tile, mid): e_1 = e1_tile * C + c
   const uint32_t mid = bx & ((1u << midbits) - 1u), e1_0 = (bx >> midbits) << cl;
-  for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
-    const uint32_t d = x % L, c = x / L;
-    const size_t row = ((size_t)(e1_0 + c) << midbits) + mid;
-    lds_st29(tile, tstride, tile_at<SWZ>(d, c, CP), fr29_from_sat(load_fr(&src[soff + (row << l) + d])));
+  {
+    const size_t soff = (size_t)blockIdx.y * a.src_stride;
+    for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
+      const uint32_t d = x % L, c = x / L;
+      const size_t row = ((size_t)(e1_0 + c) << midbits) + mid;
+      lds_st29(tile, tstride, tile_at<SWZ>(d, c, CP), fr29_from_sat(load_fr(&src[soff + (row << l) + d])));
+    }
   }
   lds_fill_stage_twiddles(tw, l, small_tw);
   __syncthreads();
   lds_ntt_dif<SWZ>(tile, tstride, tw, small_tw, l, cl, CP);
+  const NttLastArgs* late = ntt_late_args<NttLastArgs>();
+  fr_t* __restrict__ dst = late->dst;
+  const size_t doff = (size_t)blockIdx.y * late->dst_stride;
   // digit-reverse mid: mid = e_2 * 2^(l_3+..+l_{P-1}) + ... + e_{P-1}; output wants e_2 lowest.
   uint32_t mid_out = 0, shift_out = 0, rem = midbits;
   for (uint32_t i = 1; i + 1 < P; i++) {
-    rem -= plan.l[i];
-    const uint32_t digit = (mid >> rem) & ((1u << plan.l[i]) - 1u);
+    const uint32_t li = late->plan.l[i];
+    rem -= li;
+    const uint32_t digit = (mid >> rem) & ((1u << li) - 1u);
     mid_out |= digit << shift_out;
-    shift_out += plan.l[i];
+    shift_out += li;
   }
   const size_t obase = ((size_t)mid_out << l1) + e1_0;
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
@@ -362,14 +403,8 @@ __device__ __forceinline__ void ntt_pass_last_body(const fr_t* __restrict__ src,
     store_fr(&dst[doff + obase + ((size_t)e << (k - l)) + c], fr29_to_sat_canonical(v));
   }
 }
-__global__ void __launch_bounds__(512) ntt_pass_last(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
-                                                     size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw, uint32_t tile0) {
-  ntt_pass_last_body<false>(src, dst, src_stride, dst_stride, plan, small_tw, tile0);
-}
-__global__ void __launch_bounds__(256, 3) ntt_pass_last_swz(const fr_t* __restrict__ src, fr_t* __restrict__ dst, size_t src_stride,
-                                                            size_t dst_stride, NttPlan plan, const tw29_t* __restrict__ small_tw, uint32_t tile0) {
-  ntt_pass_last_body<true>(src, dst, src_stride, dst_stride, plan, small_tw, tile0);
-}
+__global__ void __launch_bounds__(512) ntt_pass_last(NttLastArgs a) { ntt_pass_last_body<false>(a); }
+__global__ void __launch_bounds__(256, 3) ntt_pass_last_swz(NttLastArgs a) { ntt_pass_last_body<true>(a); }
 
 // ---- element-wise helpers used by the Polynomial layer (src/polynomial.rs) -------------------------
 // op: 0 a+b, 1 a-b, 2 a*b (pointwise), with broadcast of a single scalar when nb == 1 is not done here.

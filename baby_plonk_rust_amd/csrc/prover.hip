@@ -290,18 +290,21 @@ static hipError_t copy_to_member(bp_ctx* m, fr_t* dst, const fr_t* src, int src_
 // the leader's tables over g <w_4n>, so a share is gathered there (strided) and copied to its member; the s_j^i / s_j^-i tables are
 // computed on the member.  The first 2 members (groups of 2 or 3) take two cosets each, the first 4 (groups of 4 and more) one.
 int circuit_split_build(bp_ctx* ctx, CircuitEntry& e) {
-  const size_t R = ctx->members.size();
-  if (R < 2) return BP_OK;
+  // experiment (BP_PROVE_COSET_ONE=1): ONE device takes all four cosets itself -- four size-n coset transforms per
+  // polynomial instead of one zero-padded size-4n transform; measured in profiles/r06_round3_coset_one_gpu_ab.txt
+  const bool one_gpu = ctx->members.size() < 2 && knob_u32("BP_PROVE_COSET_ONE", 0, 0, 1) == 1;
+  const size_t R = one_gpu ? 1 : ctx->members.size();
+  if (R < 2 && !one_gpu) return BP_OK;
   const uint32_t k = e.log_n;
   const size_t n = (size_t)1 << k, N = 4 * n;
-  const uint32_t used = R >= 4 ? 4 : 2, per = 4 / used;
+  const uint32_t used = one_gpu ? 1 : (R >= 4 ? 4 : 2), per = 4 / used;
   const fr_t g = from_u64(COSET_GEN), w4n = root_of_unity(N);
   fr_t* tmp;
   BP_TRY(ws_get(ctx, "prove.split_tmp", 10 * n * sizeof(fr_t), (void**)&tmp));
   const unsigned blocks = (unsigned)((n + 255) / 256);
   for (uint32_t r = 0; r < used; r++) {
     CosetShare sh;
-    bp_ctx* m = ctx->members[r];
+    bp_ctx* m = one_gpu ? ctx : ctx->members[r];
     sh.member = m;
     sh.first = r * per;
     sh.count = per;

@@ -118,3 +118,21 @@ void hc_fr29_radix4(uint32_t* out, const uint32_t* a_in, const uint32_t* w_in, i
 }
 void hc_fr29_roundtrip(uint32_t* r, const uint32_t* a_in) { fr_t a; memcpy(&a, a_in, 32); fr_t z = fr29_to_sat_canonical(fr29_from_sat(a)); memcpy(r, &z, 32); }
 }
+
+// ---- digit radix of fixed-base MSM tables (msm_digits.hpp): the host's choice and the kernels' digit cutter, on the CPU ----
+#include "../../baby_plonk_rust_amd/csrc/msm_digits.hpp"
+extern "C" {
+// out[0] = R (0: power-of-two windows), out[1..8] = m, out[9..16] = bias
+void hc_radix_info(uint32_t* out, uint32_t c, uint32_t W) {
+  const MsmRadix r = msm_radix_compute(c, W);
+  out[0] = r.R;
+  for (int i = 0; i < 8; i++) { out[1 + i] = r.m[i]; out[9 + i] = r.bias[i]; }
+}
+// digits[w] (int32, w < W) of the 8-limb integer k for the radix of (c, W); returns 1 when the cutter accepted k, 0 when it emitted nothing
+int hc_radix_digits(int32_t* digits, const uint32_t* k, uint32_t c, uint32_t W) {
+  const MsmRadix r = msm_radix_compute(c, W);
+  if (!r.R) return -1;
+  for (uint32_t w = 0; w < W; w++) digits[w] = 0x7fffffff;
+  return msm_radix_digits(k, r.R, r.m, r.bias, W, [&](uint32_t w, int32_t d) { digits[w] = d; }) ? 1 : 0;
+}
+}

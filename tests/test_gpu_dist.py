@@ -216,6 +216,8 @@ def _comm_body(q):
     # of the all-gather): BP_ERR_COMM, the communicator aborted -- not a stall; a new communicator works afterwards
     big = ctx.srs_generate_progression(1 << 21, a, d)
     sc_big = O.splitmix_scalars(1 << 21, 0xB16)
+    want_big = M.enc96(M.ec_mul(O.dot_progression(sc_big, a, d)))
+    assert ctx.msm_allgather(big, sc_big) == want_big                 # (first call at this size: workspaces grow, which waits for the stream inside the launch)
     ctx.comm_set_timeout_ms(1)
     try:
         ctx.msm_allgather(big, sc_big)
@@ -227,7 +229,7 @@ def _comm_body(q):
     ctx.synchronize()
     ctx.comm_set_timeout_ms(120000)
     ctx.comm_init_rank(bp.Context.comm_unique_id(), 0, 1)
-    assert ctx.msm_allgather(big, sc_big) == M.enc96(M.ec_mul(O.dot_progression(sc_big, a, d)))
+    assert ctx.msm_allgather(big, sc_big) == want_big
     ctx.comm_destroy()
     assert ctx.comm_info() == (0, 0)
     ctx.comm_init_rank(bp.Context.comm_unique_id(), 0, 1)             # and again after a destroy
@@ -277,7 +279,9 @@ def _missing_rank_worker(q):
         import traceback
         q.put(traceback.format_exc())
     finally:
-        os._exit(0)            # the parked helper thread sits in RCCL's bootstrap: leave without running RCCL's static destructors
+        q.close()
+        q.join_thread()        # the answer is on its way to the parent (Queue.put only hands it to a feeder thread) ...
+        os._exit(0)            # ... before this: the parked helper thread sits in RCCL's bootstrap, so leave without running RCCL's static destructors
 
 
 def test_comm_init_is_bounded_when_a_rank_never_arrives():

@@ -9,8 +9,10 @@ FETCH.csv / WRITE.csv are the *_counter_collection.csv files of two separate run
 Counter values are KB per dispatch.  Corrections (MI355X_MICROARCH.md, HBM section, calibrated in round 1 on known byte counts):
 FETCH_SIZE tallies a 128-B coalesced read request at 64 B, so kernels that stream 16 B per lane in >= 128-B runs are doubled;
 64-B runs (the strided NTT pass of 2^19: 2^10 x 2 columns) are counted exactly; WRITE_SIZE is exact.  The gathers of msm_accumulate
-(7 x 16 B per lane from random 112-B points in 128-B slots) are neither of the guide's calibrated cases: factor 1 is applied, which makes the
-reported traffic a LOWER bound -- the true figure lies between 1x and 2x of it (fetch_factor_range)."""
+(7 x 16 B per lane from random 112-B points in 128-B slots) are neither of the guide's calibrated cases; round 6 calibrated them on a known
+byte count (tools/ubench_gather.hip, profiles/r06_fetch_gather_calibration.txt): FETCH_SIZE shows 0.514 of the 128-byte lines such a gather
+pulls, so the counter is multiplied by GATHER_FETCH_FACTOR = 1.944 (read from that file; rounds 1-5 reported the raw counter as a lower
+bound with a 1x..2x range)."""
 import argparse
 import collections
 import csv
@@ -19,6 +21,16 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gather_fetch_factor():
+    """the measured factor of the 7 x dwordx4 gather (profiles/rNN_fetch_gather_calibration.txt, newest round), and the file it came from"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fetch_gather_calibration.txt")), reverse=True):
+        m = re.search(r"^gather<7>.*multiply the counter by ([0-9.]+)", open(path).read(), flags=re.M)
+        if m:
+            return float(m.group(1)), os.path.basename(path)
+    raise SystemExit("no profiles/rNN_fetch_gather_calibration.txt: run tools/ubench_gather under rocprofv3 --pmc FETCH_SIZE first")
 
 
 def per_kernel(path, counter):
@@ -60,12 +72,13 @@ def main():
 
     f, w = mean_big("msm_accumulate<2>", fetch), mean_big("msm_accumulate<2>", write)
     if f is not None and w is not None:
+        factor, cal = gather_fetch_factor()
         out["msm_accumulate_%s_c%d%s" % (args.tag, args.window_bits, "_tables" if args.tables else "")] = {
-            "fetch_kb_raw": f, "fetch_factor": 1, "fetch_factor_range": [1, 2], "write_kb": w, "hbm_bytes_per_launch": int((f + w) * 1024),
-            "hbm_bytes_per_launch_upper": int((2 * f + w) * 1024),
+            "fetch_kb_raw": f, "fetch_factor": factor, "fetch_factor_source": "profiles/" + cal, "write_kb": w,
+            "hbm_bytes_per_launch": int((f * factor + w) * 1024),
             "algorithmic_bytes_per_launch": 128 << log_n, "source": src,
-            "note": "one 112-B point (in its 128-B slot, one cache line) gathered per (scalar, window): algorithmic W x 112 B; lower bound (scattered 7 x dwordx4 gathers are "
-                    "uncalibrated: between 1x and 2x of FETCH_SIZE); integer-issue bound kernel"}
+            "note": "one 112-B point (in its 128-B slot, one cache line) gathered per (scalar, window): FETCH_SIZE x %.3f (the factor measured for "
+                    "exactly this access shape on a known byte count) + WRITE_SIZE; integer-issue bound kernel" % factor}
     passes, total = {}, 0.0
     for name in ("ntt_pass_strided", "ntt_pass_last", "ntt_small"):
         f, w = mean_big(name, fetch), mean_big(name, write)

@@ -31,3 +31,5 @@ for i in range(args.reps + 1):
     blob = prover.prove_device(wit[0].data_ptr(), wit[1].data_ptr(), wit[2].data_ptr(), None, blinders)
     print("prove 2^%d: %.2f ms  rounds %s" % (args.log_n, 1e3 * (time.perf_counter() - t0),
                                               ["%.2f" % r for r in prover.last_stats()["round_ms"]]), flush=True)
+import hashlib
+print("proof sha256 %s" % hashlib.sha256(blob).hexdigest()[:16], flush=True)
