@@ -279,8 +279,9 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   const uint32_t W = plan.W, B = plan.B, total = plan.total, Wr = table_c ? J : W;   // Wr: bucket sets left after accumulation
   const uint64_t max_entries = (uint64_t)W * n * J;
   const uint64_t n_chunks = (max_entries + plan.chunk - 1) / plan.chunk;
-  // bucket reduction: running sums per window (msm_reduce), or (tables: one bucket set) the bit-plane tree
-  const uint32_t blocks_per_window = table_c ? 0 : ((B + plan.seg - 1) / plan.seg + 255) / 256;
+  // bucket reduction: the bit-plane tree over one bucket set (tables) or over the forest of W bucket sets (table-free); the running sums per
+  // window of rounds 1-4 (msm_reduce: blocks_per_window, plan.seg) exist in the experiment build only (BP_MSM_REDUCE=1)
+  const uint32_t blocks_per_window = (!EXPERIMENT_BUILD || table_c) ? 0 : ((B + plan.seg - 1) / plan.seg + 255) / 256;
   // Bucket reduction without tables (W bucket sets of 2^(c-1) buckets): the same bit-plane tree as with tables, over a forest of W trees
   // (round 5; rounds 1-4 ran segmented running sums per window, msm_reduce: a dependent chain of ~46 additions per lane, 256 VGPRs + spills,
   // 0.57 ms at 2^20 points -- kept in the experiment build as BP_MSM_REDUCE=1 for the A/B), then two levels of the Horner form over each
@@ -557,8 +558,9 @@ int msm_launch_many(bp_ctx* ctx, const g1_affine28* d_points28, uint32_t J, cons
   hipLaunchKernelGGL(msm_fixup_long, dim3(512), dim3(256), 256 * sizeof(proj28_slot), st, offsets, plan, bucket_sum, partial,
                      long_count, long_list, long_cap, long_scratch, long_ticket);
   if (!reduce_running) {
-    // The tree over the B = 2^(c-1) buckets, level by level.  A level with at least PLANES_WIDE_MIN additions is throughput
-    // bound: one addition per lane through HBM (msm_planes_level; only windows wider than 17 bits have such levels).  The rest
+    // The tree over the `total` leaves (tables: B = 2^(c-1) buckets, J B for a batch; table-free: the forest of W trees, W B leaves),
+    // level by level.  A level with at least PLANES_WIDE_MIN additions is throughput bound: one addition per lane through HBM
+    // (msm_planes_level01 / msm_planes_level: six such levels at 2^19 leaves, seven for the table-free forest of 16 x 2^15).  The rest
     // is latency bound: up to PLANES_STEP_LOG levels per launch inside workgroups, cooperative additions (msm_planes_step).
     // A node of 2^k buckets carries k + 1 values; the two ping-pong buffers hold at most B values (level 1).
     const uint32_t levels = plan.c - 1;               // >= 1 (make_plan keeps c >= 2)

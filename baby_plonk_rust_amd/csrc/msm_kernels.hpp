@@ -1056,7 +1056,9 @@ msm_accumulate(const g1_affine28* __restrict__ points, const uint32_t* __restric
   uint32_t g = bucket_of(offsets, total, p0);
   // (Round 6 tried to hand this bucket to msm_fixup_edges, which bisects for the same position again: ONE 4-byte store per lane here,
   // before the loop, cost the kernel 5 % -- 1.93 -> 2.03 ms at 2^20, 0.194 -> 0.207 at 2^16, three alternating rounds on one box -- against
-  // 3 us saved there: profiles/r06_tail_ab.txt.  The store shares the loop's vmcnt counter with the gathers.)
+  // 3 us saved there.  Also tried: the loop below re-ordered so that the flush holds no load (offsets[g + 3] fetched an iteration ahead)
+  // and the compiler's wait behind the flush -- a vmcnt(0), i.e. a wait for the flush's own stores in 93 % of the iterations -- disappears:
+  // 196 registers instead of 232 and 1.5-3 % SLOWER at 2^16, 2^20 and 2^24.  Both records: profiles/r06_tail_ab.txt.)
   uint32_t g_start = offsets[g], g_end = offsets[g + 1];
   uint32_t g_end2 = g + 2 <= total ? offsets[g + 2] : M;
   uint32_t run_start = p0;

@@ -210,9 +210,9 @@ int ntt_run_part(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batc
       sa.small_tw = small;
       sa.tile0 = first;
       sa.h = tab->h;
-      sa.dst = tmp;
+      sa.dst = (decltype(sa.dst))tmp;
       sa.dst_stride = N;
-      sa.tw_lo = tab->lo; sa.tw_hi = hi; sa.tw_full = tab->full[i];
+      sa.tw_lo = (decltype(sa.tw_lo))tab->lo; sa.tw_hi = (decltype(sa.tw_hi))hi; sa.tw_full = (decltype(sa.tw_full))tab->full[i];
       hipLaunchKernelGGL(swizzled(l, cl) ? ntt_pass_strided_swz : ntt_pass_strided, dim3(count, (unsigned)batch), dim3(pass_threads(l, cl)), lds, st, sa);
     }
     if (phase != 0) {
@@ -226,7 +226,7 @@ int ntt_run_part(bp_ctx* ctx, fr_t* d_data, uint32_t k, int inverse, size_t batc
       la.small_tw = small;
       la.tile0 = first;
       la.plan = plan;
-      la.dst = d_data;
+      la.dst = (decltype(la.dst))d_data;
       la.dst_stride = stride;
       hipLaunchKernelGGL(swizzled(l, cl) ? ntt_pass_last_swz : ntt_pass_last, dim3(count, (unsigned)batch), dim3(pass_threads(l, cl)), lds, st, la);
     }

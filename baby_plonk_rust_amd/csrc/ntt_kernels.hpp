@@ -279,6 +279,15 @@ __global__ void __launch_bounds__(256) ntt_make_pass_table(const tw29_t* __restr
 // butterflies, behind an opaque barrier the compiler cannot hoist them over: rounds 2-5 kept all fourteen arguments in scalar
 // registers through the whole pass, which put every ntt_pass_* at the 106-SGPR ceiling with 4-6 spilled and a (never used) 36-byte
 // scratch frame per lane.
+// (a pointer read back from the kernarg segment would be a GENERIC pointer to the compiler -- flat_load / flat_store, which also tie up
+// the LDS counter; the device pass therefore sees the drain-phase pointers typed as global memory, the host pass as plain pointers: same bytes)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BP_GLOBAL_PTR(T) T __attribute__((address_space(1)))*
+#define BP_KERNARG_PTR(T) const T __attribute__((address_space(4)))*
+#else
+#define BP_GLOBAL_PTR(T) T*
+#define BP_KERNARG_PTR(T) const T*
+#endif
 struct NttStridedArgs {
   const fr_t* src;
   size_t src_stride;
@@ -286,15 +295,17 @@ struct NttStridedArgs {
   const tw29_t* small_tw;
   uint32_t tile0, h;             // tile0: first tile of this launch (a member of a group context runs a slice of the tiles)
   // drain phase
-  fr_t* dst;
+  BP_GLOBAL_PTR(fr_t) dst;
   size_t dst_stride;
-  const tw29_t *tw_lo, *tw_hi, *tw_full;
+  BP_GLOBAL_PTR(const tw29_t) tw_lo;
+  BP_GLOBAL_PTR(const tw29_t) tw_hi;
+  BP_GLOBAL_PTR(const tw29_t) tw_full;
 };
 template <class A>
-__device__ __forceinline__ const A* ntt_late_args() {
+__device__ __forceinline__ BP_KERNARG_PTR(A) ntt_late_args() {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const A* p = (const A*)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(p));    // the loads through p stay behind this point
+  BP_KERNARG_PTR(A) p = (BP_KERNARG_PTR(A))__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));    // the (scalar) loads through p stay behind this point
   return p;
 #else
   return nullptr;                // (host pass of the compiler: never executed)
@@ -325,22 +336,43 @@ __device__ __forceinline__ void ntt_pass_strided_body(const NttStridedArgs& a) {
   lds_fill_stage_twiddles(tw, l, small_tw);
   __syncthreads();
   lds_ntt_dif<SWZ>(tile, tstride, tw, small_tw, l, cl, CP);
-  const NttStridedArgs* late = ntt_late_args<NttStridedArgs>();
-  fr_t* dst = late->dst;
-  const tw29_t* __restrict__ tw_full = late->tw_full;
+  BP_KERNARG_PTR(NttStridedArgs) late = ntt_late_args<NttStridedArgs>();
+  fr_t* dst = (fr_t*)late->dst;
+  const tw29_t* __restrict__ tw_full = (const tw29_t*)late->tw_full;
+  const tw29_t* __restrict__ tw_lo = (const tw29_t*)late->tw_lo;
+  const tw29_t* __restrict__ tw_hi = (const tw29_t*)late->tw_hi;
   const size_t base = ((size_t)hi << mlog) + r0, doff = (size_t)blockIdx.y * late->dst_stride;
   const uint32_t tshift = k - mlog;                 // w_M^x = w_N^(x << tshift)
+  if (tw_full) {                                               // precomputed w_M^(e r): one product per element (uniform branch)
+    // The inter-pass twiddles of up to FOUR of a lane's elements are requested together, ahead of the products that use them (a lane
+    // drains L C / lanes = 2 .. 4 elements; round 5 requested each twiddle right in front of its product: a memory latency per element,
+    // the previous element's store in front of it on the same counter)
+    for (uint32_t x0 = threadIdx.x; x0 < L * C; x0 += 4 * blockDim.x) {
+      fr29 w[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {                        // (unconditional: an element beyond the tile re-reads the lane's first twiddle)
+        const uint32_t xu = x0 + u * blockDim.x, x = xu < L * C ? xu : x0;
+        w[u] = load_tw29(&tw_full[((size_t)(x >> cl) << s) + r0 + (x & (C - 1))]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t x = x0 + u * blockDim.x;
+        if (x < L * C) {
+          const uint32_t c = x & (C - 1), e = x >> cl;
+          fr29 v = fr29_mul(lds_ld29(tile, tstride, tile_at<SWZ>(bitrev(e, l), c, CP)), w[u]);
+          // dst is the transform's own intermediate buffer: the value (< 2q < 2^256 after the product) is only packed, not brought
+          // below q -- the next pass accepts anything below 2q; the last pass writes canonical residues
+          store_fr(&dst[doff + base + ((size_t)e << s) + c], fr29_pack(v));
+        }
+      }
+    }
+    return;
+  }
   for (uint32_t x = threadIdx.x; x < L * C; x += blockDim.x) {
     const uint32_t c = x & (C - 1), e = x >> cl;
     fr29 v = lds_ld29(tile, tstride, tile_at<SWZ>(bitrev(e, l), c, CP));
-    if (tw_full) {                                             // precomputed w_M^(e r): one product (uniform branch)
-      v = fr29_mul(v, load_tw29(&tw_full[((size_t)e << s) + r0 + c]));
-    } else {
-      const uint64_t E = ((uint64_t)e * (r0 + c)) << tshift;
-      v = fr29_mul(v, twiddle_lookup(late->tw_lo, late->tw_hi, late->h, E));   // tw_hi may carry the folded N^-1 (first pass of an inverse)
-    }
-    // dst is the transform's own intermediate buffer: the value (< 2q < 2^256 after the product) is only packed, not brought
-    // below q -- the next pass accepts anything below 2q; the last pass writes canonical residues
+    const uint64_t E = ((uint64_t)e * (r0 + c)) << tshift;
+    v = fr29_mul(v, twiddle_lookup(tw_lo, tw_hi, late->h, E));   // tw_hi may carry the folded N^-1 (first pass of an inverse)
     store_fr(&dst[doff + base + ((size_t)e << s) + c], fr29_pack(v));
   }
 }
@@ -359,7 +391,7 @@ struct NttLastArgs {
   uint32_t tile0;
   NttPlan plan;
   // drain phase
-  fr_t* dst;
+  BP_GLOBAL_PTR(fr_t) dst;
   size_t dst_stride;
 };
 template <bool SWZ>
@@ -384,8 +416,8 @@ __device__ __forceinline__ void ntt_pass_last_body(const NttLastArgs& a) {
   lds_fill_stage_twiddles(tw, l, small_tw);
   __syncthreads();
   lds_ntt_dif<SWZ>(tile, tstride, tw, small_tw, l, cl, CP);
-  const NttLastArgs* late = ntt_late_args<NttLastArgs>();
-  fr_t* __restrict__ dst = late->dst;
+  BP_KERNARG_PTR(NttLastArgs) late = ntt_late_args<NttLastArgs>();
+  fr_t* __restrict__ dst = (fr_t*)late->dst;
   const size_t doff = (size_t)blockIdx.y * late->dst_stride;
   // digit-reverse mid: mid = e_2 * 2^(l_3+..+l_{P-1}) + ... + e_{P-1}; output wants e_2 lowest.
   uint32_t mid_out = 0, shift_out = 0, rem = midbits;

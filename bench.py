@@ -81,6 +81,7 @@ def parse_args(argv=None):
                                                                   "stuck in and exits non-zero (the lines of the finished legs are out by then); 0 = no watchdog")
     ap.add_argument("--comm-timeout-ms", type=int, default=120000, help="bound of every wait behind a library collective and of ncclCommInitRank "
                                                                          "(bp_comm_set_timeout_ms): a missing or stuck rank is BP_ERR_COMM, not a stall")
+    ap.add_argument("--rehearse-hang-after", default="", help=argparse.SUPPRESS)     # tests: the LAST rank stops taking part after the named leg
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the N > 1 control flow on a box with fewer GPUs than ranks)")
     return ap.parse_args(argv)
@@ -553,6 +554,11 @@ def main():
         progress["leg"], progress["t"] = leg, time.monotonic()
         if use_dist:
             emit(final=False)
+        if use_dist and args.rehearse_hang_after == leg and rank == world - 1 and world > 1:
+            # rehearsal of a rank that stops taking part (tests/test_gpu_dist.py): the other ranks run into their next collective and stay there;
+            # the watchdog of every rank names the leg and ends the rank, and the lines printed so far are what the caller keeps
+            while True:
+                time.sleep(3600)
 
     def emit(final):
         per_rank = gather_objects({"rank": rank, "device": dev_index, "weak_accumulate_ms": head["acc_ms"], "weak_device_ms": head["dev_ms"],

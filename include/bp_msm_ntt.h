@@ -127,7 +127,9 @@ int  bp_srs_free(bp_ctx* ctx, uint64_t srs_handle);
  * src/setup.rs:7-10): T[w][i] = 2^(window_bits * w) * P_i for every window w, affine, resident in HBM
  * (windows x srs_len x 128 bytes -- a 112-byte point per 128-byte cache line: 1.7 GB at 2^20 points, 28 GB at 2^24).  With tables every window of an
  * MSM feeds one shared bucket set, so the bucket reduction and the Horner epilogue shrink from `windows`
- * passes to one; results are the same group element.  window_bits: 0 = chosen from srs_len (16 below 2^20 points, 20 -- thirteen
+ * passes to one; results are the same group element.  From 21-bit windows the rows are R^w * P_i for a digit radix R that need not
+ * be a power of two (12 windows of 22 bits cover 264 bits for 255-bit scalars: R = 0x288000 fills 1.33 M buckets instead of 2.1 M;
+ * csrc/msm_digits.hpp) -- invisible at this boundary, same bytes out.  window_bits: 0 = chosen from srs_len (16 below 2^20 points, 20 -- thirteen
  * windows -- from 2^20 points, 22 from 2^24), BP_SRS_TABLES_OFF = drop the tables, else 4..24 (above 16 the bucket sort is partitioned).  MSMs shorter than 2^window_bits / 8 scalars keep
  * using the table-free path.  The reference has no counterpart (its MSM recomputes from the raw points).
  * Memory budget (hipMemGetInfo per device; the bytes of the tables this SRS holds now count as free): window_bits = 0 never fails

@@ -98,6 +98,22 @@ def test_bench_self_launches_two_ranks():
     assert line1["n_gpus"] == 1 and line1["strong_scaling"]["result_sha"] == st["result_sha"]
 
 
+def test_bench_keeps_the_finished_legs_when_a_rank_stops_taking_part():
+    """VERDICT r05 #1c: the first N > 1 run must not be losable.  Rehearsal (gloo, two ranks on this card): rank 1 stops after the NTT leg;
+    rank 0 runs into the next collective and stays there; the watchdog ends the ranks after --leg-timeout, the parent exits non-zero --
+    and the COMPLETE lines of the legs that did finish (weak MSM, NTT) have been relayed and are what the caller keeps."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "14", "--ntt-log-n", "14",
+           "--strong-log-n", "15", "--prove-log-n", "0", "--backend", "gloo", "--skip-cpu", "--skip-group-legs", "--leg-timeout", "25",
+           "--rehearse-hang-after", "ntt"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode != 0, out.stdout[-1000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert [l["legs_finished"] for l in lines] == [["weak_msm"], ["weak_msm", "ntt"]] and all(l["provisional"] for l in lines), out.stdout[-2000:]
+    assert lines[-1]["value"] > 0 and lines[-1]["n_gpus"] == 2 and lines[-1]["ntt"]["value"] > 0 and "roofline" in lines[-1]
+    assert "giving up" in out.stderr and "'ntt'" in out.stderr, out.stderr[-2000:]
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     import torch
     n = torch.cuda.device_count()
