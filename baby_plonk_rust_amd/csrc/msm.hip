@@ -191,7 +191,8 @@ int srs_tables_run(bp_ctx* ctx, const g1_affine* d_points, const g1_affine28* d_
   BP_HIP(ctx, hipMalloc((void**)&t, (size_t)W * (n ? n : 1) * sizeof(g1_affine28)));
   if (n) {
     BP_HIP(ctx, hipMemcpyAsync(t, d_points28, n * sizeof(g1_affine28), hipMemcpyDeviceToDevice, ctx->stream));
-    hipLaunchKernelGGL(srs_window_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_points28, n, (c & MSM_NAF_FLAG) ? 1u : c, W, radix, t);
+    if (radix) hipLaunchKernelGGL(srs_window_tables<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_points28, n, c, W, radix, t);
+    else hipLaunchKernelGGL(srs_window_tables<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_points28, n, (c & MSM_NAF_FLAG) ? 1u : c, W, 0u, t);
   }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = stream_wait(ctx->stream);

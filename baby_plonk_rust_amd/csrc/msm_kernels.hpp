@@ -975,6 +975,8 @@ __device__ __forceinline__ M28 one_m28() {
 }
 // radix != 0: row w = radix^w P (MsmPlan::radix) -- one small scalar multiplication per row (20 doublings + 3 additions for R = 0xD0000)
 // instead of c doublings.
+// (RADIX as a template parameter: with the double-and-add in the same body the power-of-two build went from 208 to 328 registers and 35.6 -> 38.0 ms at 2^20 points)
+template <bool RADIX>
 __global__ void __launch_bounds__(256) srs_window_tables(const g1_affine28* __restrict__ in28, size_t n, uint32_t c, uint32_t W, uint32_t radix,
                                                          g1_affine28* __restrict__ table) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -996,7 +998,7 @@ __global__ void __launch_bounds__(256) srs_window_tables(const g1_affine28* __re
   for (uint32_t w0 = 1; w0 < W; w0 += TABLE_GROUP) {
     const uint32_t cnt = W - w0 < (uint32_t)TABLE_GROUP ? W - w0 : (uint32_t)TABLE_GROUP;
     for (uint32_t j = 0; j < cnt; j++) {
-      if (radix) g1_mul_small28(p, p, radix, 32 - __clz(radix));
+      if (RADIX) g1_mul_small28(p, p, radix, 32 - __clz(radix));
       else
         for (uint32_t d = 0; d < c; d++) g1_double28(p, p);
       row[j] = p;
