@@ -322,6 +322,52 @@ def test_table_width_sweep_on_the_shipped_library(ctx, c):
         ctx.srs_free(h)
 
 
+# (width, log2 points, windows, radix): the widths that take radix-R digits (csrc/msm_digits.hpp: from 21 bits), at sizes where an MSM really uses the
+# tables (8 n >= 2^c).  The values are the ones tests/test_radix_digits.py checks on the CPU.
+RADIX_CASES = [(21, 18, 13, 0xD0000), (22, 19, 12, 0x288000), (23, 20, 12, 0x288000), (24, 21, 11, 0x9C0000)]
+
+
+@pytest.mark.parametrize("c,log_n,W,R", RADIX_CASES)
+def test_radix_r_digits_through_the_tables(ctx, c, log_n, W, R):
+    """Round 6: table widths of 21 bits and more cut the scalars in a radix R that is not a power of two (T[w][i] = R^w P_i).  Scalars that sit ON the
+    digit boundaries of that radix -- multiples of R^j and their neighbours, digits of exactly +-R/2, the largest scalar -- spread over the vector
+    beside uniform ones, against the closed form sum_i s_i (a + i d) G (src/setup.rs:32-37 -> src/msm.rs:76-118: any bucket method yields the same element)."""
+    rnd = random.Random(0xAD1C5 + c)
+    n = (1 << log_n) + 37
+    a, d = rnd.randrange(1, Q), rnd.randrange(1, Q)
+    h = ctx.srs_generate_progression(n, a, d)
+    info = ctx.srs_precompute(h, c)
+    assert info["window_bits"] == c and info["windows"] == W
+    uni = O.splitmix_scalars(n, 0xAD1C5000 + c)
+    want_uni = M.enc96(M.ec_mul(oracle_dot(uni, a, d)))
+    assert ctx.msm(h, uni) == want_uni and ctx.msm_stats()["tables"] and ctx.msm_stats()["window_bits"] == c
+    edge = [0, 1, R // 2 - 1, R // 2, R // 2 + 1, R - 1, R, R + 1, Q - 1, Q - 2, Q // 2, 2 ** 254]
+    for j in range(1, W):
+        for t in (1, R // 2, R // 2 + 1, R - 1):
+            for e in (-1, 0, 1):
+                edge.append((t * R ** j + e) % Q)
+        edge.append(sum((R // 2) * R ** i for i in range(j + 1)) % Q)
+        edge.append(sum((R // 2 - 1) * R ** i for i in range(j + 1)) % Q)
+    mixed = uni.copy()
+    pos = rnd.sample(range(n), len(edge))
+    mixed[pos] = frs(edge)
+    assert ctx.msm(h, mixed) == M.enc96(M.ec_mul(oracle_dot(mixed, a, d))), (c, "edge scalars among uniform ones")
+    only = np.zeros((n, 4), dtype=np.uint64)                          # the edge scalars alone: everything else zero (no entries at all)
+    only[pos] = frs(edge)
+    assert ctx.msm(h, only) == M.enc96(M.ec_mul(oracle_dot(only, a, d))), (c, "edge scalars alone")
+    top = np.tile(bp.scalar_from_int(Q - 1), (n, 1))                  # every top digit at its maximum
+    sum_pts = (n * a + d * (n * (n - 1) // 2)) % Q
+    assert ctx.msm(h, top) == M.enc96(M.ec_mul((Q - 1) * sum_pts % Q)), (c, "q - 1 everywhere")
+    le = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in (5, Q - 1, 7)), dtype=np.uint8).reshape(-1, 32)
+    assert ctx.msm(h, le, fmt=bp.FR_BYTES_LE) == M.enc96(M.ec_mul((5 * a + (Q - 1) * (a + d) + 7 * (a + 2 * d)) % Q))       # (three scalars: the table-free path)
+    bad = np.tile(np.frombuffer((2 ** 256 - 1).to_bytes(32, "little"), dtype=np.uint8), (n, 1))           # not scalars: rejected, and no bucket index leaves the live range
+    with pytest.raises(bp.BpError) as ei:
+        ctx.msm(h, bad, fmt=bp.FR_BYTES_LE)
+    assert ei.value.code == -4
+    assert ctx.msm(h, uni) == want_uni                                # the context is intact afterwards
+    ctx.srs_free(h)
+
+
 @experiment            # every-position tables exist in the experiment build only (measured slower twice, DESIGN.md 4.4)
 @pytest.mark.parametrize("w,log_n", [(6, 9), (8, 12), (11, 13), (14, 15), (16, 16), (18, 17), (19, 17), (22, 17)])
 def test_every_position_tables_naf_digits(ctx, w, log_n):

@@ -266,6 +266,20 @@ def test_blob_records_one_gather_one_copy():
         ctx.msm_blobs_sum_device(eq.data_ptr(), 4, out.data_ptr())
         one = out.cpu().numpy().tobytes()
         assert bp.combine_blobs(one) == bp.combine_blobs(eq.cpu().numpy().tobytes()) == want
+    # Round 6: a POISONED record among the gathered ones (a rank whose MSM failed before the collective still takes part: header only, its
+    # error code and rank; capi_comm.hip) -- here rank 2 of four with BP_ERR_TOO_LARGE.  The device pre-sum carries it into the one record that
+    # travels to the host, the host-side combine of all records finds it too, and both report THAT code, never a sum without rank 2's share.
+    import struct
+    poisoned = eq.clone()
+    header = struct.pack("<7Ii2I", 0x424D5042, 0, 0, 0, 0, 0, 0, -10, 2, 0) + bytes(24)        # magic, c, Wr, n_planes, tables, status, entries, err, err_rank, quads, pad
+    assert len(header) == 64
+    poisoned[2, :64] = torch.frombuffer(bytearray(header), dtype=torch.uint8).to("cuda:0")
+    torch.cuda.synchronize()
+    ctx.msm_blobs_sum_device(poisoned.data_ptr(), 4, out.data_ptr())
+    for blob in (out.cpu().numpy().tobytes(), poisoned.cpu().numpy().tobytes()):
+        with pytest.raises(bp.BpError) as e:
+            bp.combine_blobs(blob)
+        assert e.value.code == -10
     # an empty shard contributes the identity; a corrupt record and a bad scalar are refused
     h = ctx.srs_generate_progression(10, a, d)
     rec = torch.zeros(_lib.MSM_BLOB_BYTES, dtype=torch.uint8, device="cuda:0")
